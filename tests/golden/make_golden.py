@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference, read-only).  Nothing of the
+reference travels: the fixtures are inputs/outputs (arrays), not source.
+
+Recipe: scratch cwd, import `transformers` before installing stubs,
+stub the absent third-party modules (librosa -> the reference's own vendored
+`mel_fn_librosa.mel`, torchcrepe, faiss), never instantiate `rvc.configs.config.Config`.
+Weights come from `rvc_amd.lib.synthetic` (seeded), loaded into the reference's own
+modules with load_state_dict, exactly as `rvc/infer/infer.py:464-485` does.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+"""
+import importlib.util
+import os
+import shutil
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+import transformers  # noqa: E402  (must precede the librosa stub)
+from transformers import HubertConfig, HubertModel  # noqa: E402
+
+sys.path.insert(0, os.path.join(REPO, "codename-rvc-fork-3_amd"))
+from rvc_amd.lib import synthetic as S  # noqa: E402
+
+# ---- scratch cwd + stubs -----------------------------------------------------------------------
+scratch = tempfile.mkdtemp(prefix="rvc_golden_")
+os.makedirs(os.path.join(scratch, "rvc", "models", "predictors"))
+os.makedirs(os.path.join(scratch, "rvc", "configs"))
+for f in os.listdir(os.path.join(REF, "rvc", "configs")):
+    if f.endswith(".json"):
+        shutil.copy(os.path.join(REF, "rvc", "configs", f), os.path.join(scratch, "rvc", "configs", f))
+torch.save(S.make_rmvpe_state_dict(0), os.path.join(scratch, "rvc", "models", "predictors", "rmvpe.pt"))
+os.chdir(scratch)
+sys.path.insert(0, REF)
+
+spec = importlib.util.spec_from_file_location(
+    "_melfn", os.path.join(REF, "rvc/lib/predictors/torchfcpe/mel_fn_librosa.py"))
+_melfn = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(_melfn)
+librosa = types.ModuleType("librosa")
+librosa.filters = types.ModuleType("librosa.filters")
+librosa.filters.mel = _melfn.mel
+librosa.feature = types.ModuleType("librosa.feature")
+sys.modules.update({"librosa": librosa, "librosa.filters": librosa.filters, "librosa.feature": librosa.feature,
+                    "torchcrepe": types.ModuleType("torchcrepe"), "faiss": types.ModuleType("faiss")})
+
+import rvc.infer.pipeline as ref_pipeline  # noqa: E402
+from rvc.infer.pipeline import Pipeline  # noqa: E402
+from rvc.lib.algorithm.synthesizers import Synthesizer  # noqa: E402
+from rvc.lib.predictors.RMVPE import MelSpectrogram, RMVPE0Predictor  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+class Cfg:
+    x_pad, x_query, x_center, x_max, device = 1, 6, 38, 41, "cpu"
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {name}.npz  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def build_net(cpt):
+    """rvc/infer/infer.py:464-485"""
+    net = Synthesizer(*cpt["config"], use_f0=True, text_enc_hidden_dim=768, vocoder=cpt["vocoder"])
+    del net.enc_q
+    r = net.load_state_dict(cpt["weight"], strict=False)
+    assert not r.missing_keys and not r.unexpected_keys, r
+    return net.float().eval()
+
+
+class BruteIndex:
+    """Exact stand-in for the faiss index (faiss is absent): float64 squared L2, ascending."""
+
+    def __init__(self, x):
+        self.x = np.asarray(x, dtype=np.float32)
+        self.ntotal = self.x.shape[0]
+
+    def reconstruct_n(self, a, n):
+        return self.x[a:a + n]
+
+    def search(self, q, k):
+        q64, x64 = q.astype(np.float64), self.x.astype(np.float64)
+        d = (q64 * q64).sum(1)[:, None] - 2 * q64 @ x64.T + (x64 * x64).sum(1)[None, :]
+        ix = np.argsort(d, axis=1, kind="stable")[:, :k]
+        return np.take_along_axis(d, ix, axis=1).astype(np.float32), ix.astype(np.int64)
+
+
+def main():
+    # 0. realistic inputs shipped by the reference (data files, logs/reference/*.npy)
+    for f in ("ref_feats", "ref_f0c", "ref_f0f"):
+        shutil.copy(os.path.join(REF, "logs", "reference", f + ".npy"), os.path.join(HERE, f + ".npy"))
+    ref_feats = np.load(os.path.join(HERE, "ref_feats.npy"))
+    ref_f0c = np.load(os.path.join(HERE, "ref_f0c.npy"))
+    ref_f0f = np.load(os.path.join(HERE, "ref_f0f.npy"))
+
+    # 1. butter coefficients + filtfilt (pipeline.py:23-28, 562)
+    x = S.synth_audio(4000, seed=3)
+    save("filtfilt", bh=ref_pipeline.bh, ah=ref_pipeline.ah, x=x,
+         y=ref_pipeline.signal.filtfilt(ref_pipeline.bh, ref_pipeline.ah, x))
+
+    vc = Pipeline(48000, Cfg())
+
+    # 2. segmentation / frame-count integers (pipeline.py:563-680) with a recording fake VC
+    rec = {}
+    for secs in (10, 30, 41, 45, 100):
+        calls = []
+
+        def fake_vc(model, net_g, sid, audio0, pitch, pitchf, index, big_npy, index_rate, version, protect):
+            n = audio0.shape[0]
+            F_ = (n - 400) // 320 + 1
+            T_ = min(n // 160, 2 * F_)
+            calls.append((n, pitch.shape[1], F_, T_))
+            return np.zeros(T_ * 480, dtype=np.float32)
+
+        def fake_f0(path, x_, p_len, *a, **k):
+            return np.ones(p_len + 1, dtype=int), np.zeros(p_len + 1)
+
+        vc.voice_conversion, vc.get_f0 = fake_vc, fake_f0
+        audio = S.synth_audio(16000 * secs, seed=secs)
+        out = vc.pipeline(None, None, 0, audio, 0, "rmvpe", "", 0, True, 3, 1, "v2", 0.5, 128, False, 1, None)
+        rec[f"segs_{secs}"] = np.array(calls, dtype=np.int64)
+        rec[f"outlen_{secs}"] = np.int64(out.shape[0])
+        print(f"  {secs:4d} s -> {calls} out {out.shape[0]}")
+    save("segmentation", **rec)
+    del vc.voice_conversion, vc.get_f0  # back to the class methods
+
+    # 3. f0 -> coarse ints (pipeline.py:388-410)
+    rng = np.random.default_rng(5)
+    f0 = np.concatenate([np.zeros(40), rng.uniform(30, 1500, 600), ref_f0f, np.array([50.0, 1100.0, 49.9, 1100.1])])
+    rec = {"f0": f0}
+    for shift in (0, 5, -7):
+        vc.model_rmvpe.infer_from_audio = lambda x_, thred=0.03: f0.copy()
+        coarse, f0bak = vc.get_f0("k", None, None, shift, "rmvpe", 3, 128, False, 1, None)
+        rec[f"coarse_{shift}"], rec[f"f0bak_{shift}"] = coarse.astype(np.int64), f0bak
+    save("f0_coarse", **rec)
+
+    # 4. RMVPE log-mel front end (RMVPE.py:342-417 at the :438 parameters)
+    mel_ex = MelSpectrogram(128, 16000, 1024, 160, None, 30, 8000)
+    a = torch.from_numpy(S.synth_audio(16000, seed=11)).float().unsqueeze(0)
+    save("logmel", audio=a.numpy(), mel=mel_ex(a, center=True).numpy(), mel_basis=mel_ex.mel_basis.numpy())
+
+    # 5. RMVPE network + decode (RMVPE.py:444-512)
+    pred = RMVPE0Predictor(os.path.join("rvc", "models", "predictors", "rmvpe.pt"), device="cpu")
+    audio = S.synth_audio(24000, seed=12)
+    with torch.no_grad():
+        mel = pred.mel_extractor(torch.from_numpy(audio).float().unsqueeze(0), center=True)
+        hidden = pred.mel2hidden(mel).squeeze(0).numpy()
+    save("rmvpe", audio=audio, hidden=hidden, f0=pred.infer_from_audio(audio, thred=0.03))
+
+    # 6. HuBERT (transformers.HubertModel, default config = HuBERT-base shape; call site pipeline.py:450)
+    hub = HubertModel(HubertConfig()).eval()
+    hsd = S.make_hubert_state_dict(1)
+    r = hub.load_state_dict({k: v for k, v in hsd.items() if not k.startswith("final_proj")}, strict=False)
+    assert not r.missing_keys and not r.unexpected_keys, r
+    wav = torch.from_numpy(S.synth_audio(16000, seed=13)).float().view(1, -1)
+    with torch.no_grad():
+        feats = hub(wav)["last_hidden_state"]
+    save("hubert", wav=wav.numpy(), feats=feats.numpy(), transformers_version=np.array(transformers.__version__))
+
+    # 7. retrieval blend (pipeline.py:497-507) over an exact index stand-in
+    big = S.synth_index(4096, seed=0)
+    q = (big[rng.integers(0, 4096, 64)] + rng.standard_normal((64, 768)).astype(np.float32) * 0.03).astype(np.float32)
+    idx = BruteIndex(big)
+    score, ix = idx.search(q, 8)
+    blended = vc._retrieve_speaker_embeddings(torch.from_numpy(q).unsqueeze(0), idx, big, 0.75)
+    save("knn", q=q, d2=score, ids=ix, blended=blended.numpy(), index_seed=np.int64(0), index_rows=np.int64(4096))
+
+    # 8. Synthesizer.infer per vocoder (synthesizers.py:223-260) on the reference's realistic inputs
+    T = 64
+    phone = torch.from_numpy(np.repeat(ref_feats, 2, axis=0)[:T]).unsqueeze(0)
+    pitch = torch.from_numpy(ref_f0c[:T].astype(np.int64)).unsqueeze(0)
+    pitchf = torch.from_numpy(ref_f0f[:T]).float().unsqueeze(0)
+    for tag, sr, voc in (("nsf48", 48000, "HiFi-GAN"), ("nsf40", 40000, "HiFi-GAN"), ("nsf32", 32000, "HiFi-GAN"),
+                         ("mrf48", 48000, "MRF HiFi-GAN"), ("refine48", 48000, "RefineGAN")):
+        cpt = S.make_synth_checkpoint(sr, voc, seed=0)
+        net = build_net(cpt)
+        torch.manual_seed(1234)
+        with torch.no_grad():
+            o, x_mask, (z, z_p, m_p, logs_p) = net.infer(phone, torch.tensor([T]), pitch, pitchf, torch.tensor([3]))
+        save(f"synth_{tag}", o=o[0, 0].numpy(), z=z[0].numpy(), z_p=z_p[0].numpy(), m_p=m_p[0].numpy(),
+             logs_p=logs_p[0].numpy(), seed=np.int64(1234), sid=np.int64(3), T=np.int64(T))
+        print(f"    {tag}: out rms {o.pow(2).mean().sqrt().item():.4f}")
+
+    # 9. whole Pipeline.pipeline (pipeline.py:509-694) on short clips
+    audio = S.synth_audio(24000, seed=21)
+    np.save(os.path.join(scratch, "fake.index.npy"), big)
+    ref_pipeline.faiss.read_index = lambda path: BruteIndex(big)
+    open(os.path.join(scratch, "fake.index"), "w").close()
+    for tag, sr, idx_rate, protect in (("nsf48", 48000, 0.75, 0.5), ("nsf40", 40000, 0.0, 0.33)):
+        cpt = S.make_synth_checkpoint(sr, "HiFi-GAN", seed=0)
+        net = build_net(cpt)
+        vcp = Pipeline(sr, Cfg())
+        torch.manual_seed(4321)
+        out = vcp.pipeline(hub, net, 2, audio.copy(), 2, "rmvpe", os.path.join(scratch, "fake.index"), idx_rate,
+                           True, 3, 1, "v2", protect, 128, False, 1, None)
+        save(f"pipeline_{tag}", audio=audio, out=out.astype(np.float32), seed=np.int64(4321), sid=np.int64(2),
+             pitch=np.int64(2), index_rate=np.float64(idx_rate), protect=np.float64(protect))
+        print(f"    pipeline {tag}: {out.shape[0]} samples rms {np.sqrt((out ** 2).mean()):.4f}")
+
+
+if __name__ == "__main__":
+    main()
+    shutil.rmtree(scratch, ignore_errors=True)
