@@ -1,0 +1,50 @@
+// Shared host/device helpers for librvc_amd (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+
+#include "rvc_amd.h"
+
+namespace rvc {
+
+// ---- error reporting across the C ABI -------------------------------------------------------------
+void set_error(const char *fmt, ...);
+int fail(const char *fmt, ...);  // sets the error, returns 1
+
+#define RVC_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) return ::rvc::fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                                 __FILE__, __LINE__);                         \
+    } while (0)
+
+#define RVC_LAUNCH_CHECK()                                                                    \
+    do {                                                                                      \
+        hipError_t _e = hipGetLastError();                                                    \
+        if (_e != hipSuccess) return ::rvc::fail("kernel launch failed: %s (%s:%d)",          \
+                                                 hipGetErrorString(_e), __FILE__, __LINE__);  \
+    } while (0)
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- device-side MFMA typedefs ---------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] * B[2x32], exact fp32 fma chain in k order.
+//   lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31];
+//   D register r of lane l is element (row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31).
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+}  // namespace rvc

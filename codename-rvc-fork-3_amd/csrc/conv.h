@@ -1,0 +1,44 @@
+// fp32 implicit-GEMM conv1d on the gfx950 matrix cores: shared by the decoder and the exported
+// rvc_conv1d_forward unit-test entry point.
+#pragma once
+#include "common.h"
+
+namespace rvc {
+
+// One launch computes, for every batch item b, GEMM rows m (output channels, or (phase, channel) pairs of a
+// transposed conv) and GEMM columns c (time):
+//   acc[m][c] = sum_{tap, ci} W[tap][ci][m] * act(X[ci][c + tap*dil - padl])        (zero outside [0, l_in))
+// where the input channels are the concatenation of two sources x1 (c1 channels, leaky slope1) and
+// x2 (c2 channels, leaky slope2), both [batch][c][l_in].
+// regular mode  (up_stride == 0): y[b][m][c]              = out_scale*(acc + bias[m] + res + accin)
+// scatter mode  (up_stride  > 0): y[b][m % c_out][c*s + m / c_out - up_pad] = acc + bias[m % c_out]
+struct ConvParams {
+    const float *x1 = nullptr; int c1 = 0; float slope1 = 1.f; int64_t x1_bstride = 0;
+    const float *x2 = nullptr; int c2 = 0; float slope2 = 1.f; int64_t x2_bstride = 0;
+    int64_t l_in = 0;                // row length of x1 (and of x2 unless l_in2 is set)
+    int64_t l_in2 = 0;               // row length of x2 (0 = same as l_in)
+    const float *w = nullptr;        // [KW][c1 + c2][m_total]
+    const float *bias = nullptr;     // [c_out] (+ b * bias_bstride)
+    int64_t bias_bstride = 0;
+    const float *res = nullptr;      // [batch][c_out][l_out], regular mode only
+    const float *accin = nullptr;    // [batch][c_out][l_out], regular mode only
+    float *y = nullptr;
+    int64_t y_bstride = 0;           // = c_out * l_out
+    int m_total = 0;
+    int c_out = 0;
+    int64_t n_cols = 0;
+    int64_t l_out = 0;
+    int kw = 1, dil = 1, padl = 0;
+    int up_stride = 0, up_pad = 0;
+    float out_scale = 1.f;
+    int batch = 1;
+};
+
+// picks the tile configuration from m_total; returns non-zero and sets the error on unsupported shapes
+int launch_conv(const ConvParams &p, hipStream_t stream);
+
+// host-side repacks (return freshly hipMalloc'ed device buffers)
+// regular conv weight [c_out][c_in][k] -> [k][c_in][c_out]
+int pack_conv_weight(const float *w_host, int c_out, int c_in, int k, float **out_dev);
+
+}  // namespace rvc

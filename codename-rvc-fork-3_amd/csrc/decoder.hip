@@ -1,0 +1,690 @@
+// K2 -- the vocoder ("dec" of Synthesizer, synthesizers.py:254-258) as a chain of launches on one stream:
+//   source module (sine + noise excitation)  -> har_source [B, L]
+//   conv_pre (+ speaker conditioning folded into a per-utterance bias)
+//   per stage: leaky -> ConvTranspose1d (polyphase GEMM) with noise_conv(har_source) folded in as extra
+//              input rows -> three parallel dilated ResBlocks, mean
+//   leaky(0.01) -> conv_post -> tanh
+// NSF: hifigan_nsf.py:173-207 + hifigan.py:156-228;  MRF: hifigan_mrf.py:339-366, 129-175.
+// All dense contractions go through conv.hip (fp32 MFMA implicit GEMM); this file holds the small
+// element-wise kernels, the weight repacks and the schedule.
+#include <map>
+#include <vector>
+
+#include "conv.h"
+
+namespace rvc {
+
+// ----------------------------------------------------------------------------------------------------------
+// small kernels
+// ----------------------------------------------------------------------------------------------------------
+
+// hifigan.py:172-177: carry[i] = fmod(cumsum_{i' < i}(fmod(f0[i']/sr*upp + 0.5, 1) - 0.5), 1).
+// torch's CPU cumsum accumulates in double and rounds every prefix to float; so does this.
+__global__ void nsf_carry_kernel(const float *__restrict__ f0, int64_t T, float sr, float upp, float *__restrict__ carry) {
+    if (threadIdx.x != 0) return;
+    const int64_t b = blockIdx.x;
+    const float *f = f0 + b * T;
+    float *c = carry + b * T;
+    double cum = 0.0;
+    c[0] = 0.f;
+    for (int64_t i = 0; i + 1 < T; ++i) {
+        const float last = __fmul_rn(__fdiv_rn(f[i], sr), upp);
+        const float rem = __fsub_rn(fmodf(__fadd_rn(last, 0.5f), 1.0f), 0.5f);
+        cum += (double)rem;
+        c[i + 1] = fmodf((float)cum, 1.0f);
+    }
+}
+
+// hifigan.py:186-226 + hifigan_nsf.py:50-51 for harmonic_num = 0
+__global__ void __launch_bounds__(256)
+nsf_source_kernel(const float *__restrict__ f0, const float *__restrict__ carry, const float *__restrict__ randn,
+                  int64_t T, int upp, float sr, float lin_w, float lin_b, float *__restrict__ har) {
+    const int64_t L = T * upp;
+    const int64_t b = blockIdx.y;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= L) return;
+    const int64_t i = t / upp;
+    const int j = (int)(t - i * upp);
+    const float f = f0[b * T + i];
+    const float r = __fdiv_rn(f, sr);
+    const float phase = __fadd_rn(__fmul_rn(r, (float)(j + 1)), carry[b * T + i]);
+    const float sine = __fmul_rn(sinf(__fmul_rn(6.2831853071795864769f, phase)), 0.1f);
+    const float uv = f > 0.f ? 1.f : 0.f;
+    const float amp = __fadd_rn(__fmul_rn(uv, 0.003f), __fmul_rn(1.f - uv, (float)(0.1 / 3)));
+    const float v = __fadd_rn(__fmul_rn(sine, uv), __fmul_rn(amp, randn[b * L + t]));
+    har[b * L + t] = tanhf(__fadd_rn(__fmul_rn(v, lin_w), lin_b));
+}
+
+// ---- MRF / RefineGAN sine generator (hifigan_mrf.py:129-175, refinegan.py:220-260) -------------------
+// rad = (f0*h/sr) % 1 is constant inside a frame (f0 is nearest-upsampled), so both sample-rate cumsums
+// reduce to per-frame prefixes (sequential, double, T elements) plus closed forms inside the frame.
+// Only implemented for piecewise-constant f0 (MRF); RefineGAN interpolates f0 linearly (TODO there).
+constexpr int MRF_MAX_DIM = 9;
+
+struct MrfSrcParams {
+    const float *f0; const float *rand_ini; const float *randn; float *har;
+    double *p1; double *p2; int *wraps; float *tot_unused;
+    int64_t T; int upp; int dim; float sr;
+    float lin_w[MRF_MAX_DIM]; float lin_b;
+};
+
+__device__ __forceinline__ float mrf_rad(float f0, int h, float sr) {
+    // f0_buf[..., h] = f0 * (h + 1) (fp32), rad = (f0_buf / sr) % 1
+    const float fh = (h == 0) ? f0 : __fmul_rn(f0, (float)(h + 1));
+    const float q = __fdiv_rn(fh, sr);
+    return q - floorf(q);  // torch remainder for a positive divisor
+}
+
+// pass 1: P1[b][h][i] = double prefix of rad over all samples before frame i (rand_ini added to sample 0)
+__global__ void mrf_prefix1_kernel(MrfSrcParams p) {
+    const int b = blockIdx.x, h = threadIdx.x;
+    if (h >= p.dim) return;
+    double cum = 0.0;
+    double *P1 = p.p1 + ((int64_t)b * p.dim + h) * p.T;
+    for (int64_t i = 0; i < p.T; ++i) {
+        P1[i] = cum;
+        const float rho = mrf_rad(p.f0[b * p.T + i], h, p.sr);
+        if (i == 0) {
+            const float r0 = __fadd_rn(rho, h == 0 ? 0.f : p.rand_ini[b * p.dim + h]);
+            cum += (double)r0 + (double)(p.upp - 1) * (double)rho;
+        } else {
+            cum += (double)p.upp * (double)rho;
+        }
+    }
+}
+
+__device__ __forceinline__ float mrf_tmp(const MrfSrcParams &p, const double *P1, int b, int h, int64_t i, int j) {
+    // tmp_over_one at sample (i, j): float(cumsum) % 1
+    const float rho = mrf_rad(p.f0[b * p.T + i], h, p.sr);
+    double s = P1[i];
+    if (i == 0) {
+        const float r0 = __fadd_rn(rho, h == 0 ? 0.f : p.rand_ini[b * p.dim + h]);
+        s += (double)r0 + (double)j * (double)rho;
+    } else {
+        s += (double)(j + 1) * (double)rho;
+    }
+    const float c = (float)s;
+    return c - floorf(c);
+}
+
+// pass 2: per frame, count the wrap events (tmp[t] - tmp[t-1] < 0); one wave per (b, h, frame)
+__global__ void __launch_bounds__(64) mrf_wraps_kernel(MrfSrcParams p) {
+    const int64_t i = blockIdx.x;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const double *P1 = p.p1 + ((int64_t)b * p.dim + h) * p.T;
+    int cnt = 0;
+    for (int j = threadIdx.x; j < p.upp; j += 64) {
+        if (i == 0 && j == 0) continue;  // cumsum_shift[:, 0] stays 0
+        const float cur = mrf_tmp(p, P1, b, h, i, j);
+        const float prev = (j == 0) ? mrf_tmp(p, P1, b, h, i - 1, p.upp - 1) : mrf_tmp(p, P1, b, h, i, j - 1);
+        if (__fsub_rn(cur, prev) < 0.f) ++cnt;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (threadIdx.x == 0) p.wraps[((int64_t)b * p.dim + h) * p.T + i] = cnt;
+}
+
+// pass 3: P2[b][h][i] = double prefix of (rad + shift) over all samples before frame i
+__global__ void mrf_prefix2_kernel(MrfSrcParams p) {
+    const int b = blockIdx.x, h = threadIdx.x;
+    if (h >= p.dim) return;
+    double cum = 0.0;
+    double *P2 = p.p2 + ((int64_t)b * p.dim + h) * p.T;
+    const int *W = p.wraps + ((int64_t)b * p.dim + h) * p.T;
+    for (int64_t i = 0; i < p.T; ++i) {
+        P2[i] = cum;
+        const float rho = mrf_rad(p.f0[b * p.T + i], h, p.sr);
+        const float rho_m1 = __fadd_rn(rho, -1.0f);
+        const int w = W[i];
+        if (i == 0) {
+            const float r0 = __fadd_rn(rho, h == 0 ? 0.f : p.rand_ini[b * p.dim + h]);
+            cum += (double)r0 + (double)(p.upp - 1 - w) * (double)rho + (double)w * (double)rho_m1;
+        } else {
+            cum += (double)(p.upp - w) * (double)rho + (double)w * (double)rho_m1;
+        }
+    }
+}
+
+// pass 4: one block per (frame, b): in-frame prefix of the wrap flags, sines, noise, Linear(dim -> 1), tanh
+__global__ void __launch_bounds__(256) mrf_source_kernel(MrfSrcParams p) {
+    __shared__ int wave_tot[4];
+    const int64_t i = blockIdx.x;
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t L = p.T * p.upp;
+    const float f = p.f0[b * p.T + i];
+    const float uv = f > 0.f ? 1.f : 0.f;
+    const float amp = __fadd_rn(__fmul_rn(uv, 0.003f), __fdiv_rn(__fmul_rn(1.f - uv, 0.1f), 3.f));
+    const int n_it = (p.upp + 255) / 256;
+    float out_acc[4] = {0.f, 0.f, 0.f, 0.f};  // upp <= 1024 -> at most 4 slices of 256 samples
+    for (int h = 0; h < p.dim; ++h) {
+        const double *P1 = p.p1 + ((int64_t)b * p.dim + h) * p.T;
+        const double P2 = p.p2[((int64_t)b * p.dim + h) * p.T + i];
+        const float rho = mrf_rad(f, h, p.sr);
+        const float rho_m1 = __fadd_rn(rho, -1.0f);
+        const float r0 = (i == 0) ? __fadd_rn(rho, h == 0 ? 0.f : p.rand_ini[b * p.dim + h]) : rho;
+        const float lw = p.lin_w[h];
+        int base = 0;  // wraps in the frame before this 256-sample slice
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            if (it < n_it) {  // block-uniform
+                const int j = it * 256 + threadIdx.x;
+                int flag = 0;
+                if (j < p.upp && !(i == 0 && j == 0)) {
+                    const float cur = mrf_tmp(p, P1, b, h, i, j);
+                    const float prev = (j == 0) ? mrf_tmp(p, P1, b, h, i - 1, p.upp - 1) : mrf_tmp(p, P1, b, h, i, j - 1);
+                    flag = __fsub_rn(cur, prev) < 0.f ? 1 : 0;
+                }
+                // inclusive prefix count of flags over the block
+                int incl = flag;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(incl, o);
+                    if (lane >= o) incl += v;
+                }
+                __syncthreads();
+                if (lane == 63) wave_tot[wave] = incl;
+                __syncthreads();
+                int before = base;
+                for (int w = 0; w < wave; ++w) before += wave_tot[w];
+                const int total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+                const int wcount = before + incl;  // wraps among samples [0..j] of this frame
+                if (j < p.upp) {
+                    // cumsum(rad + shift) up to and including sample j, in double like torch's CPU cumsum
+                    double s = P2;
+                    if (i == 0) s += (double)r0 + (double)(j - wcount) * (double)rho + (double)wcount * (double)rho_m1;
+                    else s += (double)(j + 1 - wcount) * (double)rho + (double)wcount * (double)rho_m1;
+                    const float c = (float)s;
+                    const float sine = __fmul_rn(sinf(__fmul_rn(__fmul_rn(c, 2.f), 3.14159265358979323846f)), 0.1f);
+                    const int64_t t = i * p.upp + j;
+                    const float nz = p.randn[((int64_t)b * L + t) * p.dim + h];
+                    const float v = __fadd_rn(__fmul_rn(sine, uv), __fmul_rn(amp, nz));
+                    out_acc[it] = fmaf(v, lw, out_acc[it]);
+                }
+                base += total;
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int j = it * 256 + threadIdx.x;
+        if (it < n_it && j < p.upp) p.har[(int64_t)b * L + i * p.upp + j] = tanhf(out_acc[it] + p.lin_b);
+    }
+}
+
+// V[b][k][q] = har[b][q*S + k - P] (0 outside): the strided views the noise conv reads, as GEMM rows
+__global__ void __launch_bounds__(256)
+unfold_src_kernel(const float *__restrict__ har, int64_t L, int64_t S, int64_t P, int k_valid, int k_rows, int64_t nq,
+                  float *__restrict__ V) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    if (q >= nq) return;
+    float v = 0.f;
+    if (k < k_valid) {
+        const int64_t idx = q * S + k - P;
+        if (idx >= 0 && idx < L) v = har[b * L + idx];
+    }
+    V[(b * k_rows + k) * nq + q] = v;
+}
+
+// bias'[b][co] = conv_pre.bias[co] + cond.bias[co] + cond.weight[co][:] . g[b][:]   (hifigan_nsf.py:179-182)
+__global__ void __launch_bounds__(64)
+cond_bias_kernel(const float *__restrict__ pre_b, const float *__restrict__ cond_w, const float *__restrict__ cond_b,
+                 const float *__restrict__ g, int gin, int c0, float *__restrict__ out) {
+    const int co = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    float s = 0.f;
+    for (int c = lane; c < gin; c += 64) s = fmaf(cond_w[(int64_t)co * gin + c], g[(int64_t)b * gin + c], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[(int64_t)b * c0 + co] = pre_b[co] + (cond_b[co] + s);
+}
+
+// out[b][t] = tanh(bias + sum_{ci,k} w[ci][k] * leaky(x[b][ci][t + k - 3], slope))   (hifigan_nsf.py:204-205)
+__global__ void __launch_bounds__(256)
+conv_post_kernel(const float *__restrict__ x, const float *__restrict__ w, float bias, int c_in, int64_t L, float slope,
+                 float *__restrict__ out) {
+    const int64_t b = blockIdx.y;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= L) return;
+    const float *xb = x + b * c_in * L;
+    float acc = bias;
+    for (int ci = 0; ci < c_in; ++ci) {
+        const float *xr = xb + (int64_t)ci * L;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int64_t tt = t + k - 3;
+            const float v = (tt >= 0 && tt < L) ? lrelu(xr[tt], slope) : 0.f;
+            acc = fmaf(w[ci * 7 + k], v, acc);
+        }
+    }
+    out[b * L + t] = tanhf(acc);
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------------------------------
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+    int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+struct DevBuf {
+    float *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int upload(const std::vector<float> &h) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        hipError_t e = hipMalloc((void **)&p, h.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+        return e == hipSuccess ? 0 : fail("device upload of %zu floats failed: %s", h.size(), hipGetErrorString(e));
+    }
+};
+
+struct ConvW {
+    DevBuf w, b;
+    int c_in = 0, c_out = 0, k = 0;
+};
+
+struct Stage {
+    int c_in = 0, c_out = 0, rate = 0, ksize = 0, pad = 0, opad = 0;
+    int taps = 0;                 // polyphase taps J = ceil(k / rate)
+    int nc_stride = 0, nc_k = 0, nc_pad = 0;
+    int vk = 0, vk_rows = 0;      // folded noise-conv rows: valid, padded to a multiple of 8
+    int64_t S = 0, P = 0;         // V[k][q] = har[q*S + k - P]
+    DevBuf w, b;                  // [taps][c_in + vk_rows][rate * c_out], [c_out]
+    std::vector<ConvW> c1, c2;    // [n_res_kernels * n_res_dilations]
+};
+
+}  // namespace rvc
+
+using namespace rvc;
+
+struct rvc_decoder {
+    rvc_decoder_config cfg;
+    std::map<std::string, HostTensor> host;
+    bool finalized = false;
+    int upp = 1;
+    int dim = 1;              // sine components (NSF 1, MRF 9)
+    float lin_w[MRF_MAX_DIM] = {0};
+    float lin_b = 0.f;
+    ConvW pre;                // conv_pre packed
+    DevBuf cond_w, cond_b;
+    std::vector<Stage> stages;
+    DevBuf post_w;
+    float post_b = 0.f;
+    int post_cin = 0;
+    // debug tap
+    int tap_stage = -2;
+    float *tap_dev = nullptr;
+};
+
+static const HostTensor *find(const rvc_decoder *d, const std::string &name) {
+    auto it = d->host.find(name);
+    return it == d->host.end() ? nullptr : &it->second;
+}
+
+static int need(const rvc_decoder *d, const std::string &name, const HostTensor **out, std::vector<int64_t> shape) {
+    const HostTensor *t = find(d, name);
+    if (!t) return fail("decoder: tensor '%s' was never set", name.c_str());
+    if (t->shape != shape) {
+        std::string got, want;
+        for (auto s : t->shape) got += std::to_string(s) + ",";
+        for (auto s : shape) want += std::to_string(s) + ",";
+        return fail("decoder: tensor '%s' has shape [%s], expected [%s]", name.c_str(), got.c_str(), want.c_str());
+    }
+    *out = t;
+    return 0;
+}
+
+static int build_conv(const rvc_decoder *d, const std::string &prefix, int c_out, int c_in, int k, bool bias, ConvW *out) {
+    const HostTensor *w, *b;
+    if (need(d, prefix + ".weight", &w, {c_out, c_in, k})) return 1;
+    std::vector<float> packed((size_t)c_out * c_in * k);
+    for (int co = 0; co < c_out; ++co)
+        for (int ci = 0; ci < c_in; ++ci)
+            for (int t = 0; t < k; ++t)
+                packed[((size_t)t * c_in + ci) * c_out + co] = w->data[((size_t)co * c_in + ci) * k + t];
+    if (out->w.upload(packed)) return 1;
+    if (bias) {
+        if (need(d, prefix + ".bias", &b, {c_out})) return 1;
+        if (out->b.upload(b->data)) return 1;
+    }
+    out->c_in = c_in; out->c_out = c_out; out->k = k;
+    return 0;
+}
+
+extern "C" int rvc_decoder_create(const rvc_decoder_config *cfg, rvc_decoder **out) {
+    if (!cfg || !out) return fail("rvc_decoder_create: null pointer");
+    if (cfg->kind != RVC_DEC_NSF && cfg->kind != RVC_DEC_MRF && cfg->kind != RVC_DEC_REFINE)
+        return fail("rvc_decoder_create: unknown decoder kind %d", cfg->kind);
+    if (cfg->kind == RVC_DEC_REFINE) return fail("rvc_decoder_create: RefineGAN decoder is not implemented yet");
+    if (cfg->n_ups < 1 || cfg->n_ups > 8) return fail("rvc_decoder_create: n_ups out of range");
+    if (cfg->n_res_kernels < 1 || cfg->n_res_kernels > 4 || cfg->n_res_dilations < 1 || cfg->n_res_dilations > 4)
+        return fail("rvc_decoder_create: resblock configuration out of range");
+    if (cfg->in_channels % 8 || cfg->upsample_initial_channel % (32 << cfg->n_ups))
+        return fail("rvc_decoder_create: channel counts must keep every stage a multiple of 32");
+    rvc_decoder *d = new rvc_decoder();
+    d->cfg = *cfg;
+    d->upp = 1;
+    for (int i = 0; i < cfg->n_ups; ++i) d->upp *= cfg->upsample_rates[i];
+    if (d->upp > 1024) { delete d; return fail("rvc_decoder_create: prod(upsample_rates) > 1024"); }
+    d->dim = cfg->kind == RVC_DEC_MRF ? 9 : 1;
+    *out = d;
+    return 0;
+}
+
+extern "C" int rvc_decoder_set_tensor(rvc_decoder *dec, const char *name, const float *data_host, const int64_t *shape,
+                                      int ndim) {
+    if (!dec || !name || !data_host || !shape || ndim < 1 || ndim > 4) return fail("rvc_decoder_set_tensor: bad argument");
+    if (dec->finalized) return fail("rvc_decoder_set_tensor: decoder already finalized");
+    HostTensor t;
+    t.shape.assign(shape, shape + ndim);
+    const int64_t n = t.numel();
+    if (n <= 0) return fail("rvc_decoder_set_tensor: empty tensor '%s'", name);
+    t.data.assign(data_host, data_host + n);
+    dec->host[name] = std::move(t);
+    return 0;
+}
+
+extern "C" int rvc_decoder_finalize(rvc_decoder *d) {
+    if (!d) return fail("rvc_decoder_finalize: null decoder");
+    if (d->finalized) return 0;
+    const rvc_decoder_config &c = d->cfg;
+    const bool mrf = c.kind == RVC_DEC_MRF;
+    const HostTensor *t;
+    // source merge: Linear(dim -> 1) + tanh
+    if (need(d, "m_source.l_linear.weight", &t, {1, d->dim})) return 1;
+    for (int h = 0; h < d->dim; ++h) d->lin_w[h] = t->data[h];
+    if (need(d, "m_source.l_linear.bias", &t, {1})) return 1;
+    d->lin_b = t->data[0];
+    // conv_pre + cond
+    const int c0 = c.upsample_initial_channel;
+    if (build_conv(d, "conv_pre", c0, c.in_channels, 7, true, &d->pre)) return 1;
+    if (need(d, "cond.weight", &t, {c0, c.gin_channels, 1})) return 1;
+    if (d->cond_w.upload(t->data)) return 1;
+    if (need(d, "cond.bias", &t, {c0})) return 1;
+    if (d->cond_b.upload(t->data)) return 1;
+    // stages
+    d->stages.clear();
+    d->stages.resize(c.n_ups);
+    for (int i = 0; i < c.n_ups; ++i) {
+        Stage &s = d->stages[i];
+        s.c_in = c0 >> i;
+        s.c_out = c0 >> (i + 1);
+        s.rate = c.upsample_rates[i];
+        s.ksize = c.upsample_kernel_sizes[i];
+        // hifigan_nsf.py:113-117,127
+        s.pad = (s.rate % 2 == 0) ? (s.ksize - s.rate) / 2 : s.rate / 2 + s.rate % 2;
+        s.opad = s.rate % 2;
+        s.taps = (s.ksize + s.rate - 1) / s.rate;
+        if (s.taps > 2) return fail("decoder: upsample kernel %d with rate %d needs %d polyphase taps (max 2)", s.ksize, s.rate, s.taps);
+        if (s.taps < 2) s.taps = 2;  // the GEMM kernel is instantiated for 2 taps; the second is zero
+        int stride_f0 = 1;
+        for (int j = i + 1; j < c.n_ups; ++j) stride_f0 *= c.upsample_rates[j];
+        s.nc_stride = stride_f0;
+        // hifigan_nsf.py:142-144
+        s.nc_k = stride_f0 == 1 ? 1 : stride_f0 * 2 - stride_f0 % 2;
+        s.nc_pad = stride_f0 == 1 ? 0 : (s.nc_k - stride_f0) / 2;
+        s.vk = (s.rate - 1) * s.nc_stride + s.nc_k;
+        s.vk_rows = (s.vk + 7) / 8 * 8;
+        s.S = (int64_t)s.rate * s.nc_stride;
+        s.P = (int64_t)s.pad * s.nc_stride + s.nc_pad;
+
+        const std::string up = (mrf ? "upsamples." : "ups.") + std::to_string(i);
+        const std::string nc = "noise_convs." + std::to_string(i);
+        const HostTensor *uw, *ub, *nw, *nb;
+        if (need(d, up + ".weight", &uw, {s.c_in, s.c_out, s.ksize})) return 1;
+        if (need(d, up + ".bias", &ub, {s.c_out})) return 1;
+        if (need(d, nc + ".weight", &nw, {s.c_out, 1, s.nc_k})) return 1;
+        if (need(d, nc + ".bias", &nb, {s.c_out})) return 1;
+        // polyphase repack.  Output t = q*rate + phase - pad gets sum_j sum_ci W[ci][co][phase + j*rate] x[ci][q - j];
+        // as GEMM taps with dil = 1, padl = taps-1: tap' = taps-1-j.  Noise rows only on the offset-0 tap.
+        const int ctot = s.c_in + s.vk_rows;
+        const int m_total = s.rate * s.c_out;
+        std::vector<float> packed((size_t)s.taps * ctot * m_total, 0.f);
+        for (int tp = 0; tp < s.taps; ++tp) {
+            const int j = s.taps - 1 - tp;
+            for (int ci = 0; ci < s.c_in; ++ci)
+                for (int ph = 0; ph < s.rate; ++ph) {
+                    const int kk = ph + j * s.rate;
+                    if (kk >= s.ksize) continue;
+                    for (int co = 0; co < s.c_out; ++co)
+                        packed[((size_t)tp * ctot + ci) * m_total + ph * s.c_out + co] =
+                            uw->data[((size_t)ci * s.c_out + co) * s.ksize + kk];
+                }
+        }
+        const int tp0 = s.taps - 1;  // the tap with input offset 0
+        for (int kq = 0; kq < s.vk; ++kq)
+            for (int ph = 0; ph < s.rate; ++ph) {
+                const int k = kq - ph * s.nc_stride;
+                if (k < 0 || k >= s.nc_k) continue;
+                for (int co = 0; co < s.c_out; ++co)
+                    packed[((size_t)tp0 * ctot + s.c_in + kq) * m_total + ph * s.c_out + co] = nw->data[(size_t)co * s.nc_k + k];
+            }
+        if (s.w.upload(packed)) return 1;
+        std::vector<float> bias(s.c_out);
+        for (int co = 0; co < s.c_out; ++co) bias[co] = ub->data[co] + nb->data[co];
+        if (s.b.upload(bias)) return 1;
+
+        const int nb_ = c.n_res_kernels * c.n_res_dilations;
+        s.c1 = std::vector<ConvW>(nb_);
+        s.c2 = std::vector<ConvW>(nb_);
+        for (int m = 0; m < c.n_res_kernels; ++m)
+            for (int j = 0; j < c.n_res_dilations; ++j) {
+                std::string p1, p2;
+                if (mrf) {
+                    const std::string base = "mrfs." + std::to_string(i) + "." + std::to_string(m) + ".layers." + std::to_string(j);
+                    p1 = base + ".conv1";
+                    p2 = base + ".conv2";
+                } else {
+                    const std::string base = "resblocks." + std::to_string(i * c.n_res_kernels + m);
+                    p1 = base + ".convs1." + std::to_string(j);
+                    p2 = base + ".convs2." + std::to_string(j);
+                }
+                const int k = c.res_kernel_sizes[m];
+                if (build_conv(d, p1, s.c_out, s.c_out, k, true, &s.c1[m * c.n_res_dilations + j])) return 1;
+                if (build_conv(d, p2, s.c_out, s.c_out, k, true, &s.c2[m * c.n_res_dilations + j])) return 1;
+            }
+    }
+    // conv_post: [1][c_last][7]
+    d->post_cin = c0 >> c.n_ups;
+    if (need(d, "conv_post.weight", &t, {1, d->post_cin, 7})) return 1;
+    if (d->post_w.upload(t->data)) return 1;
+    d->post_b = 0.f;
+    if (mrf) {
+        if (need(d, "conv_post.bias", &t, {1})) return 1;
+        d->post_b = t->data[0];
+    }
+    d->host.clear();
+    d->finalized = true;
+    return 0;
+}
+
+extern "C" int rvc_decoder_destroy(rvc_decoder *dec) {
+    delete dec;
+    return 0;
+}
+
+extern "C" int rvc_decoder_upp(const rvc_decoder *dec) { return dec ? dec->upp : 0; }
+
+namespace {
+struct Carve {
+    size_t off = 0;
+    size_t take(size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; }
+};
+struct Layout {
+    size_t har, carry, biasp, V, p1, p2, wraps, buf[4], total;
+    int64_t max_cl;
+};
+Layout make_layout(const rvc_decoder *d, int batch, int64_t T) {
+    Layout l;
+    Carve c;
+    const int64_t L = T * d->upp;
+    l.har = c.take((size_t)batch * L * 4);
+    l.carry = c.take((size_t)batch * T * 4);
+    l.biasp = c.take((size_t)batch * d->cfg.upsample_initial_channel * 4);
+    int64_t len = T, max_cl = (int64_t)d->cfg.upsample_initial_channel * T, max_v = 0;
+    for (const Stage &s : d->stages) {
+        const int64_t nq = len + 1;
+        max_v = std::max<int64_t>(max_v, (int64_t)s.vk_rows * nq);
+        len = (len - 1) * s.rate - 2 * s.pad + s.ksize + s.opad;
+        max_cl = std::max<int64_t>(max_cl, (int64_t)s.c_out * len);
+    }
+    l.V = c.take((size_t)batch * max_v * 4);
+    const size_t scan = d->dim > 1 ? (size_t)batch * d->dim * T : 0;
+    l.p1 = c.take(scan * 8);
+    l.p2 = c.take(scan * 8);
+    l.wraps = c.take(scan * 4);
+    for (int i = 0; i < 4; ++i) l.buf[i] = c.take((size_t)batch * max_cl * 4);
+    l.total = c.off;
+    l.max_cl = max_cl;
+    return l;
+}
+}  // namespace
+
+extern "C" int rvc_decoder_workspace_bytes(const rvc_decoder *dec, int batch, int64_t n_frames, size_t *bytes) {
+    if (!dec || !bytes || batch <= 0 || n_frames <= 0) return fail("rvc_decoder_workspace_bytes: bad argument");
+    if (!dec->finalized) return fail("rvc_decoder_workspace_bytes: decoder not finalized");
+    *bytes = make_layout(dec, batch, n_frames).total;
+    return 0;
+}
+
+extern "C" int rvc_decoder_set_tap(rvc_decoder *dec, int stage, float *tap_dev) {
+    if (!dec) return fail("rvc_decoder_set_tap: null decoder");
+    dec->tap_stage = tap_dev ? stage : -2;
+    dec->tap_dev = tap_dev;
+    return 0;
+}
+
+extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const float *f0_dev, const float *g_dev,
+                                   const rvc_decoder_noise *noise, int batch, int64_t T, float *out_dev,
+                                   void *workspace_dev, size_t workspace_bytes, void *stream_) {
+    if (!d || !z_dev || !f0_dev || !g_dev || !noise || !out_dev || !workspace_dev) return fail("rvc_decoder_forward: null pointer");
+    if (!d->finalized) return fail("rvc_decoder_forward: decoder not finalized");
+    if (batch <= 0 || T <= 0) return fail("rvc_decoder_forward: empty batch");
+    if (!noise->src_randn_dev) return fail("rvc_decoder_forward: src_randn_dev is required");
+    const rvc_decoder_config &c = d->cfg;
+    const bool mrf = c.kind == RVC_DEC_MRF;
+    if (mrf && !noise->src_rand_dev) return fail("rvc_decoder_forward: src_rand_dev is required for the MRF decoder");
+    hipStream_t stream = (hipStream_t)stream_;
+    const Layout lay = make_layout(d, batch, T);
+    if (workspace_bytes < lay.total) return fail("rvc_decoder_forward: workspace too small (%zu < %zu)", workspace_bytes, lay.total);
+    char *ws = (char *)workspace_dev;
+    float *har = (float *)(ws + lay.har);
+    float *carry = (float *)(ws + lay.carry);
+    float *biasp = (float *)(ws + lay.biasp);
+    float *V = (float *)(ws + lay.V);
+    float *buf[4];
+    for (int i = 0; i < 4; ++i) buf[i] = (float *)(ws + lay.buf[i]);
+    const int64_t L = T * d->upp;
+    const float sr = (float)c.sample_rate;
+
+    // ---- source module ----
+    if (!mrf) {
+        hipLaunchKernelGGL(nsf_carry_kernel, dim3(batch), dim3(64), 0, stream, f0_dev, T, sr, (float)d->upp, carry);
+        RVC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(nsf_source_kernel, dim3((unsigned)ceil_div(L, 256), batch), dim3(256), 0, stream, f0_dev, carry,
+                           noise->src_randn_dev, T, d->upp, sr, d->lin_w[0], d->lin_b, har);
+        RVC_LAUNCH_CHECK();
+    } else {
+        MrfSrcParams sp;
+        sp.f0 = f0_dev; sp.rand_ini = noise->src_rand_dev; sp.randn = noise->src_randn_dev; sp.har = har;
+        sp.p1 = (double *)(ws + lay.p1); sp.p2 = (double *)(ws + lay.p2); sp.wraps = (int *)(ws + lay.wraps);
+        sp.tot_unused = nullptr;
+        sp.T = T; sp.upp = d->upp; sp.dim = d->dim; sp.sr = sr;
+        for (int h = 0; h < MRF_MAX_DIM; ++h) sp.lin_w[h] = d->lin_w[h];
+        sp.lin_b = d->lin_b;
+        hipLaunchKernelGGL(mrf_prefix1_kernel, dim3(batch), dim3(64), 0, stream, sp);
+        RVC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(mrf_wraps_kernel, dim3((unsigned)T, d->dim, batch), dim3(64), 0, stream, sp);
+        RVC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(mrf_prefix2_kernel, dim3(batch), dim3(64), 0, stream, sp);
+        RVC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(mrf_source_kernel, dim3((unsigned)T, batch), dim3(256), 0, stream, sp);
+        RVC_LAUNCH_CHECK();
+    }
+    if (d->tap_stage == -1 && d->tap_dev)
+        RVC_HIP(hipMemcpyAsync(d->tap_dev, har, (size_t)batch * L * 4, hipMemcpyDeviceToDevice, stream));
+
+    // ---- conv_pre + cond ----
+    const int c0 = c.upsample_initial_channel;
+    hipLaunchKernelGGL(cond_bias_kernel, dim3(c0, batch), dim3(64), 0, stream, d->pre.b.p, d->cond_w.p, d->cond_b.p, g_dev,
+                       c.gin_channels, c0, biasp);
+    RVC_LAUNCH_CHECK();
+    float *cur = buf[0];   // stage input / running sum
+    {
+        ConvParams p;
+        p.x1 = z_dev; p.c1 = c.in_channels; p.slope1 = 1.f; p.x1_bstride = (int64_t)c.in_channels * T; p.l_in = T;
+        p.w = d->pre.w.p; p.bias = biasp; p.bias_bstride = c0;
+        p.y = cur; p.y_bstride = (int64_t)c0 * T; p.m_total = c0; p.c_out = c0; p.n_cols = T; p.l_out = T;
+        p.kw = 7; p.dil = 1; p.padl = 3; p.batch = batch;
+        if (launch_conv(p, stream)) return 1;
+    }
+
+    // ---- upsample stages ----
+    int64_t len = T;
+    const int nd = c.n_res_dilations, nk = c.n_res_kernels;
+    for (int i = 0; i < c.n_ups; ++i) {
+        Stage &s = d->stages[i];
+        const int64_t nq = len + 1;
+        const int64_t len_out = (len - 1) * s.rate - 2 * s.pad + s.ksize + s.opad;
+        hipLaunchKernelGGL(unfold_src_kernel, dim3((unsigned)ceil_div(nq, 256), s.vk_rows, batch), dim3(256), 0, stream, har, L,
+                           s.S, s.P, s.vk, s.vk_rows, nq, V);
+        RVC_LAUNCH_CHECK();
+        float *X = buf[1], *Y = buf[2], *T1 = buf[3];
+        {
+            ConvParams p;
+            p.x1 = cur; p.c1 = s.c_in; p.slope1 = 0.1f; p.x1_bstride = (int64_t)s.c_in * len;
+            p.x2 = V; p.c2 = s.vk_rows; p.slope2 = 1.f; p.x2_bstride = (int64_t)s.vk_rows * nq;
+            // both sources are indexed by the GEMM column q; x rows are valid on [0, len), V rows on [0, nq):
+            // V is stored with row length nq, x with row length len -> give x its own staging length
+            p.l_in = len;
+            p.w = s.w.p; p.bias = s.b.p;
+            p.y = X; p.y_bstride = (int64_t)s.c_out * len_out;
+            p.m_total = s.rate * s.c_out; p.c_out = s.c_out; p.n_cols = nq; p.l_out = len_out;
+            p.kw = s.taps; p.dil = 1; p.padl = s.taps - 1;
+            p.up_stride = s.rate; p.up_pad = s.pad; p.batch = batch;
+            p.l_in2 = nq;
+            if (launch_conv(p, stream)) return 1;
+        }
+        len = len_out;
+        const int64_t bs = (int64_t)s.c_out * len;
+        for (int m = 0; m < nk; ++m) {
+            const int k = c.res_kernel_sizes[m];
+            const float *xin = X;
+            for (int j = 0; j < nd; ++j) {
+                const int dil = c.res_dilations[j];
+                ConvParams p;
+                p.x1 = xin; p.c1 = s.c_out; p.slope1 = 0.1f; p.x1_bstride = bs; p.l_in = len;
+                p.w = s.c1[m * nd + j].w.p; p.bias = s.c1[m * nd + j].b.p;
+                p.y = T1; p.y_bstride = bs; p.m_total = s.c_out; p.c_out = s.c_out; p.n_cols = len; p.l_out = len;
+                p.kw = k; p.dil = dil; p.padl = (k - 1) / 2 * dil; p.batch = batch;
+                if (launch_conv(p, stream)) return 1;
+                ConvParams q;
+                q.x1 = T1; q.c1 = s.c_out; q.slope1 = 0.1f; q.x1_bstride = bs; q.l_in = len;
+                q.w = s.c2[m * nd + j].w.p; q.bias = s.c2[m * nd + j].b.p;
+                q.res = xin;
+                q.y_bstride = bs; q.m_total = s.c_out; q.c_out = s.c_out; q.n_cols = len; q.l_out = len;
+                q.kw = k; q.dil = 1; q.padl = (k - 1) / 2; q.batch = batch;
+                if (j + 1 < nd) {
+                    q.y = Y;
+                } else {  // last layer of the branch: add into the running sum, scale the last one by 1/nk
+                    q.y = cur;
+                    q.accin = (m > 0) ? cur : nullptr;
+                    q.out_scale = (m + 1 == nk) ? 1.f / (float)nk : 1.f;
+                }
+                if (launch_conv(q, stream)) return 1;
+                xin = Y;
+            }
+        }
+        if (d->tap_stage == i && d->tap_dev)
+            RVC_HIP(hipMemcpyAsync(d->tap_dev, cur, (size_t)batch * bs * 4, hipMemcpyDeviceToDevice, stream));
+    }
+    if (len != L) return fail("decoder: internal length mismatch (%lld vs %lld)", (long long)len, (long long)L);
+    hipLaunchKernelGGL(conv_post_kernel, dim3((unsigned)ceil_div(L, 256), batch), dim3(256), 0, stream, cur, d->post_w.p,
+                       d->post_b, d->post_cin, L, 0.01f, out_dev);
+    RVC_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,254 @@
+"""ctypes binding of librvc_amd.so (include/rvc_amd.h) for torch tensors.
+
+The library is the product: there is no CPU or PyTorch fallback.  If the shared object is
+missing this module raises at import, and every wrapper raises ``NativeError`` with the
+library's own message when a call fails.  Tensors are passed as raw device pointers
+(``tensor.data_ptr()``) and every launch goes on torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "librvc_amd.so")
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+if not os.path.isfile(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(hipcc --offload-arch=gfx950).  rvc_amd has no fallback path without its HIP library.")
+
+_lib = ctypes.CDLL(LIB_PATH)
+
+
+class DecoderConfig(ctypes.Structure):
+    _fields_ = [
+        ("kind", c_int), ("sample_rate", c_int), ("in_channels", c_int), ("upsample_initial_channel", c_int),
+        ("gin_channels", c_int), ("n_ups", c_int), ("upsample_rates", c_int * 8), ("upsample_kernel_sizes", c_int * 8),
+        ("n_res_kernels", c_int), ("res_kernel_sizes", c_int * 4), ("res_dilations", c_int * 4),
+        ("n_res_dilations", c_int),
+    ]
+
+
+class DecoderNoise(ctypes.Structure):
+    _fields_ = [("src_rand_dev", c_void_p), ("src_randn_dev", c_void_p), ("adain_randn_dev", c_void_p)]
+
+
+# every symbol include/rvc_amd.h declares: (restype, argtypes)
+SYMBOLS = {
+    "rvc_abi_version": (c_int, []),
+    "rvc_last_error": (c_char_p, []),
+    "rvc_knn_index_norms": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "rvc_knn_workspace_bytes": (c_int, [c_int64, c_int64, c_int, POINTER(c_size_t)]),
+    "rvc_knn_search": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p,
+                               c_void_p, c_size_t, c_void_p]),
+    "rvc_knn_blend": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p,
+                              c_void_p]),
+    "rvc_logmel_workspace_bytes": (c_int, [c_int, c_int64, POINTER(c_size_t)]),
+    "rvc_logmel_rmvpe": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+    "rvc_decoder_create": (c_int, [POINTER(DecoderConfig), POINTER(c_void_p)]),
+    "rvc_decoder_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]),
+    "rvc_decoder_finalize": (c_int, [c_void_p]),
+    "rvc_decoder_destroy": (c_int, [c_void_p]),
+    "rvc_decoder_upp": (c_int, [c_void_p]),
+    "rvc_decoder_workspace_bytes": (c_int, [c_void_p, c_int, c_int64, POINTER(c_size_t)]),
+    "rvc_decoder_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(DecoderNoise), c_int, c_int64,
+                                    c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rvc_decoder_set_tap": (c_int, [c_void_p, c_int, c_void_p]),
+    "rvc_conv1d_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rvc_conv1d_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                   c_int64, c_int, c_int, c_float, c_float, c_void_p]),
+}
+
+for _name, (_res, _args) in SYMBOLS.items():
+    _fn = getattr(_lib, _name)  # AttributeError here = the .so is stale
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+if _lib.rvc_abi_version() != 1:
+    raise ImportError(f"librvc_amd.so ABI {_lib.rvc_abi_version()} != 1: rebuild it")
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise NativeError(f"{what}: {_lib.rvc_last_error().decode(errors='replace')}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise NativeError(f"{name} must live in HBM (got a {t.device} tensor); the HIP path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise NativeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+class _Workspace:
+    """Grow-only scratch buffer per (device, tag) so steady-state calls allocate nothing."""
+
+    def __init__(self):
+        self._buf = {}
+
+    def get(self, tag: str, nbytes: int, device) -> torch.Tensor:
+        key = (tag, str(device))
+        buf = self._buf.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+            self._buf[key] = buf
+        return buf
+
+
+_ws = _Workspace()
+
+
+# ---- K1 ------------------------------------------------------------------------------------------
+def knn_index_norms(index: torch.Tensor) -> torch.Tensor:
+    index = _dev_f32(index, "index")
+    norms = torch.empty(index.shape[0], dtype=torch.float32, device=index.device)
+    _check(_lib.rvc_knn_index_norms(index.data_ptr(), index.shape[0], index.shape[1], norms.data_ptr(), _stream()),
+           "rvc_knn_index_norms")
+    return norms
+
+
+def knn_search(index: torch.Tensor, norms: torch.Tensor, queries: torch.Tensor, k: int = 8):
+    index, norms, queries = _dev_f32(index, "index"), _dev_f32(norms, "norms"), _dev_f32(queries, "queries")
+    nq = queries.shape[0]
+    d2 = torch.empty((nq, k), dtype=torch.float32, device=index.device)
+    ids = torch.empty((nq, k), dtype=torch.int64, device=index.device)
+    if nq == 0:
+        return d2, ids
+    need = c_size_t()
+    _check(_lib.rvc_knn_workspace_bytes(index.shape[0], nq, k, ctypes.byref(need)), "rvc_knn_workspace_bytes")
+    ws = _ws.get("knn", need.value, index.device)
+    _check(_lib.rvc_knn_search(index.data_ptr(), norms.data_ptr(), index.shape[0], index.shape[1], queries.data_ptr(),
+                               nq, k, d2.data_ptr(), ids.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+           "rvc_knn_search")
+    return d2, ids
+
+
+def knn_blend(index: torch.Tensor, feats: torch.Tensor, d2: torch.Tensor, ids: torch.Tensor, index_rate: float):
+    index, feats, d2 = _dev_f32(index, "index"), _dev_f32(feats, "feats"), _dev_f32(d2, "d2")
+    ids = ids.contiguous()
+    out = torch.empty_like(feats)
+    _check(_lib.rvc_knn_blend(index.data_ptr(), index.shape[1], feats.data_ptr(), d2.data_ptr(), ids.data_ptr(),
+                              feats.shape[0], d2.shape[1], float(index_rate), out.data_ptr(), _stream()),
+           "rvc_knn_blend")
+    return out
+
+
+# ---- K4 ------------------------------------------------------------------------------------------
+def logmel_rmvpe(audio: torch.Tensor, pad_to: int = 32) -> tuple[torch.Tensor, int]:
+    """audio [B, n] -> (log-mel [B, 128, T_padded], T) with the frame axis reflect-padded to a multiple of pad_to."""
+    audio = _dev_f32(audio, "audio")
+    b, n = audio.shape
+    t = n // 160 + 1
+    t_pad = pad_to * ((t - 1) // pad_to + 1) if pad_to > 1 else t
+    mel = torch.empty((b, 128, t_pad), dtype=torch.float32, device=audio.device)
+    need = c_size_t()
+    _check(_lib.rvc_logmel_workspace_bytes(b, n, ctypes.byref(need)), "rvc_logmel_workspace_bytes")
+    ws = _ws.get("logmel", need.value, audio.device)
+    _check(_lib.rvc_logmel_rmvpe(audio.data_ptr(), b, n, mel.data_ptr(), t_pad, ws.data_ptr(), ws.numel(), _stream()),
+           "rvc_logmel_rmvpe")
+    return mel, t
+
+
+# ---- conv1d (unit-test entry) ----------------------------------------------------------------------
+def conv1d_pack_weight(w: torch.Tensor, device) -> torch.Tensor:
+    w = w.detach().float().cpu().contiguous()
+    packed = torch.empty(w.numel(), dtype=torch.float32, device=device)
+    _check(_lib.rvc_conv1d_pack_weight(w.data_ptr(), w.shape[0], w.shape[1], w.shape[2], packed.data_ptr(), _stream()),
+           "rvc_conv1d_pack_weight")
+    return packed
+
+
+def conv1d_forward(x, w_packed, bias, c_out, k, dilation=1, slope_in=1.0, res=None, acc=None, out_scale=1.0):
+    x = _dev_f32(x, "x")
+    b, c_in, length = x.shape
+    y = torch.empty((b, c_out, length), dtype=torch.float32, device=x.device)
+    _check(_lib.rvc_conv1d_forward(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                   res.data_ptr() if res is not None else None,
+                                   acc.data_ptr() if acc is not None else None, y.data_ptr(), b, c_in, c_out, length, k,
+                                   dilation, float(slope_in), float(out_scale), _stream()), "rvc_conv1d_forward")
+    return y
+
+
+# ---- K2/K3 -----------------------------------------------------------------------------------------
+DEC_KINDS = {"HiFi-GAN": 0, "MRF HiFi-GAN": 1, "RefineGAN": 2}
+
+
+class Decoder:
+    """Handle on the library's vocoder: weights are repacked into HBM once, forward() launches the chain."""
+
+    def __init__(self, vocoder: str, sr: int, folded_weights: dict, *, in_channels=192, upsample_initial_channel=512,
+                 gin_channels=256, upsample_rates=(12, 10, 2, 2), upsample_kernel_sizes=(24, 20, 4, 4),
+                 res_kernel_sizes=(3, 7, 11), res_dilations=(1, 3, 5)):
+        if not torch.cuda.is_available():
+            raise NativeError("rvc_amd.Decoder needs a HIP device (no CPU fallback)")
+        cfg = DecoderConfig()
+        cfg.kind = DEC_KINDS[vocoder]
+        cfg.sample_rate = sr
+        cfg.in_channels = in_channels
+        cfg.upsample_initial_channel = upsample_initial_channel
+        cfg.gin_channels = gin_channels
+        cfg.n_ups = len(upsample_rates)
+        for i, (u, k) in enumerate(zip(upsample_rates, upsample_kernel_sizes)):
+            cfg.upsample_rates[i] = int(u)
+            cfg.upsample_kernel_sizes[i] = int(k)
+        cfg.n_res_kernels = len(res_kernel_sizes)
+        for i, k in enumerate(res_kernel_sizes):
+            cfg.res_kernel_sizes[i] = int(k)
+        cfg.n_res_dilations = len(res_dilations)
+        for i, d in enumerate(res_dilations):
+            cfg.res_dilations[i] = int(d)
+        self._h = c_void_p()
+        self.vocoder = vocoder
+        _check(_lib.rvc_decoder_create(ctypes.byref(cfg), ctypes.byref(self._h)), "rvc_decoder_create")
+        for name, t in folded_weights.items():
+            t = t.detach().float().cpu().contiguous()
+            shape = (c_int64 * t.dim())(*t.shape)
+            _check(_lib.rvc_decoder_set_tensor(self._h, name.encode(), t.data_ptr(), shape, t.dim()),
+                   f"rvc_decoder_set_tensor({name})")
+        _check(_lib.rvc_decoder_finalize(self._h), "rvc_decoder_finalize")
+        self.upp = _lib.rvc_decoder_upp(self._h)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.rvc_decoder_destroy(h)
+            self._h = None
+
+    def set_tap(self, stage: int, tap: torch.Tensor | None):
+        _check(_lib.rvc_decoder_set_tap(self._h, stage, tap.data_ptr() if tap is not None else None),
+               "rvc_decoder_set_tap")
+
+    def forward(self, z: torch.Tensor, f0: torch.Tensor, g: torch.Tensor, *, src_randn: torch.Tensor,
+                src_rand: torch.Tensor | None = None, adain_randn: torch.Tensor | None = None) -> torch.Tensor:
+        z, f0, g = _dev_f32(z, "z"), _dev_f32(f0, "f0"), _dev_f32(g, "g")
+        b, _, t = z.shape
+        noise = DecoderNoise()
+        src_randn = _dev_f32(src_randn, "src_randn")
+        noise.src_randn_dev = src_randn.data_ptr()
+        if src_rand is not None:
+            src_rand = _dev_f32(src_rand, "src_rand")
+            noise.src_rand_dev = src_rand.data_ptr()
+        if adain_randn is not None:
+            adain_randn = _dev_f32(adain_randn, "adain_randn")
+            noise.adain_randn_dev = adain_randn.data_ptr()
+        out = torch.empty((b, 1, t * self.upp), dtype=torch.float32, device=z.device)
+        need = c_size_t()
+        _check(_lib.rvc_decoder_workspace_bytes(self._h, b, t, ctypes.byref(need)), "rvc_decoder_workspace_bytes")
+        ws = _ws.get("decoder", need.value, z.device)
+        _check(_lib.rvc_decoder_forward(self._h, z.data_ptr(), f0.data_ptr(), g.data_ptr(), ctypes.byref(noise), b, t,
+                                        out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "rvc_decoder_forward")
+        return out

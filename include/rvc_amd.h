@@ -1,0 +1,152 @@
+/*
+ * rvc_amd.h -- C ABI of librvc_amd.so: the MI355X (gfx950) kernels of the RVC inference hot path.
+ *
+ * The reference (codename0og/codename-rvc-fork-3) is 100 % Python: it has no FFI / plugin interface,
+ * the boundary it offers is Python method signatures.  Each entry point below replaces
+ * the body of one reference call; the reference-side binding a maintainer would add is a ctypes stub,
+ * shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer named *_dev is a device (HBM) address owned by the caller (e.g. torch tensor.data_ptr());
+ *     *_host pointers are host addresses; nothing here allocates caller-visible memory;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); every launch is
+ *     asynchronous on it; 0 / NULL = the default stream;
+ *   - every function returns 0 on success, non-zero on error; rvc_last_error() describes the last failure
+ *     of the calling thread;
+ *   - a handle is bound to the device that was current when it was created and is not thread-safe;
+ *     distinct handles are independent;
+ *   - tensors are dense, row-major, fp32 unless said otherwise.
+ */
+#ifndef RVC_AMD_H
+#define RVC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RVC_AMD_ABI_VERSION 1
+
+/* ---- library ------------------------------------------------------------------------------------ */
+
+int rvc_abi_version(void);
+/* NUL-terminated description of the calling thread's last error ("" if none). */
+const char *rvc_last_error(void);
+
+/* ---- K1: feature retrieval --------------------------------------------------------------------- *
+ * Replaces `index.search(npy, k=8)` + the weighting/blend of
+ * rvc/infer/pipeline.py:497-507 (`Pipeline._retrieve_speaker_embeddings`), where `index` is the faiss
+ * index read at pipeline.py:555 and `big_npy = index.reconstruct_n(0, ntotal)` (pipeline.py:556).
+ * Search is exact brute-force squared L2 over big_npy (faiss IndexFlat semantics: ascending distance,
+ * ties -> lower id).
+ */
+
+/* ||x_n||^2 for every index row; run once when the index is loaded. norms_dev: [n_rows] */
+int rvc_knn_index_norms(const float *index_dev, int64_t n_rows, int dim, float *norms_dev, void *stream);
+
+/* bytes of scratch rvc_knn_search needs for (n_rows, n_queries) */
+int rvc_knn_workspace_bytes(int64_t n_rows, int64_t n_queries, int k, size_t *bytes);
+
+/* out_d2_dev [n_queries,k] squared distances ascending; out_ids_dev [n_queries,k] int64 row ids. k must be 8, dim % 32 == 0. */
+int rvc_knn_search(const float *index_dev, const float *norms_dev, int64_t n_rows, int dim,
+                   const float *queries_dev, int64_t n_queries, int k,
+                   float *out_d2_dev, int64_t *out_ids_dev,
+                   void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* pipeline.py:500-506: w = (1/d2)^2, w /= sum(w); out = index_rate * sum_k w_k * index[id_k] + (1-index_rate) * feats.
+ * feats_dev/out_dev: [n_queries, dim] (may alias). */
+int rvc_knn_blend(const float *index_dev, int dim, const float *feats_dev, const float *d2_dev,
+                  const int64_t *ids_dev, int64_t n_queries, int k, float index_rate,
+                  float *out_dev, void *stream);
+
+/* ---- K4: RMVPE log-mel front end --------------------------------------------------------------- *
+ * Replaces `MelSpectrogram.forward(audio, center=True)` as configured at
+ * rvc/lib/predictors/RMVPE.py:438 (n_fft = win = 1024, hop 160, 128 HTK mel bands 30-8000 Hz,
+ * log(clamp(., 1e-5)); forward at RMVPE.py:388-417) and the reflect pad of the frame axis to a multiple
+ * of 32 done in `mel2hidden` (RMVPE.py:452-455).
+ * audio_dev: [batch, n_samples]; mel_dev: [batch, 128, n_frames_padded] where n_frames = n_samples/160 + 1 and
+ * n_frames_padded >= n_frames is the row stride (columns >= n_frames are filled by reflection).
+ */
+int rvc_logmel_workspace_bytes(int batch, int64_t n_samples, size_t *bytes);
+int rvc_logmel_rmvpe(const float *audio_dev, int batch, int64_t n_samples, float *mel_dev,
+                     int64_t n_frames_padded, void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* ---- K2/K3: vocoder ("dec" of Synthesizer) ---------------------------------------------------- *
+ * Replaces `self.dec(z * x_mask, nsff0, g=g)` at rvc/lib/algorithm/synthesizers.py:254-258, i.e.
+ *   RVC_DEC_NSF    HiFiGANNSFGenerator.forward  rvc/lib/algorithm/generators/hifigan_nsf.py:173-207
+ *   RVC_DEC_MRF    HiFiGANMRFGenerator.forward  rvc/lib/algorithm/generators/hifigan_mrf.py:339-366
+ *   RVC_DEC_REFINE RefineGANGenerator.forward   rvc/lib/algorithm/generators/refinegan.py:368-405
+ * Weights are handed over once, by state-dict name with weight-norm already folded (w = g*v/||v||),
+ * fp32, host memory; the library repacks them into its own HBM layouts.
+ */
+typedef struct rvc_decoder rvc_decoder;
+
+enum { RVC_DEC_NSF = 0, RVC_DEC_MRF = 1, RVC_DEC_REFINE = 2 };
+
+typedef struct rvc_decoder_config {
+    int kind;                 /* RVC_DEC_* */
+    int sample_rate;          /* 32000 / 40000 / 48000 */
+    int in_channels;          /* inter_channels, 192 */
+    int upsample_initial_channel; /* 512 */
+    int gin_channels;         /* 256 */
+    int n_ups;                /* number of upsample stages, <= 8 */
+    int upsample_rates[8];
+    int upsample_kernel_sizes[8];
+    int n_res_kernels;        /* 3 */
+    int res_kernel_sizes[4];  /* 3,7,11 */
+    int res_dilations[4];     /* 1,3,5 (same for every kernel size) */
+    int n_res_dilations;      /* 3 */
+} rvc_decoder_config;
+
+int rvc_decoder_create(const rvc_decoder_config *cfg, rvc_decoder **out);
+/* name: state-dict key without the "dec." prefix, e.g. "ups.0.weight", "resblocks.3.convs1.1.bias". */
+int rvc_decoder_set_tensor(rvc_decoder *dec, const char *name, const float *data_host,
+                           const int64_t *shape, int ndim);
+/* call after the last set_tensor: checks that every tensor arrived, builds derived tables */
+int rvc_decoder_finalize(rvc_decoder *dec);
+int rvc_decoder_destroy(rvc_decoder *dec);
+
+/* samples produced per input frame (prod(upsample_rates)) */
+int rvc_decoder_upp(const rvc_decoder *dec);
+int rvc_decoder_workspace_bytes(const rvc_decoder *dec, int batch, int64_t n_frames, size_t *bytes);
+
+/* Explicit noise inputs, in the order and shapes the reference draws them (SURVEY §7 hard part 1):
+ *   NSF:    src_randn_dev [batch, T*upp]                         (hifigan.py:223; the rand of :189 is zeroed)
+ *   MRF:    src_rand_dev [batch, 9] (hifigan_mrf.py:143), src_randn_dev [batch, T*upp, 9] (hifigan_mrf.py:172)
+ *   REFINE: src_rand_dev [batch, 1], src_randn_dev [batch, T*upp, 1], adain_randn_dev = the 24 AdaIN draws
+ *           concatenated in call order (refinegan.py:111)
+ * Unused pointers may be NULL. */
+typedef struct rvc_decoder_noise {
+    const float *src_rand_dev;
+    const float *src_randn_dev;
+    const float *adain_randn_dev;
+} rvc_decoder_noise;
+
+/* z_dev [batch, in_channels, T] (already multiplied by x_mask), f0_dev [batch, T], g_dev [batch, gin_channels],
+ * out_dev [batch, T*upp] = tanh(conv_post(...)). */
+int rvc_decoder_forward(rvc_decoder *dec, const float *z_dev, const float *f0_dev, const float *g_dev,
+                        const rvc_decoder_noise *noise, int batch, int64_t n_frames, float *out_dev,
+                        void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* Debug hook for the parity tests: after stage `stage` of the next forward calls, copy that stage's output
+ * ([batch][C_stage][L_stage], the mean of the three ResBlocks) to tap_dev; stage -1 = har_source [batch][T*upp].
+ * tap_dev = NULL switches it off. */
+int rvc_decoder_set_tap(rvc_decoder *dec, int stage, float *tap_dev);
+
+/* ---- generic fp32 conv1d (the decoder's work-horse, exported for unit tests) -------------------- *
+ * y[b,co,t] = out_scale * ( bias[co] + sum_{ci,k} w[co,ci,k] * act(x[b,ci,t + (k - (K-1)/2)*dil]) + res[b,co,t] + acc[b,co,t] )
+ * with act = leaky_relu(slope_in) (slope_in = 1 -> identity), zero padding, K odd.
+ * w_packed_dev is the [K][C_in][C_out] repack produced by rvc_conv1d_pack_weight.
+ * res_dev / acc_dev / bias_dev may be NULL.  C_in % 8 == 0, C_out % 32 == 0. */
+int rvc_conv1d_pack_weight(const float *w_host, int c_out, int c_in, int k, float *w_packed_dev, void *stream);
+int rvc_conv1d_forward(const float *x_dev, const float *w_packed_dev, const float *bias_dev,
+                       const float *res_dev, const float *acc_dev, float *y_dev,
+                       int batch, int c_in, int c_out, int64_t length, int k, int dilation,
+                       float slope_in, float out_scale, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RVC_AMD_H */

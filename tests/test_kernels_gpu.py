@@ -1,0 +1,188 @@
+"""Parity of every HIP kernel against the oracle, through the C ABI (ctypes -> librvc_amd.so).
+
+Run on the MI355X box: python -m pytest tests -m gpu.  Tolerances are stated at each check:
+integer outputs (neighbour ids) are exact up to documented near-ties; waveforms are gated at the
+north_star's 1e-3 RMS with the observed error asserted far below it.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, rms
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from rvc_amd import _native
+    return _native
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+# ---- K3 conv1d ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("c_in,c_out,k,dil,length,batch", [
+    (32, 32, 3, 1, 1000, 1), (32, 32, 11, 5, 1537, 2), (64, 64, 7, 3, 700, 1), (128, 128, 11, 5, 513, 1),
+    (256, 256, 3, 3, 300, 2), (192, 512, 7, 1, 100, 1), (64, 64, 3, 5, 31, 1), (128, 128, 7, 1, 4097, 1),
+])
+def test_conv1d_matches_torch_fp32(native, dev, c_in, c_out, k, dil, length, batch):
+    g = torch.Generator().manual_seed(c_in * 1000 + k * 10 + dil)
+    x = torch.randn(batch, c_in, length, generator=g)
+    w = torch.randn(c_out, c_in, k, generator=g) / (c_in * k) ** 0.5
+    b = torch.randn(c_out, generator=g)
+    res = torch.randn(batch, c_out, length, generator=g)
+    acc = torch.randn(batch, c_out, length, generator=g)
+    ref = (F.conv1d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), padding=(k - 1) // 2 * dil, dilation=dil)
+           + res.double() + acc.double()) / 3
+    wp = native.conv1d_pack_weight(w, dev)
+    y = native.conv1d_forward(x.to(dev), wp, b.to(dev), c_out, k, dil, 0.1, res=res.to(dev), acc=acc.to(dev),
+                              out_scale=1 / 3)
+    err = (y.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-5, err  # fp32 fma chain vs float64 reference, |ref| ~ 1
+    # plain conv: no activation, no residual
+    y2 = native.conv1d_forward(x.to(dev), wp, None, c_out, k, dil, 1.0)
+    ref2 = F.conv1d(x.double(), w.double(), None, padding=(k - 1) // 2 * dil, dilation=dil)
+    assert (y2.cpu().double() - ref2).abs().max().item() <= 2e-5
+
+
+# ---- K1 kNN ------------------------------------------------------------------------------------------
+def _knn_case(native, dev, n_rows, n_q, seed):
+    from oracle import rvc_oracle as O
+    from rvc_amd.lib import synthetic as S
+    big = S.synth_index(n_rows, seed=seed)
+    rng = np.random.default_rng(seed + 100)
+    q = (big[rng.integers(0, n_rows, n_q)] + rng.standard_normal((n_q, 768)).astype(np.float32) * 0.03).astype(np.float32)
+    index = torch.from_numpy(big).to(dev)
+    norms = native.knn_index_norms(index)
+    assert torch.allclose(norms.cpu(), torch.from_numpy((big.astype(np.float64) ** 2).sum(1)).float(), rtol=1e-5)
+    d2, ids = native.knn_search(index, norms, torch.from_numpy(q).to(dev))
+    d2, ids = d2.cpu().numpy(), ids.cpu().numpy()
+    d2_ref, ids_ref = O.knn_search(big, q, 8, np.float64)
+    return big, q, d2, ids, d2_ref, ids_ref
+
+
+@pytest.mark.parametrize("n_rows,n_q", [(4096, 64), (10007, 129), (100, 5), (50000, 300)])
+def test_knn_ids_and_distances(native, dev, n_rows, n_q):
+    big, q, d2, ids, d2_ref, ids_ref = _knn_case(native, dev, n_rows, n_q, seed=3)
+    assert (np.diff(d2, axis=1) >= 0).all()  # ascending
+    # ids bit-exact except documented near-ties: where they differ, the true distances must agree to 1e-5 relative
+    mism = ids != ids_ref
+    if mism.any():
+        qi, ki = np.nonzero(mism)
+        true_d = ((q[qi].astype(np.float64) - big[ids[qi, ki]].astype(np.float64)) ** 2).sum(1)
+        assert np.all(np.abs(true_d - d2_ref[qi, ki]) <= 1e-5 * d2_ref[qi, ki]), "id mismatch that is not a near-tie"
+    assert mism.mean() <= 0.01
+    assert np.allclose(d2, d2_ref, rtol=2e-4, atol=1e-4)  # ||x||^2 - 2q.x + ||q||^2 in fp32 (faiss' own form)
+
+
+def test_knn_golden_and_blend(native, dev):
+    from rvc_amd.lib import synthetic as S
+    g = load_golden("knn")
+    big = S.synth_index(int(g["index_rows"]), seed=int(g["index_seed"]))
+    index = torch.from_numpy(big).to(dev)
+    norms = native.knn_index_norms(index)
+    q = torch.from_numpy(g["q"]).to(dev)
+    d2, ids = native.knn_search(index, norms, q)
+    assert np.array_equal(ids.cpu().numpy(), g["ids"])
+    blended = native.knn_blend(index, q, d2, ids, 0.75).cpu().numpy()
+    assert np.abs(blended - g["blended"][0]).max() <= 1e-4
+
+
+# ---- K4 log-mel --------------------------------------------------------------------------------------
+def test_logmel_golden(native, dev):
+    g = load_golden("logmel")
+    mel, t = native.logmel_rmvpe(torch.from_numpy(g["audio"]).to(dev), pad_to=32)
+    assert t == 101 and mel.shape == (1, 128, 128)
+    got = mel.cpu().numpy()
+    assert np.abs(got[:, :, :101] - g["mel"]).max() <= 2e-3  # log domain; DFT-by-GEMM vs FFT
+    ref_pad = F.pad(torch.from_numpy(g["mel"]), (0, 27), mode="reflect").numpy()
+    assert np.abs(got - ref_pad).max() <= 2e-3
+
+
+def test_logmel_long_batch(native, dev):
+    from oracle import rvc_oracle as O
+    from rvc_amd.lib import synthetic as S
+    a = np.stack([S.synth_audio(80000, seed=s) for s in (1, 2)]).astype(np.float32)
+    mel, t = native.logmel_rmvpe(torch.from_numpy(a).to(dev), pad_to=32)
+    ref = O.logmel_rmvpe(torch.from_numpy(a)).numpy()
+    assert t == ref.shape[-1] == 501
+    assert np.abs(mel.cpu().numpy()[:, :, :t] - ref).max() <= 2e-3
+
+
+# ---- K2/K3 decoder -----------------------------------------------------------------------------------
+def _decoder_inputs(ref_inputs, T, batch=1):
+    feats, f0c, f0f = ref_inputs
+    f0 = torch.from_numpy(f0f[:T]).float().unsqueeze(0).repeat(batch, 1)
+    if batch > 1:
+        f0[1] = torch.roll(f0[1], 7) * 1.3
+    return f0
+
+
+@pytest.mark.parametrize("tag,sr,voc", [("nsf48", 48000, "HiFi-GAN"), ("nsf40", 40000, "HiFi-GAN"),
+                                        ("nsf32", 32000, "HiFi-GAN"), ("mrf48", 48000, "MRF HiFi-GAN")])
+def test_decoder_matches_oracle(native, dev, ref_inputs, tag, sr, voc):
+    from oracle import rvc_oracle as O
+    from rvc_amd.lib import synthetic as S
+    from rvc_amd.lib.algorithm.weights import fold_weight_norm
+    T, batch = 64, 2
+    cpt = S.make_synth_checkpoint(sr, voc, seed=0)
+    w = O.fold_weight_norm(cpt["weight"])
+    rates, ksizes = cpt["config"][12], cpt["config"][14]
+    upp = int(np.prod(rates))
+    gen = torch.Generator().manual_seed(7)
+    z = torch.randn(batch, 192, T, generator=gen)
+    g = torch.randn(batch, 256, 1, generator=gen)
+    f0 = _decoder_inputs(ref_inputs, T, batch)
+    dim = 9 if voc.startswith("MRF") else 1
+    src_rand = torch.rand(batch, dim, generator=gen)
+    src_randn = torch.randn(batch, T * upp, dim, generator=gen)
+    outs = []
+    for b in range(batch):
+        if dim == 1:
+            noise = O.ListNoise([torch.zeros(1, 1, 1), src_randn[b:b + 1]])
+            o = O.decoder_nsf(w, z[b:b + 1], f0[b:b + 1], g[b:b + 1], rates, ksizes, sr, noise)
+        else:
+            noise = O.ListNoise([src_rand[b:b + 1].clone(), src_randn[b:b + 1]])
+            o = O.decoder_mrf(w, z[b:b + 1], f0[b:b + 1], g[b:b + 1], rates, ksizes, sr, noise)
+        outs.append(o)
+    ref = torch.cat(outs, 0).numpy()
+
+    folded = {k[4:]: v for k, v in fold_weight_norm(cpt["weight"]).items() if k.startswith("dec.")}
+    dec = native.Decoder(voc, sr, folded, upsample_rates=rates, upsample_kernel_sizes=ksizes)
+    assert dec.upp == upp
+    out = dec.forward(z.to(dev), f0.to(dev), g[:, :, 0].to(dev), src_randn=src_randn.to(dev),
+                      src_rand=src_rand.to(dev)).cpu().numpy()
+    assert out.shape == ref.shape
+    err = rms(out - ref)
+    assert rms(ref) > 0.02
+    assert err <= 5e-5, (tag, err)  # gate is 1e-3 (north_star); fp32 MFMA vs torch-CPU fp32 sits ~1e-6
+
+
+def test_decoder_full_synth_golden(native, dev, ref_inputs):
+    """Decoder fed with the golden z of the reference run reproduces the reference waveform."""
+    from oracle import rvc_oracle as O
+    from rvc_amd.lib import synthetic as S
+    from rvc_amd.lib.algorithm.weights import fold_weight_norm
+    g = load_golden("synth_nsf48")
+    feats, f0c, f0f = ref_inputs
+    T = int(g["T"])
+    cpt = S.make_synth_checkpoint(48000, "HiFi-GAN", seed=0)
+    folded_all = fold_weight_norm(cpt["weight"])
+    folded = {k[4:]: v for k, v in folded_all.items() if k.startswith("dec.")}
+    dec = native.Decoder("HiFi-GAN", 48000, folded)
+    # replay the reference's draws: randn_like(m_p), rand(1,1,1), randn_like(sine)
+    torch.manual_seed(int(g["seed"]))
+    torch.randn(1, 192, T)
+    torch.rand(1, 1, 1)
+    src_randn = torch.randn(1, T * 480, 1)
+    z = torch.from_numpy(g["z"]).unsqueeze(0)
+    gvec = folded_all["emb_g.weight"][int(g["sid"])].view(1, 256)
+    f0 = torch.from_numpy(f0f[:T]).float().unsqueeze(0)
+    out = dec.forward(z.to(dev), f0.to(dev), gvec.to(dev), src_randn=src_randn.to(dev)).cpu().numpy()[0, 0]
+    assert rms(out - g["o"]) <= 5e-5, rms(out - g["o"])
