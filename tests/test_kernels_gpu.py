@@ -71,12 +71,15 @@ def _knn_case(native, dev, n_rows, n_q, seed):
 def test_knn_ids_and_distances(native, dev, n_rows, n_q):
     big, q, d2, ids, d2_ref, ids_ref = _knn_case(native, dev, n_rows, n_q, seed=3)
     assert (np.diff(d2, axis=1) >= 0).all()  # ascending
-    # ids bit-exact except documented near-ties: where they differ, the true distances must agree to 1e-5 relative
+    # ids bit-exact except documented near-ties.  ||x||^2 - 2 q.x + ||q||^2 (faiss' own BLAS formulation) rounds at
+    # the granularity of the NORMS, not of d2: two candidates whose true distances differ by less than
+    # 8 ulp_fp32(||q||^2 + ||x||^2) are a tie for this algorithm and may swap places.
     mism = ids != ids_ref
     if mism.any():
         qi, ki = np.nonzero(mism)
         true_d = ((q[qi].astype(np.float64) - big[ids[qi, ki]].astype(np.float64)) ** 2).sum(1)
-        assert np.all(np.abs(true_d - d2_ref[qi, ki]) <= 1e-5 * d2_ref[qi, ki]), "id mismatch that is not a near-tie"
+        scale = (q[qi].astype(np.float64) ** 2).sum(1) + (big[ids[qi, ki]].astype(np.float64) ** 2).sum(1)
+        assert np.all(np.abs(true_d - d2_ref[qi, ki]) <= 8 * 1.1920929e-07 * scale), "id mismatch that is not a near-tie"
     assert mism.mean() <= 0.01
     assert np.allclose(d2, d2_ref, rtol=2e-4, atol=1e-4)  # ||x||^2 - 2q.x + ||q||^2 in fp32 (faiss' own form)
 
