@@ -1,0 +1,182 @@
+"""``VoiceConverter`` -- orchestration around the pipeline with the reference's surface
+(rvc/infer/infer.py:41-493).  File decoding/resampling, noise reduction and the pedalboard effects are out of
+scope: ``convert_audio`` handles WAV I/O through the standard library and expects
+16 kHz mono input, or use ``convert_array`` with a NumPy signal.
+"""
+from __future__ import annotations
+
+import os
+import time
+import traceback
+import wave
+
+import numpy as np
+import torch
+
+from rvc_amd.configs.config import Config
+from rvc_amd.infer.pipeline import Pipeline as VC
+from rvc_amd.lib.algorithm.synthesizers import Synthesizer
+from rvc_amd.lib.hubert import HubertModelWithFinalProj
+
+
+def _read_wav_16k_mono(path):
+    with wave.open(path, "rb") as f:
+        sr, ch, sw, n = f.getframerate(), f.getnchannels(), f.getsampwidth(), f.getnframes()
+        raw = f.readframes(n)
+    if sw != 2:
+        raise RuntimeError("only 16-bit PCM WAV input is supported without soundfile")
+    a = np.frombuffer(raw, dtype="<i2").astype(np.float64) / 32768.0
+    if ch > 1:
+        a = a.reshape(-1, ch).mean(1)
+    if sr != 16000:
+        raise RuntimeError(f"input must be 16 kHz (got {sr}); resampling (soxr) is outside the hot path")
+    return a
+
+
+def _write_wav(path, audio, sr):
+    pcm = np.clip(audio, -1.0, 1.0)
+    pcm = (pcm * 32767.0).astype("<i2")
+    with wave.open(path, "wb") as f:
+        f.setnchannels(1)
+        f.setsampwidth(2)
+        f.setframerate(int(sr))
+        f.writeframes(pcm.tobytes())
+
+
+class VoiceConverter:
+    def __init__(self, device: str | None = None):
+        self.config = Config(device)
+        self.hubert_model = None
+        self.last_embedder_model = None
+        self.tgt_sr = None
+        self.net_g = None
+        self.vc = None
+        self.cpt = None
+        self.version = None
+        self.n_spk = None
+        self.use_f0 = None
+        self.loaded_model = None
+
+    # ---- embedder (infer.py:64-74; file layout rvc/lib/utils.py:96-146) ----
+    def load_hubert(self, embedder_model: str, embedder_model_custom: str = None):
+        root = os.path.join(os.getcwd(), "rvc", "models", "embedders")
+        path = embedder_model_custom if embedder_model == "custom" and embedder_model_custom else \
+            os.path.join(root, {"chinese-hubert-base": "chinese_hubert_base", "japanese-hubert-base": "japanese_hubert_base",
+                                "korean-hubert-base": "korean_hubert_base"}.get(embedder_model, embedder_model))
+        sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+        self.load_hubert_state_dict(sd)
+
+    def load_hubert_state_dict(self, sd):
+        self.hubert_model = HubertModelWithFinalProj(sd, device=self.config.device).float().eval()
+
+    # ---- model (infer.py:416-493) ----
+    def get_vc(self, weight_root, sid):
+        if not self.loaded_model or self.loaded_model != weight_root:
+            self.load_model(weight_root)
+            if self.cpt is not None:
+                self.setup_network()
+                self.setup_vc_instance()
+            self.loaded_model = weight_root
+
+    def load_model(self, weight_root):
+        self.cpt = torch.load(weight_root, map_location="cpu", weights_only=True) if os.path.isfile(weight_root) else None
+
+    def load_checkpoint_dict(self, cpt: dict):
+        """Same as get_vc() for an in-memory checkpoint dict (extract_model.py:56-107 format)."""
+        self.cpt = dict(cpt)
+        self.cpt["config"] = list(cpt["config"])
+        self.setup_network()
+        self.setup_vc_instance()
+        self.loaded_model = cpt.get("model_name", "<dict>")
+
+    def setup_network(self):
+        if self.cpt is not None:
+            self.tgt_sr = self.cpt["config"][-1]
+            self.cpt["config"][-3] = self.cpt["weight"]["emb_g.weight"].shape[0]
+            self.use_f0 = self.cpt.get("f0", 1)
+            self.version = self.cpt.get("version", "v1")
+            self.text_enc_hidden_dim = 768 if self.version == "v2" else 256
+            self.vocoder = self.cpt.get("vocoder", "HiFi-GAN")
+            self.net_g = Synthesizer(*self.cpt["config"], use_f0=self.use_f0,
+                                     text_enc_hidden_dim=self.text_enc_hidden_dim, vocoder=self.vocoder)
+            del self.net_g.enc_q
+            self.net_g.load_state_dict(self.cpt["weight"], strict=False)
+            self.net_g = self.net_g.to(self.config.device).float()
+            self.net_g.eval()
+
+    def setup_vc_instance(self):
+        if self.cpt is not None:
+            self.vc = VC(self.tgt_sr, self.config)
+            self.n_spk = self.cpt["config"][-3]
+
+    # ---- conversion ----
+    def convert_array(self, audio: np.ndarray, *, index_path: str = "", pitch: int = 0, f0_file=None,
+                      f0_method: str = "rmvpe", index_rate: float = 0.75, volume_envelope: float = 1,
+                      protect: float = 0.5, hop_length: int = 128, f0_autotune: bool = False,
+                      f0_autotune_strength: float = 1, filter_radius: float = 3.0, sid: int = 0, noise_seed=None):
+        """The array-level core of convert_audio (infer.py:262-311): 16 kHz float array in, float32 @tgt_sr out."""
+        audio = np.asarray(audio, dtype=np.float64).copy()
+        audio_max = np.abs(audio).max() / 0.95  # infer.py:262-265
+        if audio_max > 1:
+            audio /= audio_max
+        file_index = index_path.strip().strip('"').strip("\n").strip('"').strip().replace("trained", "added")
+        return self.vc.pipeline(model=self.hubert_model, net_g=self.net_g, sid=sid, audio=audio, pitch=pitch,
+                                f0_method=f0_method, file_index=file_index, index_rate=index_rate,
+                                pitch_guidance=self.use_f0, filter_radius=filter_radius,
+                                volume_envelope=volume_envelope, version=self.version, protect=protect,
+                                hop_length=hop_length, f0_autotune=f0_autotune,
+                                f0_autotune_strength=f0_autotune_strength, f0_file=f0_file, noise_seed=noise_seed)
+
+    def convert_audio(self, audio_input_path: str, audio_output_path: str, model_path: str, index_path: str,
+                      pitch: int = 0, f0_file: str = None, f0_method: str = "rmvpe", index_rate: float = 0.75,
+                      volume_envelope: float = 1, protect: float = 0.5, hop_length: int = 128,
+                      split_audio: bool = False, f0_autotune: bool = False, f0_autotune_strength: float = 1,
+                      filter_radius: float = 3.0, embedder_model: str = "contentvec",
+                      embedder_model_custom: str = None, clean_audio: bool = False, clean_strength: float = 0.5,
+                      export_format: str = "WAV", post_process: bool = False, resample_sr: int = 0, sid: int = 0,
+                      **kwargs):
+        """infer.py:193-348: same arguments, defaults and error convention (never raises; prints and returns None)."""
+        if not model_path:
+            print("No model path provided. Aborting conversion.")
+            return
+        self.get_vc(model_path, sid)
+        try:
+            start_time = time.time()
+            print(f"Converting audio '{audio_input_path}'...")
+            if split_audio or clean_audio or post_process or export_format != "WAV":
+                raise NotImplementedError("split_audio / clean_audio / post_process / non-WAV export are outside "
+                                          "the hot path (SURVEY §2 items 2, 9)")
+            audio = _read_wav_16k_mono(audio_input_path)
+            if not self.hubert_model or embedder_model != self.last_embedder_model:
+                self.load_hubert(embedder_model, embedder_model_custom)
+                self.last_embedder_model = embedder_model
+            if self.tgt_sr != resample_sr >= 16000:  # infer.py:280-281
+                self.tgt_sr = resample_sr
+            audio_opt = self.convert_array(audio, index_path=index_path, pitch=pitch, f0_file=f0_file,
+                                           f0_method=f0_method, index_rate=index_rate,
+                                           volume_envelope=volume_envelope, protect=protect, hop_length=hop_length,
+                                           f0_autotune=f0_autotune, f0_autotune_strength=f0_autotune_strength,
+                                           filter_radius=filter_radius, sid=sid)
+            _write_wav(audio_output_path, audio_opt, self.tgt_sr)
+            print(f"Conversion completed at '{audio_output_path}' in {time.time() - start_time:.2f} seconds.")
+        except Exception as error:
+            print(f"An error occurred during audio conversion: {error}")
+            print(traceback.format_exc())
+
+    def convert_audio_batch(self, audio_input_paths: str, audio_output_path: str, **kwargs):
+        """infer.py:350-414: sequential loop over a folder, skipping existing outputs."""
+        try:
+            start_time = time.time()
+            print(f"Converting audio batch '{audio_input_paths}'...")
+            audio_files = [f for f in sorted(os.listdir(audio_input_paths)) if f.lower().endswith("wav")]
+            print(f"Detected {len(audio_files)} audio files for inference.")
+            for a in audio_files:
+                new_input = os.path.join(audio_input_paths, a)
+                new_output = os.path.join(audio_output_path, os.path.splitext(a)[0] + "_output.wav")
+                if os.path.exists(new_output):
+                    continue
+                self.convert_audio(audio_input_path=new_input, audio_output_path=new_output, **kwargs)
+            print(f"Batch conversion completed in {time.time() - start_time:.2f} seconds.")
+        except Exception as error:
+            print(f"An error occurred during audio batch conversion: {error}")
+            print(traceback.format_exc())

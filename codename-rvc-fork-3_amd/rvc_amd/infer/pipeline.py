@@ -1,0 +1,251 @@
+"""``Pipeline`` -- the per-utterance voice-conversion pipeline with the reference's method surface
+(rvc/infer/pipeline.py:117-694), rebuilt so that everything heavy stays on the MI355X:
+
+* HuBERT, TextEncoder, flow, RMVPE network: PyTorch-ROCm (fp32)
+* feature retrieval (``_retrieve_speaker_embeddings``), log-mel, vocoder: librvc_amd HIP kernels
+* float64 host math the reference pins with integers (filtfilt, split points, f0 quantisation) is kept
+  verbatim in NumPy/SciPy so those integers are bit-exact.
+
+Signatures and defaults follow the reference; additions are keyword-only and optional:
+``noise_seed`` (parity mode: reproduce the reference's CPU RNG stream) and ``set_index`` /
+``.npy`` index files (faiss is not a dependency here).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from scipy import signal
+
+from rvc_amd import _native
+from rvc_amd.lib.predictors.RMVPE import RMVPE0Predictor
+
+FILTER_ORDER = 5
+CUTOFF_FREQUENCY = 48  # Hz
+SAMPLE_RATE = 16000  # Hz
+bh, ah = signal.butter(N=FILTER_ORDER, Wn=CUTOFF_FREQUENCY, btype="high", fs=SAMPLE_RATE)  # pipeline.py:23-28
+
+
+class FeatureIndex:
+    """Device-resident replacement of the faiss index + ``big_npy`` pair (pipeline.py:553-556).
+
+    Exact squared-L2 search over the reconstructed vectors; truthy as a plain object, as the caller's
+    ``if index:`` requires (pipeline.py:456-458)."""
+
+    def __init__(self, big_npy, device):
+        if isinstance(big_npy, np.ndarray):
+            big_npy = torch.from_numpy(np.ascontiguousarray(big_npy, dtype=np.float32))
+        self.vectors = big_npy.to(device=device, dtype=torch.float32).contiguous()
+        self.norms = _native.knn_index_norms(self.vectors)
+        self.ntotal = int(self.vectors.shape[0])
+
+    def __bool__(self):
+        return True
+
+    def search_device(self, queries: torch.Tensor, k: int = 8):
+        return _native.knn_search(self.vectors, self.norms, queries, k)
+
+    def search(self, npy: np.ndarray, k: int = 8):
+        """faiss-style host API: (D2 [Q,k] float32 ascending, I [Q,k] int64)."""
+        d2, ids = self.search_device(torch.from_numpy(np.ascontiguousarray(npy, dtype=np.float32)).to(self.vectors.device), k)
+        return d2.cpu().numpy(), ids.cpu().numpy()
+
+    def reconstruct_n(self, start: int, n: int):
+        return self.vectors[start:start + n].cpu().numpy()
+
+
+def _load_index_file(path: str):
+    """``.npy`` holds big_npy directly; ``.index`` needs faiss (the reference's format, pipeline.py:555-556)."""
+    if path.endswith(".npy"):
+        return np.load(path)
+    import faiss  # noqa: F401  (optional; absent in this image)
+    index = faiss.read_index(path)
+    return index.reconstruct_n(0, index.ntotal)
+
+
+class Pipeline:
+    def __init__(self, tgt_sr, config):
+        self.x_pad, self.x_query, self.x_center, self.x_max = config.x_pad, config.x_query, config.x_center, config.x_max
+        self.sample_rate = 16000
+        self.window = 160
+        self.t_pad = self.sample_rate * self.x_pad
+        self.t_pad_tgt = tgt_sr * self.x_pad
+        self.t_pad2 = self.t_pad * 2
+        self.t_query = self.sample_rate * self.x_query
+        self.t_center = self.sample_rate * self.x_center
+        self.t_max = self.sample_rate * self.x_max
+        self.time_step = self.window / self.sample_rate * 1000
+        self.f0_min, self.f0_max = 50, 1100
+        self.f0_mel_min = 1127 * np.log(1 + self.f0_min / 700)
+        self.f0_mel_max = 1127 * np.log(1 + self.f0_max / 700)
+        self.device = config.device
+        rmvpe_path = os.path.join("rvc", "models", "predictors", "rmvpe.pt")  # pipeline.py:207-210
+        self.model_rmvpe = RMVPE0Predictor(rmvpe_path if os.path.isfile(rmvpe_path) else None, device=self.device)
+        self._index_cache = {}
+        self._preset_index = None
+
+    # ---- additions -------------------------------------------------------------------------------------
+    def load_rmvpe_state_dict(self, sd):
+        self.model_rmvpe.load_state_dict(sd)
+
+    def set_index(self, big_npy):
+        """Install a feature index directly (N x 768 float32) instead of reading a faiss file per call."""
+        self._preset_index = FeatureIndex(big_npy, self.device) if big_npy is not None else None
+
+    def _get_index(self, file_index, index_rate):
+        if index_rate <= 0:
+            return None
+        if file_index != "" and os.path.exists(file_index):
+            key = (file_index, os.path.getmtime(file_index))
+            if key not in self._index_cache:
+                try:
+                    self._index_cache = {key: FeatureIndex(_load_index_file(file_index), self.device)}
+                except Exception as error:  # pipeline.py:557-559: warn and continue without retrieval
+                    print(f"An error occurred reading the FAISS index: {error}")
+                    return None
+            return self._index_cache[key]
+        return self._preset_index
+
+    # ---- F0 ------------------------------------------------------------------------------------------------
+    def get_f0(self, input_audio_path, x, p_len, pitch, f0_method, filter_radius, hop_length, f0_autotune,
+               f0_autotune_strength, inp_f0=None):
+        """pipeline.py:322-410, rmvpe branch (the other estimators are out of scope)."""
+        if f0_method != "rmvpe":
+            raise NotImplementedError(f"f0_method={f0_method!r}: only 'rmvpe' is implemented")
+        if torch.is_tensor(x):
+            f0 = self.model_rmvpe.infer_from_audio_device(x, thred=0.03).cpu().numpy()
+        else:
+            f0 = self.model_rmvpe.infer_from_audio(x, thred=0.03)
+        if f0_autotune is True:
+            raise NotImplementedError("f0_autotune is not implemented")
+        f0 *= pow(2, pitch / 12)
+        tf0 = self.sample_rate // self.window
+        if inp_f0 is not None:  # pipeline.py:390-400
+            delta_t = np.round((inp_f0[:, 0].max() - inp_f0[:, 0].min()) * tf0 + 1).astype("int16")
+            replace_f0 = np.interp(list(range(delta_t)), inp_f0[:, 0] * 100, inp_f0[:, 1])
+            shape = f0[self.x_pad * tf0: self.x_pad * tf0 + len(replace_f0)].shape[0]
+            f0[self.x_pad * tf0: self.x_pad * tf0 + len(replace_f0)] = replace_f0[:shape]
+        f0bak = f0.copy()
+        f0_mel = 1127 * np.log(1 + f0 / 700)
+        f0_mel[f0_mel > 0] = (f0_mel[f0_mel > 0] - self.f0_mel_min) * 254 / (self.f0_mel_max - self.f0_mel_min) + 1
+        f0_mel[f0_mel <= 1] = 1
+        f0_mel[f0_mel > 255] = 255
+        return np.rint(f0_mel).astype(int), f0bak
+
+    # ---- per-segment conversion -------------------------------------------------------------------------
+    def voice_conversion(self, model, net_g, sid, audio0, pitch, pitchf, index, big_npy, index_rate, version, protect,
+                         noise=None, as_tensor=False):
+        """pipeline.py:412-495.  ``audio0``: NumPy or device tensor (1-D, 16 kHz)."""
+        with torch.no_grad():
+            pitch_guidance = pitch is not None and pitchf is not None
+            if torch.is_tensor(audio0):
+                feats = audio0.to(self.device).float()
+            else:
+                feats = torch.from_numpy(np.ascontiguousarray(audio0)).float().to(self.device)
+            feats = feats.mean(-1) if feats.dim() == 2 else feats
+            assert feats.dim() == 1, feats.dim()
+            n_audio = feats.shape[0]
+            feats = model(feats.view(1, -1))["last_hidden_state"]
+            feats = model.final_proj(feats[0]).unsqueeze(0) if version == "v1" else feats
+            feats0 = feats.clone() if pitch_guidance else None
+            if index:
+                feats = self._retrieve_speaker_embeddings(feats, index, big_npy, index_rate)
+            feats = F.interpolate(feats.permute(0, 2, 1), scale_factor=2).permute(0, 2, 1)
+            p_len = min(n_audio // self.window, feats.shape[1])
+            if pitch_guidance:
+                feats0 = F.interpolate(feats0.permute(0, 2, 1), scale_factor=2).permute(0, 2, 1)
+                pitch, pitchf = pitch[:, :p_len], pitchf[:, :p_len]
+                if protect < 0.5:  # pipeline.py:474-481
+                    pitchff = pitchf.clone()
+                    pitchff[pitchf > 0] = 1
+                    pitchff[pitchf < 1] = protect
+                    feats = feats * pitchff.unsqueeze(-1) + feats0 * (1 - pitchff.unsqueeze(-1))
+                    feats = feats.to(feats0.dtype)
+            else:
+                raise NotImplementedError("models without pitch guidance are not supported (SURVEY §2 item 3b)")
+            p_len_t = torch.tensor([p_len], device=self.device).long()
+            audio1 = net_g.infer(feats.float(), p_len_t, pitch, pitchf.float(), sid, noise=noise)[0][0, 0]
+            if as_tensor:
+                return audio1
+            return audio1.data.cpu().float().numpy()
+
+    def _retrieve_speaker_embeddings(self, feats, index, big_npy, index_rate):
+        """pipeline.py:497-507 without the device->host->faiss->device round trip: exact L2 top-8 and the
+        (1/d^2)^2 blend both run in HBM (librvc_amd rvc_knn_search / rvc_knn_blend)."""
+        if not isinstance(index, FeatureIndex):  # a foreign index object with the faiss API: wrap its vectors once
+            index = FeatureIndex(big_npy, self.device)
+        q = feats[0].contiguous()
+        d2, ids = index.search_device(q, 8)
+        return _native.knn_blend(index.vectors, q, d2, ids, float(index_rate)).unsqueeze(0)
+
+    # ---- whole utterance ------------------------------------------------------------------------------------
+    def pipeline(self, model, net_g, sid, audio, pitch, f0_method, file_index, index_rate, pitch_guidance,
+                 filter_radius, volume_envelope, version, protect, hop_length, f0_autotune, f0_autotune_strength,
+                 f0_file, *, noise_seed=None):
+        """pipeline.py:509-694.  ``audio``: 1-D float NumPy @16 kHz -> float32 NumPy @tgt_sr.
+
+        noise_seed: None -> noise is drawn on the device; int -> parity mode: seed torch's CPU generator and
+        draw every random tensor in the reference's order (including the 12 LayerDrop draws transformers'
+        HuBERT makes per forward), so the result matches the reference CPU path run under the same seed."""
+        if volume_envelope != 1:
+            raise NotImplementedError("volume_envelope != 1 (change_rms) is not implemented (SURVEY §8 a19)")
+        if not pitch_guidance:
+            raise NotImplementedError("models without pitch guidance are not supported (SURVEY §2 item 3b)")
+        index = self._get_index(file_index, index_rate)
+        big_npy = index.vectors if index is not None else None
+        audio = signal.filtfilt(bh, ah, audio)
+        audio_pad = np.pad(audio, (self.window // 2, self.window // 2), mode="reflect")
+        opt_ts = []
+        if audio_pad.shape[0] > self.t_max:  # pipeline.py:565-577
+            audio_sum = np.zeros_like(audio)
+            for i in range(self.window):
+                audio_sum += audio_pad[i: i - self.window]
+            for t in range(self.t_center, audio.shape[0], self.t_center):
+                seg = np.abs(audio_sum[t - self.t_query: t + self.t_query])
+                opt_ts.append(t - self.t_query + np.where(seg == seg.min())[0][0])
+        s = 0
+        audio_opt = []
+        t = None
+        audio_pad = np.pad(audio, (self.t_pad, self.t_pad), mode="reflect")
+        p_len = audio_pad.shape[0] // self.window
+        inp_f0 = None
+        if hasattr(f0_file, "name"):  # pipeline.py:584-593
+            try:
+                with open(f0_file.name, "r") as f:
+                    lines = f.read().strip("\n").split("\n")
+                inp_f0 = np.array([[float(i) for i in line.split(",")] for line in lines], dtype="float32")
+            except Exception as error:
+                print(f"An error occurred reading the F0 file: {error}")
+        sid = torch.tensor(sid, device=self.device).unsqueeze(0).long()
+        audio_dev = torch.from_numpy(audio_pad).float().to(self.device)  # one upload; segments are views of it
+
+        noise = None
+        if noise_seed is not None:
+            torch.manual_seed(int(noise_seed))
+            noise = "cpu"
+        model.consume_layerdrop_rng = noise_seed is not None
+
+        pitch, pitchf = self.get_f0("input_audio_path", audio_dev, p_len, pitch, f0_method, filter_radius, hop_length,
+                                    f0_autotune, f0_autotune_strength, inp_f0)
+        pitch, pitchf = pitch[:p_len], pitchf[:p_len]
+        pitch = torch.tensor(pitch, device=self.device).unsqueeze(0).long()
+        pitchf = torch.tensor(pitchf, device=self.device).unsqueeze(0).float()
+        for t in opt_ts:
+            t = t // self.window * self.window
+            seg = self.voice_conversion(model, net_g, sid, audio_dev[s: t + self.t_pad2 + self.window],
+                                        pitch[:, s // self.window: (t + self.t_pad2) // self.window],
+                                        pitchf[:, s // self.window: (t + self.t_pad2) // self.window],
+                                        index, big_npy, index_rate, version, protect, noise=noise, as_tensor=True)
+            audio_opt.append(seg[self.t_pad_tgt: -self.t_pad_tgt])
+            s = t
+        seg = self.voice_conversion(model, net_g, sid, audio_dev[t:] if t is not None else audio_dev,
+                                    pitch[:, t // self.window:] if t is not None else pitch,
+                                    pitchf[:, t // self.window:] if t is not None else pitchf,
+                                    index, big_npy, index_rate, version, protect, noise=noise, as_tensor=True)
+        audio_opt.append(seg[self.t_pad_tgt: -self.t_pad_tgt])
+        out = torch.cat(audio_opt) if len(audio_opt) > 1 else audio_opt[0]
+        audio_max = out.abs().max() / 0.99  # pipeline.py:686-688
+        out = torch.where(audio_max > 1, out / audio_max, out)
+        return out.cpu().numpy()

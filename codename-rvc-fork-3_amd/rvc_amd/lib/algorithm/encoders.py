@@ -1,0 +1,81 @@
+"""TextEncoder on PyTorch-ROCm (rvc/lib/algorithm/encoders.py:88-144, attentions.py:6-243,
+normalization.py:19-26), functional over the folded state dict.
+
+Differences from the reference that do not change the arithmetic being computed:
+* the window-10 relative-position terms are applied in banded form (21 diagonals) instead of through
+  zero-padded [T, 2T-1] tables and pad/reshape tricks (attentions.py:143-180), which at T = 3198 saves
+  two 164 MB intermediates per layer;
+* the attention mask is skipped when every frame is valid (single utterances: lengths == T).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+WINDOW = 10
+
+
+def channel_layer_norm(x, gamma, beta, eps=1e-5):
+    return F.layer_norm(x.transpose(1, -1), (x.shape[1],), gamma, beta, eps).transpose(1, -1)
+
+
+def rel_attention(x, w: Dict[str, torch.Tensor], p: str, n_heads: int, attn_mask: Optional[torch.Tensor]):
+    q = F.conv1d(x, w[p + ".conv_q.weight"], w[p + ".conv_q.bias"])
+    k = F.conv1d(x, w[p + ".conv_k.weight"], w[p + ".conv_k.bias"])
+    v = F.conv1d(x, w[p + ".conv_v.weight"], w[p + ".conv_v.bias"])
+    b, d, t = q.shape
+    kc = d // n_heads
+    q = q.view(b, n_heads, kc, t).transpose(2, 3)
+    k = k.view(b, n_heads, kc, t).transpose(2, 3)
+    v = v.view(b, n_heads, kc, t).transpose(2, 3)
+    qs = q / math.sqrt(kc)
+    scores = torch.matmul(qs, k.transpose(-2, -1))
+    ek, ev = w[p + ".emb_rel_k"][0], w[p + ".emb_rel_v"][0]
+    rel_logits = torch.matmul(qs, ek.t())  # [b,h,t,21]
+    for r in range(2 * WINDOW + 1):
+        off = r - WINDOW
+        i0, i1 = max(0, -off), min(t, t - off)
+        if i0 < i1:
+            torch.diagonal(scores, off, -2, -1).add_(rel_logits[:, :, i0:i1, r])
+    if attn_mask is not None:
+        scores = scores.masked_fill(attn_mask == 0, -1e4)
+    p_attn = F.softmax(scores, dim=-1)
+    out = torch.matmul(p_attn, v)
+    band = torch.zeros(b, n_heads, t, 2 * WINDOW + 1, dtype=x.dtype, device=x.device)
+    for r in range(2 * WINDOW + 1):
+        off = r - WINDOW
+        i0, i1 = max(0, -off), min(t, t - off)
+        if i0 < i1:
+            band[:, :, i0:i1, r] = torch.diagonal(p_attn, off, -2, -1)
+    out = out + torch.matmul(band, ev)
+    out = out.transpose(2, 3).contiguous().view(b, d, t)
+    return F.conv1d(out, w[p + ".conv_o.weight"], w[p + ".conv_o.bias"])
+
+
+def text_encoder(w: Dict[str, torch.Tensor], phone, pitch, lengths, *, hidden=192, out_channels=192, n_heads=2,
+                 n_layers=6, kernel_size=3):
+    x = F.linear(phone, w["enc_p.emb_phone.weight"], w["enc_p.emb_phone.bias"])
+    if pitch is not None:
+        x = x + F.embedding(pitch, w["enc_p.emb_pitch.weight"])
+    x = F.leaky_relu(x * math.sqrt(hidden), 0.1)
+    x = x.transpose(1, -1)
+    t = x.size(2)
+    x_mask = (torch.arange(t, device=x.device)[None, :] < lengths[:, None]).unsqueeze(1).to(x.dtype)
+    full = bool((lengths == t).all())
+    attn_mask = None if full else x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
+    pad = (kernel_size - 1) // 2
+    x = x * x_mask
+    for i in range(n_layers):
+        y = rel_attention(x, w, f"enc_p.encoder.attn_layers.{i}", n_heads, attn_mask)
+        x = channel_layer_norm(x + y, w[f"enc_p.encoder.norm_layers_1.{i}.gamma"], w[f"enc_p.encoder.norm_layers_1.{i}.beta"])
+        f = f"enc_p.encoder.ffn_layers.{i}"
+        y = torch.relu(F.conv1d(x * x_mask, w[f + ".conv_1.weight"], w[f + ".conv_1.bias"], padding=pad))
+        y = F.conv1d(y * x_mask, w[f + ".conv_2.weight"], w[f + ".conv_2.bias"], padding=pad) * x_mask
+        x = channel_layer_norm(x + y, w[f"enc_p.encoder.norm_layers_2.{i}.gamma"], w[f"enc_p.encoder.norm_layers_2.{i}.beta"])
+    x = x * x_mask
+    stats = F.conv1d(x, w["enc_p.proj.weight"], w["enc_p.proj.bias"]) * x_mask
+    m, logs = torch.split(stats, out_channels, dim=1)
+    return m, logs, x_mask

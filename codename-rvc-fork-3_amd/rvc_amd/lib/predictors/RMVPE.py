@@ -1,0 +1,135 @@
+"""RMVPE F0 estimator on the GPU (rvc/lib/predictors/RMVPE.py).
+
+* log-mel front end  -> librvc_amd ``rvc_logmel_rmvpe`` (HIP; RMVPE.py:342-417, reflect pad of :452-455 fused)
+* E2E network        -> PyTorch-ROCm, functional over the reference's state dict (RMVPE.py:289-339), BatchNorm
+                        (eval) folded into the convolutions at load
+* salience decode    -> vectorised on the device in float64 (RMVPE.py:459-512 runs a Python loop per frame)
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+N_MELS, N_CLASS = 128, 360
+
+
+def _fold_bn(conv_w: torch.Tensor, sd, bn: str, out_dim: int = 0, eps: float = 1e-5):
+    scale = sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + eps)
+    shift = sd[bn + ".bias"].double() - sd[bn + ".running_mean"].double() * scale
+    shape = [1] * conv_w.dim()
+    shape[out_dim] = -1
+    return (conv_w.double() * scale.view(shape)).float(), shift.float()
+
+
+class RMVPE0Predictor:
+    def __init__(self, model_path=None, device=None, state_dict: Dict[str, torch.Tensor] | None = None):
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self.w: Dict[str, torch.Tensor] = {}
+        if state_dict is None and model_path is not None:
+            state_dict = torch.load(model_path, map_location="cpu", weights_only=True)
+        if state_dict is not None:
+            self.load_state_dict(state_dict)
+        cents = 20 * np.arange(N_CLASS) + 1997.3794084376191  # RMVPE.py:441-442
+        self.cents_mapping = torch.from_numpy(np.pad(cents, (4, 4))).to(self.device)
+
+    def load_state_dict(self, sd):
+        w = {}
+        sd = {k: v.float() if v.is_floating_point() else v for k, v in sd.items()}
+
+        def block(p):
+            w[p + ".c1.w"], w[p + ".c1.b"] = _fold_bn(sd[p + ".conv.0.weight"], sd, p + ".conv.1")
+            w[p + ".c2.w"], w[p + ".c2.b"] = _fold_bn(sd[p + ".conv.3.weight"], sd, p + ".conv.4")
+            if p + ".shortcut.weight" in sd:
+                w[p + ".sc.w"], w[p + ".sc.b"] = sd[p + ".shortcut.weight"], sd[p + ".shortcut.bias"]
+
+        bn = "unet.encoder.bn"
+        s = sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + 1e-5)
+        w["in.scale"] = s.float()
+        w["in.shift"] = (sd[bn + ".bias"].double() - sd[bn + ".running_mean"].double() * s).float()
+        for i in range(5):
+            for m in range(4):
+                block(f"unet.encoder.layers.{i}.conv.{m}")
+        for i in range(4):
+            for m in range(4):
+                block(f"unet.intermediate.layers.{i}.conv.{m}")
+        for i in range(5):
+            p = f"unet.decoder.layers.{i}"
+            w[p + ".up.w"], w[p + ".up.b"] = _fold_bn(sd[p + ".conv1.0.weight"], sd, p + ".conv1.1", out_dim=1)
+            for m in range(4):
+                block(f"{p}.conv2.{m}")
+        w["cnn.w"], w["cnn.b"] = sd["cnn.weight"], sd["cnn.bias"]
+        for sfx in ("", "_reverse"):
+            for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+                w["gru." + n + sfx] = sd["fc.0.gru." + n + sfx]
+        w["fc.w"], w["fc.b"] = sd["fc.1.weight"], sd["fc.1.bias"]
+        self.w = {k: v.to(self.device).contiguous() for k, v in w.items()}
+        self._gru_flat = [self.w["gru." + n + sfx] for sfx in ("", "_reverse")
+                          for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")]
+        return self
+
+    def _block(self, x, p):
+        w = self.w
+        y = F.relu(F.conv2d(x, w[p + ".c1.w"], w[p + ".c1.b"], 1, 1))
+        y = F.relu(F.conv2d(y, w[p + ".c2.w"], w[p + ".c2.b"], 1, 1))
+        if p + ".sc.w" in w:
+            return y + F.conv2d(x, w[p + ".sc.w"], w[p + ".sc.b"])
+        return y + x
+
+    @torch.no_grad()
+    def mel2hidden(self, mel: torch.Tensor, n_frames: int) -> torch.Tensor:
+        """mel [B,128,T32] (frame axis already reflect-padded to a multiple of 32) -> salience [B,n_frames,360]."""
+        w = self.w
+        x = mel.transpose(-1, -2).unsqueeze(1)
+        x = x * w["in.scale"] + w["in.shift"]
+        skips = []
+        for i in range(5):
+            for m in range(4):
+                x = self._block(x, f"unet.encoder.layers.{i}.conv.{m}")
+            skips.append(x)
+            x = F.avg_pool2d(x, (2, 2))
+        for i in range(4):
+            for m in range(4):
+                x = self._block(x, f"unet.intermediate.layers.{i}.conv.{m}")
+        for i in range(5):
+            p = f"unet.decoder.layers.{i}"
+            x = F.relu(F.conv_transpose2d(x, w[p + ".up.w"], w[p + ".up.b"], stride=(2, 2), padding=(1, 1),
+                                          output_padding=(1, 1)))
+            x = torch.cat((x, skips[-1 - i]), dim=1)
+            for m in range(4):
+                x = self._block(x, f"{p}.conv2.{m}")
+        x = F.conv2d(x, w["cnn.w"], w["cnn.b"], 1, 1)
+        x = x.transpose(1, 2).flatten(-2)
+        h0 = torch.zeros(2, x.shape[0], 256, dtype=x.dtype, device=x.device)
+        x = torch._VF.gru(x.contiguous(), h0, self._gru_flat, True, 1, 0.0, False, True, True)[0]
+        return torch.sigmoid(F.linear(x, w["fc.w"], w["fc.b"]))[:, :n_frames]
+
+    @torch.no_grad()
+    def decode(self, hidden: torch.Tensor, thred=0.03) -> torch.Tensor:
+        """salience [T,360] (device) -> f0 [T] float64 (device); RMVPE.py:459-512."""
+        center = torch.argmax(hidden, dim=1)
+        sal = F.pad(hidden, (4, 4)).double()
+        idx = center[:, None] + torch.arange(9, device=hidden.device)[None, :]  # (center+4) - 4 .. +4
+        todo = torch.gather(sal, 1, idx)
+        cents_w = self.cents_mapping[idx]
+        cents = (todo * cents_w).sum(1) / todo.sum(1)
+        cents = torch.where(hidden.max(dim=1).values <= thred, torch.zeros_like(cents), cents)
+        f0 = 10 * torch.pow(2.0, cents / 1200)
+        return torch.where(f0 == 10, torch.zeros_like(f0), f0)
+
+    @torch.no_grad()
+    def infer_from_audio_device(self, audio: torch.Tensor, thred=0.03) -> torch.Tensor:
+        """audio [n] or [1,n] float32 on the device -> f0 float64 on the device."""
+        from rvc_amd import _native
+        if audio.dim() == 1:
+            audio = audio.unsqueeze(0)
+        mel, n_frames = _native.logmel_rmvpe(audio.float(), pad_to=32)
+        hidden = self.mel2hidden(mel, n_frames)
+        return self.decode(hidden[0], thred)
+
+    def infer_from_audio(self, audio, thred=0.03) -> np.ndarray:
+        """Reference signature (RMVPE.py:472-485): NumPy audio in, NumPy float64 f0 out."""
+        a = torch.from_numpy(np.ascontiguousarray(audio)).float().to(self.device)
+        return self.infer_from_audio_device(a, thred).cpu().numpy()
