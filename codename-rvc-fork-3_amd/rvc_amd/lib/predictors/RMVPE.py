@@ -110,11 +110,15 @@ class RMVPE0Predictor:
     def decode(self, hidden: torch.Tensor, thred=0.03) -> torch.Tensor:
         """salience [T,360] (device) -> f0 [T] float64 (device); RMVPE.py:459-512."""
         center = torch.argmax(hidden, dim=1)
-        sal = F.pad(hidden, (4, 4)).double()
+        sal = F.pad(hidden, (4, 4))
         idx = center[:, None] + torch.arange(9, device=hidden.device)[None, :]  # (center+4) - 4 .. +4
-        todo = torch.gather(sal, 1, idx)
-        cents_w = self.cents_mapping[idx]
-        cents = (todo * cents_w).sum(1) / todo.sum(1)
+        todo = torch.gather(sal, 1, idx)                     # float32, like the reference's todo_salience
+        prod = todo.double() * self.cents_mapping[idx]       # float32 * float64 -> float64 (NumPy promotion)
+
+        def pairwise9(t):  # NumPy's pairwise reduction order for 9 contiguous elements
+            return (((t[:, 0] + t[:, 1]) + (t[:, 2] + t[:, 3])) + ((t[:, 4] + t[:, 5]) + (t[:, 6] + t[:, 7]))) + t[:, 8]
+
+        cents = pairwise9(prod) / pairwise9(todo).double()   # weight_sum is a float32 sum in the reference
         cents = torch.where(hidden.max(dim=1).values <= thred, torch.zeros_like(cents), cents)
         f0 = 10 * torch.pow(2.0, cents / 1200)
         return torch.where(f0 == 10, torch.zeros_like(f0), f0)
