@@ -66,8 +66,11 @@ class RMVPE0Predictor:
                 w["gru." + n + sfx] = sd["fc.0.gru." + n + sfx]
         w["fc.w"], w["fc.b"] = sd["fc.1.weight"], sd["fc.1.bias"]
         self.w = {k: v.to(self.device).contiguous() for k, v in w.items()}
-        self._gru_flat = [self.w["gru." + n + sfx] for sfx in ("", "_reverse")
-                          for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")]
+        # BiGRU: one GEMM for the input projections of both directions, recurrence in librvc_amd (gru.hip)
+        self.w["gru.wih"] = torch.cat([self.w["gru.weight_ih_l0"], self.w["gru.weight_ih_l0_reverse"]], 0).contiguous()
+        self.w["gru.bih"] = torch.cat([self.w["gru.bias_ih_l0"], self.w["gru.bias_ih_l0_reverse"]], 0).contiguous()
+        self.w["gru.whhT"] = torch.stack([self.w["gru.weight_hh_l0"].t(), self.w["gru.weight_hh_l0_reverse"].t()], 0).contiguous()
+        self.w["gru.bhh"] = torch.stack([self.w["gru.bias_hh_l0"], self.w["gru.bias_hh_l0_reverse"]], 0).contiguous()
         return self
 
     def _block(self, x, p):
@@ -102,8 +105,9 @@ class RMVPE0Predictor:
                 x = self._block(x, f"{p}.conv2.{m}")
         x = F.conv2d(x, w["cnn.w"], w["cnn.b"], 1, 1)
         x = x.transpose(1, 2).flatten(-2)
-        h0 = torch.zeros(2, x.shape[0], 256, dtype=x.dtype, device=x.device)
-        x = torch._VF.gru(x.contiguous(), h0, self._gru_flat, True, 1, 0.0, False, True, True)[0]
+        from rvc_amd import _native
+        gi = F.linear(x, w["gru.wih"], w["gru.bih"]).view(x.shape[0], x.shape[1], 2, 768)
+        x = _native.bigru_forward(gi, w["gru.whhT"], w["gru.bhh"])
         return torch.sigmoid(F.linear(x, w["fc.w"], w["fc.b"]))[:, :n_frames]
 
     @torch.no_grad()

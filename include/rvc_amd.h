@@ -73,6 +73,15 @@ int rvc_logmel_workspace_bytes(int batch, int64_t n_samples, size_t *bytes);
 int rvc_logmel_rmvpe(const float *audio_dev, int batch, int64_t n_samples, float *mel_dev,
                      int64_t n_frames_padded, void *workspace_dev, size_t workspace_bytes, void *stream);
 
+/* ---- K5: RMVPE BiGRU recurrence -------------------------------------------------------------- *
+ * Replaces the sequential part of `self.gru(x)[0]` (rvc/lib/predictors/RMVPE.py:515-536, nn.GRU(384, 256,
+ * num_layers=1, batch_first, bidirectional)).  The caller computes the input projections for all steps with one
+ * GEMM: gi_dev [batch][n_steps][2][768] = W_ih x_t + b_ih (direction 0 = forward, 1 = reverse; gate order r,z,n).
+ * whhT_dev [2][256][768] = W_hh transposed per direction, bhh_dev [2][768]; out_dev [batch][n_steps][512]
+ * (forward hidden in [0,256), reverse in [256,512), as torch lays it out). */
+int rvc_bigru_forward(const float *gi_dev, const float *whhT_dev, const float *bhh_dev, float *out_dev,
+                      int batch, int64_t n_steps, int hidden, void *stream);
+
 /* ---- K2/K3: vocoder ("dec" of Synthesizer) ---------------------------------------------------- *
  * Replaces `self.dec(z * x_mask, nsff0, g=g)` at rvc/lib/algorithm/synthesizers.py:254-258, i.e.
  *   RVC_DEC_NSF    HiFiGANNSFGenerator.forward  rvc/lib/algorithm/generators/hifigan_nsf.py:173-207

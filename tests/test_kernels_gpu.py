@@ -189,3 +189,22 @@ def test_decoder_full_synth_golden(native, dev, ref_inputs):
     f0 = torch.from_numpy(f0f[:T]).float().unsqueeze(0)
     out = dec.forward(z.to(dev), f0.to(dev), gvec.to(dev), src_randn=src_randn.to(dev)).cpu().numpy()[0, 0]
     assert rms(out - g["o"]) <= 5e-5, rms(out - g["o"])
+
+
+# ---- K5 BiGRU ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("batch,steps", [(1, 96), (2, 333)])
+def test_bigru_matches_torch_gru(native, dev, batch, steps):
+    torch.manual_seed(5)
+    gru = torch.nn.GRU(384, 256, num_layers=1, batch_first=True, bidirectional=True).eval()
+    x = torch.randn(batch, steps, 384)
+    with torch.no_grad():
+        ref = gru(x)[0]
+    sd = gru.state_dict()
+    wih = torch.cat([sd["weight_ih_l0"], sd["weight_ih_l0_reverse"]], 0)
+    bih = torch.cat([sd["bias_ih_l0"], sd["bias_ih_l0_reverse"]], 0)
+    gi = F.linear(x, wih, bih).view(batch, steps, 2, 768)
+    whh_t = torch.stack([sd["weight_hh_l0"].t(), sd["weight_hh_l0_reverse"].t()], 0).contiguous()
+    bhh = torch.stack([sd["bias_hh_l0"], sd["bias_hh_l0_reverse"]], 0).contiguous()
+    out = native.bigru_forward(gi.to(dev), whh_t.to(dev), bhh.to(dev)).cpu()
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max().item() <= 2e-5
