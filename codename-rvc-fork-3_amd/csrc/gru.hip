@@ -82,17 +82,152 @@ bigru_kernel(const float *__restrict__ gi,      // [B][T][2][768]  W_ih x + b_ih
     }
 }
 
+
+// ---- multi-CU variant: weights register-resident, h exchanged through 8-byte {epoch, value} granules ----------
+// GRU_CUS workgroups per (direction, batch item); workgroup c owns hidden units [64c, 64c+64): its 192 gate rows x 256
+// columns of W_hh live in VGPRs (64 per thread, thread = (row, k-quarter)), so a step touches no weight memory at
+// all.  After the gate math the 64 new h values are published as self-validating granules (one aligned 8-byte
+// write-through store each: tag = step + 1, no separate flag, no fence -- cdna_hip_programming.md §6 G16 form R2);
+// one wave polls the 192 foreign granules with relaxed agent-scope loads.  Two parities of the exchange buffer are
+// enough: a workgroup cannot get two steps ahead of a peer whose step-s value it still needs.
+// Every spin is bounded; on a timeout the workgroup stops polling and poisons its output with NaN.
+constexpr int GRU_CUS = 4;
+constexpr int GRU_UNITS = GRU_H / GRU_CUS;      // 64 hidden units per workgroup
+constexpr int GRU_ROWS = 3 * GRU_UNITS;         // 192 gate rows per workgroup
+constexpr int GRU_HS = 68;                      // LDS stride between k-quarters of h (bank spread for the b128 reads)
+constexpr unsigned GRU_SPIN_LIMIT = 1u << 22;
+
+typedef unsigned long long u64;
+
+__global__ void __launch_bounds__(GRU_THREADS)
+bigru_mc_kernel(const float *__restrict__ gi, const float *__restrict__ whhT, const float *__restrict__ bhh,
+                float *__restrict__ out, u64 *__restrict__ xchg, int T) {
+    __shared__ __attribute__((aligned(16))) float h_s[4 * GRU_HS];
+    __shared__ float g_s[GRU_ROWS];
+    __shared__ int dead_s;
+    const int tid = threadIdx.x;
+    const int c = blockIdx.x % GRU_CUS;
+    const int dir = blockIdx.x / GRU_CUS;
+    const int b = blockIdx.y;
+    const int q = tid & 3;            // k quarter
+    const int r = tid >> 2;           // local gate row 0..191
+    const int gate = r / GRU_UNITS;
+    const int ul = r % GRU_UNITS;
+    const int j = gate * GRU_H + c * GRU_UNITS + ul;   // global gate row
+    const float *W = whhT + (size_t)dir * GRU_H * GRU_G;
+    float w[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) w[i] = W[(size_t)(64 * q + i) * GRU_G + j];
+    const float *gib = gi + (size_t)b * T * 2 * GRU_G + (size_t)dir * GRU_G + c * GRU_UNITS;
+    float *outb = out + (size_t)b * T * 2 * GRU_H + dir * GRU_H + c * GRU_UNITS;
+    u64 *xb = xchg + ((size_t)b * 2 + dir) * 2 * GRU_H;   // [parity][256]
+    float b_r = 0.f, b_z = 0.f, b_n = 0.f;
+    if (tid < GRU_UNITS) {
+        b_r = bhh[dir * GRU_G + c * GRU_UNITS + tid];
+        b_z = bhh[dir * GRU_G + GRU_H + c * GRU_UNITS + tid];
+        b_n = bhh[dir * GRU_G + 2 * GRU_H + c * GRU_UNITS + tid];
+    }
+    if (tid < 4 * GRU_HS) h_s[tid] = 0.f;
+    if (tid == 0) dead_s = 0;
+    __syncthreads();
+    const float4 *hq = reinterpret_cast<const float4 *>(h_s + GRU_HS * q);
+    for (int s = 0; s < T; ++s) {
+        const int t = dir == 0 ? s : T - 1 - s;
+        float gr = 0.f, gz = 0.f, gn = 0.f;
+        if (tid < GRU_UNITS) {
+            const float *g = gib + (size_t)t * 2 * GRU_G;
+            gr = g[tid];
+            gz = g[GRU_H + tid];
+            gn = g[2 * GRU_H + tid];
+        }
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float4 hv = hq[i];
+            a0 = fmaf(w[4 * i + 0], hv.x, a0);
+            a1 = fmaf(w[4 * i + 1], hv.y, a1);
+            a2 = fmaf(w[4 * i + 2], hv.z, a2);
+            a3 = fmaf(w[4 * i + 3], hv.w, a3);
+        }
+        float acc = (a0 + a1) + (a2 + a3);
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if (q == 0) g_s[r] = acc;
+        __syncthreads();
+        const unsigned epoch = (unsigned)s + 1u;
+        u64 *xp = xb + (size_t)(s & 1) * GRU_H;
+        if (tid < GRU_UNITS) {
+            const int u = c * GRU_UNITS + tid;
+            const float hold = h_s[GRU_HS * (u >> 6) + (u & 63)];
+            const float rr = sigmoidf_(gr + (g_s[tid] + b_r));
+            const float zz = sigmoidf_(gz + (g_s[GRU_UNITS + tid] + b_z));
+            const float nn = tanhf(gn + rr * (g_s[2 * GRU_UNITS + tid] + b_n));
+            const float hnew = (1.f - zz) * nn + zz * hold;
+            __hip_atomic_store(xp + u, ((u64)epoch << 32) | (u64)__float_as_uint(hnew), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            h_s[GRU_HS * (u >> 6) + (u & 63)] = hnew;
+            outb[(size_t)t * 2 * GRU_H + tid] = hnew;
+        } else if (tid < 2 * GRU_UNITS) {
+            // wave 1: gather the other workgroups' 192 values of this step
+            const int lane = tid - GRU_UNITS;
+            unsigned spins = 0;
+            int idx[GRU_CUS - 1];
+#pragma unroll
+            for (int m = 0; m < GRU_CUS - 1; ++m) idx[m] = ((c + 1 + m) % GRU_CUS) * GRU_UNITS + lane;
+            if (!dead_s) {
+                for (;;) {
+                    bool ok = true;
+                    float v[GRU_CUS - 1];
+#pragma unroll
+                    for (int m = 0; m < GRU_CUS - 1; ++m) {
+                        const u64 x = __hip_atomic_load(xp + idx[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok &= (unsigned)(x >> 32) == epoch;
+                        v[m] = __uint_as_float((unsigned)x);
+                    }
+                    if (__all(ok)) {
+#pragma unroll
+                        for (int m = 0; m < GRU_CUS - 1; ++m) h_s[GRU_HS * (idx[m] >> 6) + (idx[m] & 63)] = v[m];
+                        break;
+                    }
+                    if (++spins > GRU_SPIN_LIMIT) { if (lane == 0) dead_s = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (dead_s && tid < GRU_UNITS) outb[(size_t)(dir == 0 ? T - 1 : 0) * 2 * GRU_H + tid] = __int_as_float(0x7fc00000);
+}
+
 }  // namespace rvc
 
 using namespace rvc;
 
+extern "C" int rvc_bigru_workspace_bytes(int batch, size_t *bytes) {
+    if (!bytes || batch <= 0) return fail("rvc_bigru_workspace_bytes: bad argument");
+    *bytes = (size_t)batch * 2 * 2 * GRU_H * sizeof(u64);
+    return 0;
+}
+
 extern "C" int rvc_bigru_forward(const float *gi_dev, const float *whhT_dev, const float *bhh_dev, float *out_dev,
-                                 int batch, int64_t n_steps, int hidden, void *stream) {
+                                 int batch, int64_t n_steps, int hidden, void *workspace_dev, size_t workspace_bytes,
+                                 void *stream) {
     if (!gi_dev || !whhT_dev || !bhh_dev || !out_dev) return fail("rvc_bigru_forward: null pointer");
     if (hidden != GRU_H) return fail("rvc_bigru_forward: hidden size must be %d (RMVPE.py:325), got %d", GRU_H, hidden);
     if (batch <= 0 || n_steps <= 0 || n_steps > (1 << 30)) return fail("rvc_bigru_forward: bad shape");
-    hipLaunchKernelGGL(bigru_kernel, dim3(2, batch), dim3(GRU_THREADS), 0, (hipStream_t)stream, gi_dev, whhT_dev, bhh_dev,
-                       out_dev, (int)n_steps);
+    if (!workspace_dev) {  // single-workgroup-per-direction variant (weights streamed from L2)
+        hipLaunchKernelGGL(bigru_kernel, dim3(2, batch), dim3(GRU_THREADS), 0, (hipStream_t)stream, gi_dev, whhT_dev,
+                           bhh_dev, out_dev, (int)n_steps);
+        RVC_LAUNCH_CHECK();
+        return 0;
+    }
+    size_t need = 0;
+    if (rvc_bigru_workspace_bytes(batch, &need)) return 1;
+    if (workspace_bytes < need) return fail("rvc_bigru_forward: workspace too small (%zu < %zu)", workspace_bytes, need);
+    if (batch * 2 * GRU_CUS > 128) return fail("rvc_bigru_forward: batch %d needs %d co-resident workgroups (max 128)", batch, batch * 2 * GRU_CUS);
+    RVC_HIP(hipMemsetAsync(workspace_dev, 0, need, (hipStream_t)stream));  // tags must start below epoch 1 on every call
+    hipLaunchKernelGGL(bigru_mc_kernel, dim3(2 * GRU_CUS, batch), dim3(GRU_THREADS), 0, (hipStream_t)stream, gi_dev, whhT_dev,
+                       bhh_dev, out_dev, (u64 *)workspace_dev, (int)n_steps);
     RVC_LAUNCH_CHECK();
     return 0;
 }

@@ -54,7 +54,9 @@ SYMBOLS = {
                               c_void_p]),
     "rvc_logmel_workspace_bytes": (c_int, [c_int, c_int64, POINTER(c_size_t)]),
     "rvc_logmel_rmvpe": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
-    "rvc_bigru_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    "rvc_bigru_workspace_bytes": (c_int, [c_int, POINTER(c_size_t)]),
+    "rvc_bigru_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_size_t,
+                                  c_void_p]),
     "rvc_decoder_create": (c_int, [POINTER(DecoderConfig), POINTER(c_void_p)]),
     "rvc_decoder_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]),
     "rvc_decoder_finalize": (c_int, [c_void_p]),
@@ -165,13 +167,19 @@ def logmel_rmvpe(audio: torch.Tensor, pad_to: int = 32) -> tuple[torch.Tensor, i
 
 
 # ---- K5 ------------------------------------------------------------------------------------------
-def bigru_forward(gi: torch.Tensor, whh_t: torch.Tensor, bhh: torch.Tensor) -> torch.Tensor:
+def bigru_forward(gi: torch.Tensor, whh_t: torch.Tensor, bhh: torch.Tensor, multi_cu: bool = True) -> torch.Tensor:
     """gi [B,T,2,768] (input projections) -> [B,T,512]; see include/rvc_amd.h."""
     gi, whh_t, bhh = _dev_f32(gi, "gi"), _dev_f32(whh_t, "whh_t"), _dev_f32(bhh, "bhh")
     b, t = gi.shape[0], gi.shape[1]
     out = torch.empty((b, t, 512), dtype=torch.float32, device=gi.device)
-    _check(_lib.rvc_bigru_forward(gi.data_ptr(), whh_t.data_ptr(), bhh.data_ptr(), out.data_ptr(), b, t, 256, _stream()),
-           "rvc_bigru_forward")
+    ws_ptr, ws_bytes = None, 0
+    if multi_cu:
+        need = c_size_t()
+        _check(_lib.rvc_bigru_workspace_bytes(b, ctypes.byref(need)), "rvc_bigru_workspace_bytes")
+        ws = _ws.get("bigru", need.value, gi.device)
+        ws_ptr, ws_bytes = ws.data_ptr(), ws.numel()
+    _check(_lib.rvc_bigru_forward(gi.data_ptr(), whh_t.data_ptr(), bhh.data_ptr(), out.data_ptr(), b, t, 256, ws_ptr,
+                                  ws_bytes, _stream()), "rvc_bigru_forward")
     return out
 
 

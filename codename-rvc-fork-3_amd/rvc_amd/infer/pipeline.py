@@ -85,6 +85,7 @@ class Pipeline:
         self.model_rmvpe = RMVPE0Predictor(rmvpe_path if os.path.isfile(rmvpe_path) else None, device=self.device)
         self._index_cache = {}
         self._preset_index = None
+        self._f0_stream = None
 
     # ---- additions -------------------------------------------------------------------------------------
     def load_rmvpe_state_dict(self, sd):
@@ -118,6 +119,10 @@ class Pipeline:
             f0 = self.model_rmvpe.infer_from_audio_device(x, thred=0.03).cpu().numpy()
         else:
             f0 = self.model_rmvpe.infer_from_audio(x, thred=0.03)
+        return self._postprocess_f0(f0, pitch, f0_autotune, inp_f0)
+
+    def _postprocess_f0(self, f0, pitch, f0_autotune=False, inp_f0=None):
+        """pipeline.py:385-410 on a float64 host contour: key shift, optional f0-file override, coarse bins 1..255."""
         if f0_autotune is True:
             raise NotImplementedError("f0_autotune is not implemented")
         f0 *= pow(2, pitch / 12)
@@ -135,38 +140,45 @@ class Pipeline:
         return np.rint(f0_mel).astype(int), f0bak
 
     # ---- per-segment conversion -------------------------------------------------------------------------
+    def _extract_features(self, model, audio0, index, big_npy, index_rate, version):
+        """pipeline.py:445-465: HuBERT features, retrieval blend, x2 nearest upsampling (pitch-independent half)."""
+        if torch.is_tensor(audio0):
+            feats = audio0.to(self.device).float()
+        else:
+            feats = torch.from_numpy(np.ascontiguousarray(audio0)).float().to(self.device)
+        feats = feats.mean(-1) if feats.dim() == 2 else feats
+        assert feats.dim() == 1, feats.dim()
+        n_audio = feats.shape[0]
+        feats = model(feats.view(1, -1))["last_hidden_state"]
+        feats = model.final_proj(feats[0]).unsqueeze(0) if version == "v1" else feats
+        feats0 = feats
+        if index:
+            feats = self._retrieve_speaker_embeddings(feats, index, big_npy, index_rate)
+        feats = F.interpolate(feats.permute(0, 2, 1), scale_factor=2).permute(0, 2, 1)
+        return feats, feats0, n_audio
+
+    def _synthesize(self, net_g, sid, feats, feats0, n_audio, pitch, pitchf, protect, noise):
+        """pipeline.py:466-490: length bookkeeping, protect blend, net_g.infer."""
+        p_len = min(n_audio // self.window, feats.shape[1])
+        pitch, pitchf = pitch[:, :p_len], pitchf[:, :p_len]
+        if protect < 0.5:  # pipeline.py:474-481
+            feats0 = F.interpolate(feats0.permute(0, 2, 1), scale_factor=2).permute(0, 2, 1)
+            pitchff = pitchf.clone()
+            pitchff[pitchf > 0] = 1
+            pitchff[pitchf < 1] = protect
+            feats = feats * pitchff.unsqueeze(-1) + feats0 * (1 - pitchff.unsqueeze(-1))
+            feats = feats.to(feats0.dtype)
+        p_len_t = torch.tensor([p_len], device=self.device).long()
+        return net_g.infer(feats.float(), p_len_t, pitch, pitchf.float(), sid, noise=noise)[0][0, 0]
+
     def voice_conversion(self, model, net_g, sid, audio0, pitch, pitchf, index, big_npy, index_rate, version, protect,
                          noise=None, as_tensor=False):
         """pipeline.py:412-495.  ``audio0``: NumPy or device tensor (1-D, 16 kHz)."""
         with torch.no_grad():
-            pitch_guidance = pitch is not None and pitchf is not None
-            if torch.is_tensor(audio0):
-                feats = audio0.to(self.device).float()
-            else:
-                feats = torch.from_numpy(np.ascontiguousarray(audio0)).float().to(self.device)
-            feats = feats.mean(-1) if feats.dim() == 2 else feats
-            assert feats.dim() == 1, feats.dim()
-            n_audio = feats.shape[0]
-            feats = model(feats.view(1, -1))["last_hidden_state"]
-            feats = model.final_proj(feats[0]).unsqueeze(0) if version == "v1" else feats
-            feats0 = feats.clone() if pitch_guidance else None
-            if index:
-                feats = self._retrieve_speaker_embeddings(feats, index, big_npy, index_rate)
-            feats = F.interpolate(feats.permute(0, 2, 1), scale_factor=2).permute(0, 2, 1)
-            p_len = min(n_audio // self.window, feats.shape[1])
-            if pitch_guidance:
-                feats0 = F.interpolate(feats0.permute(0, 2, 1), scale_factor=2).permute(0, 2, 1)
-                pitch, pitchf = pitch[:, :p_len], pitchf[:, :p_len]
-                if protect < 0.5:  # pipeline.py:474-481
-                    pitchff = pitchf.clone()
-                    pitchff[pitchf > 0] = 1
-                    pitchff[pitchf < 1] = protect
-                    feats = feats * pitchff.unsqueeze(-1) + feats0 * (1 - pitchff.unsqueeze(-1))
-                    feats = feats.to(feats0.dtype)
-            else:
+            if pitch is None or pitchf is None:
                 raise NotImplementedError("models without pitch guidance are not supported (SURVEY §2 item 3b)")
-            p_len_t = torch.tensor([p_len], device=self.device).long()
-            audio1 = net_g.infer(feats.float(), p_len_t, pitch, pitchf.float(), sid, noise=noise)[0][0, 0]
+            feats, feats0, n_audio = self._extract_features(model, audio0, index, big_npy, index_rate, version)
+            audio1 = self._synthesize(net_g, sid, feats, feats0, n_audio, pitch, pitchf, protect, noise)
             if as_tensor:
                 return audio1
             return audio1.data.cpu().float().numpy()
@@ -225,26 +237,41 @@ class Pipeline:
         if noise_seed is not None:
             torch.manual_seed(int(noise_seed))
             noise = "cpu"
-        model.consume_layerdrop_rng = noise_seed is not None
 
-        pitch, pitchf = self.get_f0("input_audio_path", audio_dev, p_len, pitch, f0_method, filter_radius, hop_length,
-                                    f0_autotune, f0_autotune_strength, inp_f0)
-        pitch, pitchf = pitch[:p_len], pitchf[:p_len]
-        pitch = torch.tensor(pitch, device=self.device).unsqueeze(0).long()
-        pitchf = torch.tensor(pitchf, device=self.device).unsqueeze(0).float()
+        # segment plan (pipeline.py:614-680): (audio slice, pitch slice) per segment
+        plan = []
         for t in opt_ts:
             t = t // self.window * self.window
-            seg = self.voice_conversion(model, net_g, sid, audio_dev[s: t + self.t_pad2 + self.window],
-                                        pitch[:, s // self.window: (t + self.t_pad2) // self.window],
-                                        pitchf[:, s // self.window: (t + self.t_pad2) // self.window],
-                                        index, big_npy, index_rate, version, protect, noise=noise, as_tensor=True)
-            audio_opt.append(seg[self.t_pad_tgt: -self.t_pad_tgt])
+            plan.append((slice(s, t + self.t_pad2 + self.window), slice(s // self.window, (t + self.t_pad2) // self.window)))
             s = t
-        seg = self.voice_conversion(model, net_g, sid, audio_dev[t:] if t is not None else audio_dev,
-                                    pitch[:, t // self.window:] if t is not None else pitch,
-                                    pitchf[:, t // self.window:] if t is not None else pitchf,
-                                    index, big_npy, index_rate, version, protect, noise=noise, as_tensor=True)
-        audio_opt.append(seg[self.t_pad_tgt: -self.t_pad_tgt])
+        plan.append((slice(t, None), slice(t // self.window if t is not None else None, None)))
+
+        with torch.no_grad():
+            # F0 (RMVPE) is independent of HuBERT + retrieval until the synthesizer: run it on a side stream.  Its
+            # BiGRU recurrence occupies two CUs for ~6 us x 3232 steps; the other 254 take the features meanwhile.
+            main = torch.cuda.current_stream()
+            if self._f0_stream is None:
+                self._f0_stream = torch.cuda.Stream(device=self.device)
+            side = self._f0_stream
+            side.wait_stream(main)
+            audio_dev.record_stream(side)
+            with torch.cuda.stream(side):
+                f0_dev = self.model_rmvpe.infer_from_audio_device(audio_dev, thred=0.03)
+            feats_list = [self._extract_features(model, audio_dev[a], index, big_npy, index_rate, version) for a, _ in plan]
+            with torch.cuda.stream(side):
+                f0_host = f0_dev.cpu().numpy()  # waits for the side stream only
+            if f0_method != "rmvpe":
+                raise NotImplementedError(f"f0_method={f0_method!r}: only 'rmvpe' is implemented")
+            pitch, pitchf = self._postprocess_f0(f0_host, pitch, f0_autotune, inp_f0)
+            pitch, pitchf = pitch[:p_len], pitchf[:p_len]
+            pitch = torch.tensor(pitch, device=self.device).unsqueeze(0).long()
+            pitchf = torch.tensor(pitchf, device=self.device).unsqueeze(0).float()
+            for (feats, feats0, n_audio), (_, ps) in zip(feats_list, plan):
+                if noise_seed is not None:
+                    for _ in range(12):  # transformers' HuBERT LayerDrop draws, made per segment before the synthesizer's
+                        torch.rand([])
+                seg = self._synthesize(net_g, sid, feats, feats0, n_audio, pitch[:, ps], pitchf[:, ps], protect, noise)
+                audio_opt.append(seg[self.t_pad_tgt: -self.t_pad_tgt])
         out = torch.cat(audio_opt) if len(audio_opt) > 1 else audio_opt[0]
         audio_max = out.abs().max() / 0.99  # pipeline.py:686-688
         out = torch.where(audio_max > 1, out / audio_max, out)

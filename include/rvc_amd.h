@@ -78,9 +78,12 @@ int rvc_logmel_rmvpe(const float *audio_dev, int batch, int64_t n_samples, float
  * num_layers=1, batch_first, bidirectional)).  The caller computes the input projections for all steps with one
  * GEMM: gi_dev [batch][n_steps][2][768] = W_ih x_t + b_ih (direction 0 = forward, 1 = reverse; gate order r,z,n).
  * whhT_dev [2][256][768] = W_hh transposed per direction, bhh_dev [2][768]; out_dev [batch][n_steps][512]
- * (forward hidden in [0,256), reverse in [256,512), as torch lays it out). */
+ * (forward hidden in [0,256), reverse in [256,512), as torch lays it out).
+ * workspace_dev: rvc_bigru_workspace_bytes() bytes of scratch for the multi-workgroup variant (4 workgroups per
+ * direction exchange h through it); NULL selects the single-workgroup-per-direction variant. */
+int rvc_bigru_workspace_bytes(int batch, size_t *bytes);
 int rvc_bigru_forward(const float *gi_dev, const float *whhT_dev, const float *bhh_dev, float *out_dev,
-                      int batch, int64_t n_steps, int hidden, void *stream);
+                      int batch, int64_t n_steps, int hidden, void *workspace_dev, size_t workspace_bytes, void *stream);
 
 /* ---- K2/K3: vocoder ("dec" of Synthesizer) ---------------------------------------------------- *
  * Replaces `self.dec(z * x_mask, nsff0, g=g)` at rvc/lib/algorithm/synthesizers.py:254-258, i.e.

@@ -192,8 +192,9 @@ def test_decoder_full_synth_golden(native, dev, ref_inputs):
 
 
 # ---- K5 BiGRU ----------------------------------------------------------------------------------------
-@pytest.mark.parametrize("batch,steps", [(1, 96), (2, 333)])
-def test_bigru_matches_torch_gru(native, dev, batch, steps):
+@pytest.mark.parametrize("multi_cu", [False, True])
+@pytest.mark.parametrize("batch,steps", [(1, 96), (2, 333), (1, 3232)])
+def test_bigru_matches_torch_gru(native, dev, batch, steps, multi_cu):
     torch.manual_seed(5)
     gru = torch.nn.GRU(384, 256, num_layers=1, batch_first=True, bidirectional=True).eval()
     x = torch.randn(batch, steps, 384)
@@ -205,6 +206,7 @@ def test_bigru_matches_torch_gru(native, dev, batch, steps):
     gi = F.linear(x, wih, bih).view(batch, steps, 2, 768)
     whh_t = torch.stack([sd["weight_hh_l0"].t(), sd["weight_hh_l0_reverse"].t()], 0).contiguous()
     bhh = torch.stack([sd["bias_hh_l0"], sd["bias_hh_l0_reverse"]], 0).contiguous()
-    out = native.bigru_forward(gi.to(dev), whh_t.to(dev), bhh.to(dev)).cpu()
+    out = native.bigru_forward(gi.to(dev), whh_t.to(dev), bhh.to(dev), multi_cu=multi_cu).cpu()
+    assert torch.isfinite(out).all()
     assert out.shape == ref.shape
     assert (out - ref).abs().max().item() <= 2e-5

@@ -40,7 +40,8 @@ for it in range(3):
         return pl.model_rmvpe.mel2hidden(mel, n)
     hidden = tm.run("rmvpe net (unet+gru)", unet)
     gi = torch.randn(1, 3232, 2, 768, device=dev)
-    tm.run("  of which bigru (HIP)", lambda: _native.bigru_forward(gi, w["gru.whhT"], w["gru.bhh"]))
+    tm.run("  of which bigru multi-CU", lambda: _native.bigru_forward(gi, w["gru.whhT"], w["gru.bhh"], True))
+    tm.run("  (bigru single-CU variant)", lambda: _native.bigru_forward(gi, w["gru.whhT"], w["gru.bhh"], False))
     f0 = tm.run("rmvpe decode + D2H", lambda: pl.model_rmvpe.decode(hidden[0]).cpu().numpy())
     def quant():
         f0_mel = 1127 * np.log(1 + f0 / 700)
@@ -68,5 +69,5 @@ print(f"{'stage':28s} {'ms (last run)':>12s}")
 tot = 0
 for k, v in tm.t.items():
     print(f"{k:28s} {v[-1]:12.2f}")
-    if k != "whole pipeline()": tot += v[-1]
+    if k != "whole pipeline()" and not k.startswith("  "): tot += v[-1]
 print(f"{'sum of stages':28s} {tot:12.2f}")
