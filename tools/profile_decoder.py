@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Decoder-only run for rocprofv3 (BASELINE cfg-2 shape: T = 3198 frames, NSF 48k)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "codename-rvc-fork-3_amd")]
+import torch
+from rvc_amd import _native
+from rvc_amd.lib import synthetic as S
+from rvc_amd.lib.algorithm.weights import fold_weight_norm
+voc = sys.argv[1] if len(sys.argv) > 1 else "HiFi-GAN"
+cpt = S.make_synth_checkpoint(48000, voc, seed=0)
+folded = {k[4:]: v for k, v in fold_weight_norm(cpt["weight"]).items() if k.startswith("dec.")}
+dec = _native.Decoder(voc, 48000, folded)
+dev = "cuda:0"
+T = 3198
+dim = 9 if voc.startswith("MRF") else 1
+z = torch.randn(1, 192, T, device=dev); f0 = torch.full((1, T), 220.0, device=dev); g = torch.randn(1, 256, device=dev)
+nz = torch.randn(1, T * 480, dim, device=dev); rnd = torch.rand(1, dim, device=dev)
+for _ in range(int(os.environ.get("REPS", "3"))):
+    dec.forward(z, f0, g, src_randn=nz, src_rand=rnd)
+torch.cuda.synchronize()

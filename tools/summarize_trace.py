@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Aggregate a rocprofv3 kernel-trace CSV by (kernel, grid) -> calls, avg us, total ms."""
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+skip = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+agg = collections.OrderedDict()
+for r in rows:
+    name = r["Kernel_Name"]
+    if "rvc::" not in name and len(sys.argv) <= 3: continue
+    key = (name.split("(")[0][-60:], r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Grid_Size_Y", ""))
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    agg.setdefault(key, []).append(d)
+tot = 0
+for k, v in agg.items():
+    v2 = v[len(v) // 3:] if len(v) >= 3 else v   # drop the first (warm-up) third
+    print(f"{k[0]:62s} grid {k[1]:>8s},{k[2]:>4s} calls {len(v):4d} avg {sum(v2)/len(v2):9.1f} us  total/run {sum(v2)/len(v2)*len(v)/3/1e3:8.2f} ms")
+    tot += sum(v2) / len(v2) * len(v) / 3 / 1e3
+print("total per run (ms):", round(tot, 2))
