@@ -54,6 +54,8 @@ SYMBOLS = {
                               c_void_p]),
     "rvc_logmel_workspace_bytes": (c_int, [c_int, c_int64, POINTER(c_size_t)]),
     "rvc_logmel_rmvpe": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+    "rvc_filtfilt_workspace_bytes": (c_int, [c_int64, POINTER(c_size_t)]),
+    "rvc_filtfilt_order5": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rvc_bigru_workspace_bytes": (c_int, [c_int, POINTER(c_size_t)]),
     "rvc_bigru_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_size_t,
                                   c_void_p]),
@@ -164,6 +166,37 @@ def logmel_rmvpe(audio: torch.Tensor, pad_to: int = 32) -> tuple[torch.Tensor, i
     _check(_lib.rvc_logmel_rmvpe(audio.data_ptr(), b, n, mel.data_ptr(), t_pad, ws.data_ptr(), ws.numel(), _stream()),
            "rvc_logmel_rmvpe")
     return mel, t
+
+
+# ---- K6 ------------------------------------------------------------------------------------------
+_ff_coef_cache = {}
+
+
+def _filtfilt_coef(b, a):
+    import numpy as np
+    from scipy import signal
+    key = (tuple(b), tuple(a))
+    if key not in _ff_coef_cache:
+        b = np.asarray(b, dtype=np.float64)
+        a = np.asarray(a, dtype=np.float64)
+        assert b.shape == (6,) and a.shape == (6,) and a[0] == 1.0
+        _ff_coef_cache[key] = np.ascontiguousarray(np.concatenate([b, a, signal.lfilter_zi(b, a)]))
+    return _ff_coef_cache[key]
+
+
+def filtfilt_order5(x: torch.Tensor, b, a) -> torch.Tensor:
+    """scipy.signal.filtfilt(b, a, x) for a 5th-order filter; x: 1-D float64 on the device."""
+    if not x.is_cuda or x.dtype != torch.float64 or x.dim() != 1:
+        raise NativeError("filtfilt_order5 wants a 1-D float64 HBM tensor")
+    x = x.contiguous()
+    coef = _filtfilt_coef(b, a)
+    y = torch.empty_like(x)
+    need = c_size_t()
+    _check(_lib.rvc_filtfilt_workspace_bytes(x.numel(), ctypes.byref(need)), "rvc_filtfilt_workspace_bytes")
+    ws = _ws.get("filtfilt", need.value, x.device)
+    _check(_lib.rvc_filtfilt_order5(x.data_ptr(), x.numel(), coef.ctypes.data, y.data_ptr(), ws.data_ptr(),
+                                    ws.numel(), _stream()), "rvc_filtfilt_order5")
+    return y
 
 
 # ---- K5 ------------------------------------------------------------------------------------------

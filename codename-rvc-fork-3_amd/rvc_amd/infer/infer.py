@@ -115,10 +115,15 @@ class VoiceConverter:
                       protect: float = 0.5, hop_length: int = 128, f0_autotune: bool = False,
                       f0_autotune_strength: float = 1, filter_radius: float = 3.0, sid: int = 0, noise_seed=None):
         """The array-level core of convert_audio (infer.py:262-311): 16 kHz float array in, float32 @tgt_sr out."""
-        audio = np.asarray(audio, dtype=np.float64).copy()
-        audio_max = np.abs(audio).max() / 0.95  # infer.py:262-265
-        if audio_max > 1:
-            audio /= audio_max
+        if torch.is_tensor(audio):  # HBM-resident entry: same peak limiting on the device
+            audio = audio.to(device=self.config.device, dtype=torch.float64)
+            audio_max = audio.abs().max() / 0.95
+            audio = torch.where(audio_max > 1, audio / audio_max, audio)
+        else:
+            audio = np.asarray(audio, dtype=np.float64).copy()
+            audio_max = np.abs(audio).max() / 0.95  # infer.py:262-265
+            if audio_max > 1:
+                audio /= audio_max
         file_index = index_path.strip().strip('"').strip("\n").strip('"').strip().replace("trained", "added")
         return self.vc.pipeline(model=self.hubert_model, net_g=self.net_g, sid=sid, audio=audio, pitch=pitch,
                                 f0_method=f0_method, file_index=file_index, index_rate=index_rate,

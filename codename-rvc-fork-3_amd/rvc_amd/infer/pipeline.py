@@ -196,7 +196,8 @@ class Pipeline:
     def pipeline(self, model, net_g, sid, audio, pitch, f0_method, file_index, index_rate, pitch_guidance,
                  filter_radius, volume_envelope, version, protect, hop_length, f0_autotune, f0_autotune_strength,
                  f0_file, *, noise_seed=None):
-        """pipeline.py:509-694.  ``audio``: 1-D float NumPy @16 kHz -> float32 NumPy @tgt_sr.
+        """pipeline.py:509-694.  ``audio``: 1-D float NumPy @16 kHz -> float32 NumPy @tgt_sr (a device tensor in
+        gives a device tensor out: the HBM-resident entry used by bench.py).
 
         noise_seed: None -> noise is drawn on the device; int -> parity mode: seed torch's CPU generator and
         draw every random tensor in the reference's order (including the 12 LayerDrop draws transformers'
@@ -207,20 +208,34 @@ class Pipeline:
             raise NotImplementedError("models without pitch guidance are not supported (SURVEY §2 item 3b)")
         index = self._get_index(file_index, index_rate)
         big_npy = index.vectors if index is not None else None
-        audio = signal.filtfilt(bh, ah, audio)
-        audio_pad = np.pad(audio, (self.window // 2, self.window // 2), mode="reflect")
+        # high-pass, split points and padding stay float64 but run in HBM (the reference does them in NumPy/SciPy)
+        as_tensor = torch.is_tensor(audio)
+        if as_tensor:
+            audio = audio.to(device=self.device, dtype=torch.float64)
+        else:
+            audio = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float64)).to(self.device)
+        if audio.shape[0] + self.window > self.t_max:
+            # long inputs are cut at arg-min positions of a 160-tap box sum of the filtered signal (below); this
+            # direct-form high-pass amplifies 1-ulp differences to ~2e-8, enough to move such an arg-min, so the split
+            # integers are only reproducible with SciPy's exact sequential recurrence: run that one on the host
+            audio = torch.from_numpy(np.ascontiguousarray(signal.filtfilt(bh, ah, audio.cpu().numpy()))).to(self.device)
+        else:
+            audio = _native.filtfilt_order5(audio, bh, ah)                  # pipeline.py:562, in HBM
+        n_audio = audio.shape[0]
         opt_ts = []
-        if audio_pad.shape[0] > self.t_max:  # pipeline.py:565-577
-            audio_sum = np.zeros_like(audio)
-            for i in range(self.window):
-                audio_sum += audio_pad[i: i - self.window]
-            for t in range(self.t_center, audio.shape[0], self.t_center):
-                seg = np.abs(audio_sum[t - self.t_query: t + self.t_query])
-                opt_ts.append(t - self.t_query + np.where(seg == seg.min())[0][0])
+        if n_audio + self.window > self.t_max:                               # pipeline.py:563-577
+            pad = F.pad(audio.view(1, 1, -1), (self.window // 2, self.window // 2), mode="reflect").view(-1)
+            audio_sum = torch.zeros_like(audio)
+            for i in range(self.window):                                     # same 160 sequential float64 adds
+                audio_sum += pad[i: i + n_audio]
+            for t in range(self.t_center, n_audio, self.t_center):
+                seg = audio_sum[t - self.t_query: t + self.t_query].abs()
+                first_min = int(torch.nonzero(seg == seg.min())[0, 0])
+                opt_ts.append(t - self.t_query + first_min)
         s = 0
         audio_opt = []
         t = None
-        audio_pad = np.pad(audio, (self.t_pad, self.t_pad), mode="reflect")
+        audio_pad = F.pad(audio.view(1, 1, -1), (self.t_pad, self.t_pad), mode="reflect").view(-1)  # pipeline.py:581
         p_len = audio_pad.shape[0] // self.window
         inp_f0 = None
         if hasattr(f0_file, "name"):  # pipeline.py:584-593
@@ -231,7 +246,7 @@ class Pipeline:
             except Exception as error:
                 print(f"An error occurred reading the F0 file: {error}")
         sid = torch.tensor(sid, device=self.device).unsqueeze(0).long()
-        audio_dev = torch.from_numpy(audio_pad).float().to(self.device)  # one upload; segments are views of it
+        audio_dev = audio_pad.float()  # segments are views of it
 
         noise = None
         if noise_seed is not None:
@@ -275,4 +290,4 @@ class Pipeline:
         out = torch.cat(audio_opt) if len(audio_opt) > 1 else audio_opt[0]
         audio_max = out.abs().max() / 0.99  # pipeline.py:686-688
         out = torch.where(audio_max > 1, out / audio_max, out)
-        return out.cpu().numpy()
+        return out if as_tensor else out.cpu().numpy()

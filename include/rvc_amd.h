@@ -73,6 +73,16 @@ int rvc_logmel_workspace_bytes(int batch, int64_t n_samples, size_t *bytes);
 int rvc_logmel_rmvpe(const float *audio_dev, int batch, int64_t n_samples, float *mel_dev,
                      int64_t n_frames_padded, void *workspace_dev, size_t workspace_bytes, void *stream);
 
+/* ---- K6: zero-phase high-pass ------------------------------------------------------------------ *
+ * Replaces `signal.filtfilt(bh, ah, audio)` (rvc/infer/pipeline.py:562; 5th-order Butterworth, pipeline.py:23-28)
+ * with SciPy's defaults (padtype "odd", padlen 18, lfilter_zi initial conditions), float64, on the device.
+ * coef_host (host memory, 17 doubles): b[6], a[6] (a[0] == 1), zi[5] = scipy.signal.lfilter_zi(b, a).
+ * x_dev, y_dev: [n] float64 (must not alias).  Agrees with SciPy to the conditioning of the recurrence (~5e-8,
+ * see csrc/filtfilt.hip). */
+int rvc_filtfilt_workspace_bytes(int64_t n, size_t *bytes);
+int rvc_filtfilt_order5(const double *x_dev, int64_t n, const double *coef_host, double *y_dev,
+                        void *workspace_dev, size_t workspace_bytes, void *stream);
+
 /* ---- K5: RMVPE BiGRU recurrence -------------------------------------------------------------- *
  * Replaces the sequential part of `self.gru(x)[0]` (rvc/lib/predictors/RMVPE.py:515-536, nn.GRU(384, 256,
  * num_layers=1, batch_first, bidirectional)).  The caller computes the input projections for all steps with one
