@@ -32,6 +32,7 @@ struct ConvParams {
     int up_stride = 0, up_pad = 0;
     float out_scale = 1.f;
     int batch = 1;
+    int debug = 0;   // experiments only (RVC_CONV_DEBUG): 1 = skip x loads, 2 = skip y stores, 4 = skip res loads
 };
 
 // picks the tile configuration from m_total; returns non-zero and sets the error on unsupported shapes

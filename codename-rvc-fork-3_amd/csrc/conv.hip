@@ -12,6 +12,8 @@
 // staging) and weight slab [KW][8][BM] go HBM/L2 -> registers -> LDS while the previous chunk is multiplied.
 // Fragment reads are ds_read_b32 with 32 consecutive lanes on consecutive addresses (conflict-free).
 // Epilogue fuses bias, the residual add, the running sum of the three parallel ResBlocks and its 1/3.
+#include <stdlib.h>
+
 #include "conv.h"
 
 namespace rvc {
@@ -19,13 +21,10 @@ namespace rvc {
 constexpr int CONV_CH_ALIGN = 8;  // input channel counts must be multiples of this
 constexpr int CONV_MAX_DIL = 5;
 
-// CIC = input channels per staged chunk (4 for the 11-tap kernels to bound the staging registers)
-template <int KW> struct ConvCic { static constexpr int v = (KW >= 11) ? 4 : 8; };
-
-template <int KW, int MT, int NT, int WM, int WN>
+// CONV_CIC = input channels per staged chunk
+template <int KW, int MT, int NT, int WM, int WN, int CONV_CIC>
 __global__ void __launch_bounds__(WM *WN * 64)
 conv_mfma_kernel(const ConvParams p) {
-    constexpr int CONV_CIC = ConvCic<KW>::v;
     constexpr int BM = 32 * MT * WM;
     constexpr int BN = 32 * NT * WN;
     constexpr int NTH = 64 * WM * WN;
@@ -35,8 +34,10 @@ conv_mfma_kernel(const ConvParams p) {
     constexpr int W4TOT = KW * CONV_CIC * BM / 4;
     constexpr int WN4 = (W4TOT + NTH - 1) / NTH;              // staged weight float4s per thread
 
-    __shared__ __attribute__((aligned(16))) float ws[KW * CONV_CIC * BM];
-    __shared__ float xs[XTOT];
+    // two LDS buffers: chunk c+1 is written while other waves still multiply chunk c -> one barrier per chunk
+    constexpr int WTOT = KW * CONV_CIC * BM;
+    __shared__ __attribute__((aligned(16))) float ws[2 * WTOT];
+    __shared__ float xs[2 * XTOT];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -88,7 +89,7 @@ conv_mfma_kernel(const ConvParams p) {
                 const int ci = idx / XW;
                 const int cc = idx - ci * XW;
                 const int64_t t = col0 + cc - padl;
-                if (t >= 0 && t < l_in) v = lrelu(src[(int64_t)ci * l_in + t], slope);
+                if (t >= 0 && t < l_in && !(p.debug & 1)) v = lrelu(src[(int64_t)ci * l_in + t], slope);
             }
             xr[i] = v;
         }
@@ -106,16 +107,16 @@ conv_mfma_kernel(const ConvParams p) {
             wr[i] = v;  // unconditional: a partially-defined register array is demoted to scratch
         }
     };
-    auto store_chunk = [&]() {
+    auto store_chunk = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < XN; ++i) {
             const int idx = tid + i * NTH;
-            if (idx < XTOT) xs[idx] = xr[i];
+            if (idx < XTOT) xs[buf * XTOT + idx] = xr[i];
         }
 #pragma unroll
         for (int i = 0; i < WN4; ++i) {
             const int idx4 = tid + i * NTH;
-            if (idx4 < W4TOT) *reinterpret_cast<float4 *>(&ws[idx4 * 4]) = wr[i];
+            if (idx4 < W4TOT) *reinterpret_cast<float4 *>(&ws[buf * WTOT + idx4 * 4]) = wr[i];
         }
     };
 
@@ -128,14 +129,13 @@ conv_mfma_kernel(const ConvParams p) {
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
     load_chunk(0);
+    store_chunk(0);
+    if (n_chunks > 1) load_chunk(1);
+    __syncthreads();
     for (int c = 0; c < n_chunks; ++c) {
-        __syncthreads();
-        store_chunk();
-        __syncthreads();
-        if (c + 1 < n_chunks) load_chunk(c + 1);
-
-        const float *wa = &ws[half * BM + wm * MT * 32 + l31];
-        const float *xb = &xs[half * XW + wn * NT * 32 + l31];
+        const int buf = c & 1;
+        const float *wa = &ws[buf * WTOT + half * BM + wm * MT * 32 + l31];
+        const float *xb = &xs[buf * XTOT + half * XW + wn * NT * 32 + l31];
 #pragma unroll
         for (int tap = 0; tap < KW; ++tap) {
 #pragma unroll
@@ -151,6 +151,12 @@ conv_mfma_kernel(const ConvParams p) {
                     for (int n = 0; n < NT; ++n) acc[m][n] = mfma32(a[m], bb[n], acc[m][n]);
             }
         }
+        if (c + 1 < n_chunks) {
+            // buffer buf^1 was last read during chunk c-1; every wave passed the barrier that ended it
+            store_chunk(buf ^ 1);
+            if (c + 2 < n_chunks) load_chunk(c + 2);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue --------------------------------------------------------------------------------------
@@ -159,6 +165,28 @@ conv_mfma_kernel(const ConvParams p) {
     if (p.up_stride == 0) {
         const float *res = p.res ? p.res + (int64_t)b * p.y_bstride : nullptr;
         const float *accin = p.accin ? p.accin + (int64_t)b * p.y_bstride : nullptr;
+        // Two passes.  res/accin may alias y (the ResBlock updates its state in place), so a fused
+        // load-add-store loop would have to wait for every load before the next store (measured: ~110 us per block,
+        // 380 us per launch); gathering all addends into the accumulators first keeps 64 loads per lane in flight.
+        if ((res || accin) && !(p.debug & 4)) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * MT * 32 + m * 32 + mfma32_row(r, lane);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int64_t col = col0 + wn * NT * 32 + n * 32 + l31;
+                        if (col < p.n_cols) {
+                            const int64_t o = (int64_t)row * p.l_out + col;
+                            float add = 0.f;
+                            if (res) add = res[o];
+                            if (accin) add += accin[o];
+                            acc[m][n][r] += add;
+                        }
+                    }
+                }
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -168,13 +196,7 @@ conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     const int64_t col = col0 + wn * NT * 32 + n * 32 + l31;
-                    if (col < p.n_cols) {
-                        const int64_t o = (int64_t)row * p.l_out + col;
-                        float v = acc[m][n][r] + bv;
-                        if (res) v += res[o];
-                        if (accin) v += accin[o];
-                        y[o] = v * p.out_scale;
-                    }
+                    if (col < p.n_cols && (!(p.debug & 2) || acc[m][n][r] == 12345.678f)) y[(int64_t)row * p.l_out + col] = (acc[m][n][r] + bv) * p.out_scale;
                 }
             }
         }
@@ -199,25 +221,51 @@ conv_mfma_kernel(const ConvParams p) {
     }
 }
 
-template <int KW, int MT, int NT, int WM, int WN>
+template <int KW, int MT, int NT, int WM, int WN, int CIC>
 static int launch_cfg(const ConvParams &p, hipStream_t stream) {
     constexpr int BM = 32 * MT * WM;
     constexpr int BN = 32 * NT * WN;
     dim3 grid((unsigned)ceil_div(p.n_cols, BN), (unsigned)(p.m_total / BM), (unsigned)p.batch);
-    hipLaunchKernelGGL((conv_mfma_kernel<KW, MT, NT, WM, WN>), grid, dim3(64 * WM * WN), 0, stream, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<KW, MT, NT, WM, WN, CIC>), grid, dim3(64 * WM * WN), 0, stream, p);
     RVC_LAUNCH_CHECK();
     return 0;
 }
 
+// tuning knobs for experiments (tools/bench_conv.py): RVC_CONV_CIC=4|8 overrides the chunk depth,
+// RVC_CONV_TILE=1 selects the 128x256 block tile where it applies
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+template <int KW, int MT, int NT, int WM, int WN>
+static int launch_cic(const ConvParams &p, hipStream_t stream, int cic) {
+    switch (cic) {
+        case 4: return launch_cfg<KW, MT, NT, WM, WN, 4>(p, stream);
+        case 16:
+            if constexpr (KW <= 3) return launch_cfg<KW, MT, NT, WM, WN, 16>(p, stream);
+        default: return launch_cfg<KW, MT, NT, WM, WN, 8>(p, stream);
+    }
+}
+
 template <int KW>
 static int launch_kw(const ConvParams &p, hipStream_t stream) {
-    if (p.m_total % 128 == 0) return launch_cfg<KW, 2, 2, 2, 2>(p, stream);   // 128 x 128
-    if (p.m_total % 64 == 0) return launch_cfg<KW, 2, 2, 1, 4>(p, stream);    //  64 x 256
-    if (p.m_total % 32 == 0) return launch_cfg<KW, 1, 4, 1, 4>(p, stream);    //  32 x 512
+    static const int cic_env = env_int("RVC_CONV_CIC", 0);
+    // chunk depth: deep kernels (7, 11 taps) stage 4 channels per chunk (staging registers, 3 blocks/CU);
+    // shallow ones amortise the barrier over more channels
+    int cic = KW >= 7 ? 4 : 8;
+    if (cic_env) cic = cic_env;
+    if ((p.c1 % cic) || (p.c2 % cic)) cic = 8;
+    if (p.m_total % 128 == 0) return launch_cic<KW, 2, 2, 2, 2>(p, stream, cic);   // 128 x 128
+    if (p.m_total % 64 == 0) return launch_cic<KW, 2, 2, 1, 4>(p, stream, cic);    //  64 x 256
+    if (p.m_total % 32 == 0) return launch_cic<KW, 1, 4, 1, 4>(p, stream, cic);    //  32 x 512
     return fail("conv: GEMM rows (%d) must be a multiple of 32", p.m_total);
 }
 
-int launch_conv(const ConvParams &p, hipStream_t stream) {
+int launch_conv(const ConvParams &p_in, hipStream_t stream) {
+    static const int dbg = env_int("RVC_CONV_DEBUG", 0);
+    ConvParams p = p_in;
+    p.debug = dbg;
     if ((p.c1 % CONV_CH_ALIGN) || (p.c2 % CONV_CH_ALIGN) || p.c1 + p.c2 <= 0)
         return fail("conv: input channels (%d + %d) must be multiples of %d", p.c1, p.c2, CONV_CH_ALIGN);
     if (p.dil < 1 || p.dil > CONV_MAX_DIL) return fail("conv: dilation %d out of range 1..%d", p.dil, CONV_MAX_DIL);
