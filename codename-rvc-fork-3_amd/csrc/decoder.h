@@ -1,0 +1,99 @@
+// Shared host-side structures of the vocoder handle (decoder.hip: NSF / MRF schedule; refine.hip: RefineGAN).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "conv.h"
+
+namespace rvc {
+
+constexpr int MRF_MAX_DIM = 9;
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+    int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+struct DevBuf {
+    float *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int upload(const std::vector<float> &h) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        hipError_t e = hipMalloc((void **)&p, h.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+        return e == hipSuccess ? 0 : fail("device upload of %zu floats failed: %s", h.size(), hipGetErrorString(e));
+    }
+};
+
+struct ConvW {
+    DevBuf w, b;
+    int c_in = 0, c_out = 0, k = 0;
+};
+
+struct Stage {
+    int c_in = 0, c_out = 0, rate = 0, ksize = 0, pad = 0, opad = 0;
+    int taps = 0;                 // polyphase taps J = ceil(k / rate)
+    int nc_stride = 0, nc_k = 0, nc_pad = 0;
+    int vk = 0, vk_rows = 0;      // folded noise-conv rows: valid, padded to a multiple of 8
+    int64_t S = 0, P = 0;         // V[k][q] = har[q*S + k - P]
+    DevBuf w, b;                  // [taps][c_in + vk_rows][rate * c_out], [c_out]
+    std::vector<ConvW> c1, c2;    // [n_res_kernels * n_res_dilations]
+};
+
+// RefineGAN-only state (refine.hip)
+struct RefineStage {
+    int ch_in = 0, ch_out = 0, rate = 0, down_c = 0, down_k = 0, down_stride = 0, down_pad = 0;
+    DevBuf down_w, down_b;             // [down_c][down_k], [down_c]
+    ConvW input_conv;                  // k7, (ch_in + down_c) -> ch_out
+    DevBuf adain1[4], adain2[4];       // per branch [ch_out]
+    std::vector<ConvW> c1, c2;         // [n_res_kernels * n_res_dilations]
+};
+
+}  // namespace rvc
+
+struct rvc_decoder {
+    rvc_decoder_config cfg;
+    std::map<std::string, rvc::HostTensor> host;
+    bool finalized = false;
+    int upp = 1;
+    int dim = 1;              // sine components (NSF 1, MRF 9)
+    float lin_w[rvc::MRF_MAX_DIM] = {0};
+    float lin_b = 0.f;
+    rvc::ConvW pre;                // conv_pre packed
+    rvc::DevBuf cond_w, cond_b;
+    std::vector<rvc::Stage> stages;
+    rvc::DevBuf post_w;
+    float post_b = 0.f;
+    int post_cin = 0;
+    // RefineGAN (kind == RVC_DEC_REFINE)
+    float merge_w = 1.f;
+    rvc::DevBuf pre_w, pre_b;      // pre_conv [256][7], [256]
+    rvc::ConvW mel;                // mel_conv k7 192 -> 256
+    std::vector<rvc::RefineStage> rstages;
+    // debug tap
+    int tap_stage = -2;
+    float *tap_dev = nullptr;
+};
+
+
+namespace rvc {
+const HostTensor *find(const rvc_decoder *d, const std::string &name);
+int need(const rvc_decoder *d, const std::string &name, const HostTensor **out, std::vector<int64_t> shape);
+int build_conv(const rvc_decoder *d, const std::string &prefix, int c_out, int c_in, int k, bool bias, ConvW *out);
+
+// small kernels shared by both schedules (launch wrappers defined in decoder.hip)
+int launch_unfold_src(const float *har, int batch, int64_t L, int64_t S, int64_t P, int k_valid, int k_rows, int64_t nq, float *V,
+                      hipStream_t stream);
+int launch_cond_bias(const float *pre_b, const float *cond_w, const float *cond_b, const float *g, int batch, int gin, int c0,
+                     float *out, hipStream_t stream);
+int launch_conv_post(const float *x, const float *w, float bias, int batch, int c_in, int64_t L, float slope, float *out,
+                     hipStream_t stream);
+
+// refine.hip
+int refine_finalize(rvc_decoder *d);
+size_t refine_workspace_bytes(const rvc_decoder *d, int batch, int64_t T);
+int refine_forward(rvc_decoder *d, const float *z_dev, const float *f0_dev, const float *g_dev, const rvc_decoder_noise *noise,
+                   int batch, int64_t T, float *out_dev, void *workspace_dev, size_t workspace_bytes, hipStream_t stream);
+}  // namespace rvc

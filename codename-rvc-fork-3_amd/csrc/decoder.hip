@@ -7,10 +7,7 @@
 // NSF: hifigan_nsf.py:173-207 + hifigan.py:156-228;  MRF: hifigan_mrf.py:339-366, 129-175.
 // All dense contractions go through conv.hip (fp32 MFMA implicit GEMM); this file holds the small
 // element-wise kernels, the weight repacks and the schedule.
-#include <map>
-#include <vector>
-
-#include "conv.h"
+#include "decoder.h"
 
 namespace rvc {
 
@@ -59,7 +56,6 @@ nsf_source_kernel(const float *__restrict__ f0, const float *__restrict__ carry,
 // rad = (f0*h/sr) % 1 is constant inside a frame (f0 is nearest-upsampled), so both sample-rate cumsums
 // reduce to per-frame prefixes (sequential, double, T elements) plus closed forms inside the frame.
 // Only implemented for piecewise-constant f0 (MRF); RefineGAN interpolates f0 linearly (TODO there).
-constexpr int MRF_MAX_DIM = 9;
 
 struct MrfSrcParams {
     const float *f0; const float *rand_ini; const float *randn; float *har;
@@ -261,71 +257,44 @@ conv_post_kernel(const float *__restrict__ x, const float *__restrict__ w, float
     out[b * L + t] = tanhf(acc);
 }
 
+int launch_unfold_src(const float *har, int batch, int64_t L, int64_t S, int64_t P, int k_valid, int k_rows, int64_t nq, float *V,
+                      hipStream_t stream) {
+    hipLaunchKernelGGL(unfold_src_kernel, dim3((unsigned)ceil_div(nq, 256), k_rows, batch), dim3(256), 0, stream, har, L, S, P,
+                       k_valid, k_rows, nq, V);
+    RVC_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_cond_bias(const float *pre_b, const float *cond_w, const float *cond_b, const float *g, int batch, int gin, int c0,
+                     float *out, hipStream_t stream) {
+    hipLaunchKernelGGL(cond_bias_kernel, dim3(c0, batch), dim3(64), 0, stream, pre_b, cond_w, cond_b, g, gin, c0, out);
+    RVC_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_conv_post(const float *x, const float *w, float bias, int batch, int c_in, int64_t L, float slope, float *out,
+                     hipStream_t stream) {
+    hipLaunchKernelGGL(conv_post_kernel, dim3((unsigned)ceil_div(L, 256), batch), dim3(256), 0, stream, x, w, bias, c_in, L, slope,
+                       out);
+    RVC_LAUNCH_CHECK();
+    return 0;
+}
+
 // ----------------------------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------------------------
-
-struct HostTensor {
-    std::vector<float> data;
-    std::vector<int64_t> shape;
-    int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
-};
-
-struct DevBuf {
-    float *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int upload(const std::vector<float> &h) {
-        if (p) { (void)hipFree(p); p = nullptr; }
-        hipError_t e = hipMalloc((void **)&p, h.size() * sizeof(float));
-        if (e == hipSuccess) e = hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
-        return e == hipSuccess ? 0 : fail("device upload of %zu floats failed: %s", h.size(), hipGetErrorString(e));
-    }
-};
-
-struct ConvW {
-    DevBuf w, b;
-    int c_in = 0, c_out = 0, k = 0;
-};
-
-struct Stage {
-    int c_in = 0, c_out = 0, rate = 0, ksize = 0, pad = 0, opad = 0;
-    int taps = 0;                 // polyphase taps J = ceil(k / rate)
-    int nc_stride = 0, nc_k = 0, nc_pad = 0;
-    int vk = 0, vk_rows = 0;      // folded noise-conv rows: valid, padded to a multiple of 8
-    int64_t S = 0, P = 0;         // V[k][q] = har[q*S + k - P]
-    DevBuf w, b;                  // [taps][c_in + vk_rows][rate * c_out], [c_out]
-    std::vector<ConvW> c1, c2;    // [n_res_kernels * n_res_dilations]
-};
 
 }  // namespace rvc
 
 using namespace rvc;
 
-struct rvc_decoder {
-    rvc_decoder_config cfg;
-    std::map<std::string, HostTensor> host;
-    bool finalized = false;
-    int upp = 1;
-    int dim = 1;              // sine components (NSF 1, MRF 9)
-    float lin_w[MRF_MAX_DIM] = {0};
-    float lin_b = 0.f;
-    ConvW pre;                // conv_pre packed
-    DevBuf cond_w, cond_b;
-    std::vector<Stage> stages;
-    DevBuf post_w;
-    float post_b = 0.f;
-    int post_cin = 0;
-    // debug tap
-    int tap_stage = -2;
-    float *tap_dev = nullptr;
-};
-
-static const HostTensor *find(const rvc_decoder *d, const std::string &name) {
+namespace rvc {
+const HostTensor *find(const rvc_decoder *d, const std::string &name) {
     auto it = d->host.find(name);
     return it == d->host.end() ? nullptr : &it->second;
 }
 
-static int need(const rvc_decoder *d, const std::string &name, const HostTensor **out, std::vector<int64_t> shape) {
+int need(const rvc_decoder *d, const std::string &name, const HostTensor **out, std::vector<int64_t> shape) {
     const HostTensor *t = find(d, name);
     if (!t) return fail("decoder: tensor '%s' was never set", name.c_str());
     if (t->shape != shape) {
@@ -338,7 +307,7 @@ static int need(const rvc_decoder *d, const std::string &name, const HostTensor 
     return 0;
 }
 
-static int build_conv(const rvc_decoder *d, const std::string &prefix, int c_out, int c_in, int k, bool bias, ConvW *out) {
+int build_conv(const rvc_decoder *d, const std::string &prefix, int c_out, int c_in, int k, bool bias, ConvW *out) {
     const HostTensor *w, *b;
     if (need(d, prefix + ".weight", &w, {c_out, c_in, k})) return 1;
     std::vector<float> packed((size_t)c_out * c_in * k);
@@ -354,12 +323,12 @@ static int build_conv(const rvc_decoder *d, const std::string &prefix, int c_out
     out->c_in = c_in; out->c_out = c_out; out->k = k;
     return 0;
 }
+}  // namespace rvc
 
 extern "C" int rvc_decoder_create(const rvc_decoder_config *cfg, rvc_decoder **out) {
     if (!cfg || !out) return fail("rvc_decoder_create: null pointer");
     if (cfg->kind != RVC_DEC_NSF && cfg->kind != RVC_DEC_MRF && cfg->kind != RVC_DEC_REFINE)
         return fail("rvc_decoder_create: unknown decoder kind %d", cfg->kind);
-    if (cfg->kind == RVC_DEC_REFINE) return fail("rvc_decoder_create: RefineGAN decoder is not implemented yet");
     if (cfg->n_ups < 1 || cfg->n_ups > 8) return fail("rvc_decoder_create: n_ups out of range");
     if (cfg->n_res_kernels < 1 || cfg->n_res_kernels > 4 || cfg->n_res_dilations < 1 || cfg->n_res_dilations > 4)
         return fail("rvc_decoder_create: resblock configuration out of range");
@@ -391,6 +360,12 @@ extern "C" int rvc_decoder_set_tensor(rvc_decoder *dec, const char *name, const 
 extern "C" int rvc_decoder_finalize(rvc_decoder *d) {
     if (!d) return fail("rvc_decoder_finalize: null decoder");
     if (d->finalized) return 0;
+    if (d->cfg.kind == RVC_DEC_REFINE) {
+        if (refine_finalize(d)) return 1;
+        d->host.clear();
+        d->finalized = true;
+        return 0;
+    }
     const rvc_decoder_config &c = d->cfg;
     const bool mrf = c.kind == RVC_DEC_MRF;
     const HostTensor *t;
@@ -547,7 +522,7 @@ Layout make_layout(const rvc_decoder *d, int batch, int64_t T) {
 extern "C" int rvc_decoder_workspace_bytes(const rvc_decoder *dec, int batch, int64_t n_frames, size_t *bytes) {
     if (!dec || !bytes || batch <= 0 || n_frames <= 0) return fail("rvc_decoder_workspace_bytes: bad argument");
     if (!dec->finalized) return fail("rvc_decoder_workspace_bytes: decoder not finalized");
-    *bytes = make_layout(dec, batch, n_frames).total;
+    *bytes = dec->cfg.kind == RVC_DEC_REFINE ? refine_workspace_bytes(dec, batch, n_frames) : make_layout(dec, batch, n_frames).total;
     return 0;
 }
 
@@ -565,6 +540,8 @@ extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const flo
     if (!d->finalized) return fail("rvc_decoder_forward: decoder not finalized");
     if (batch <= 0 || T <= 0) return fail("rvc_decoder_forward: empty batch");
     if (!noise->src_randn_dev) return fail("rvc_decoder_forward: src_randn_dev is required");
+    if (d->cfg.kind == RVC_DEC_REFINE)
+        return refine_forward(d, z_dev, f0_dev, g_dev, noise, batch, T, out_dev, workspace_dev, workspace_bytes, (hipStream_t)stream_);
     const rvc_decoder_config &c = d->cfg;
     const bool mrf = c.kind == RVC_DEC_MRF;
     if (mrf && !noise->src_rand_dev) return fail("rvc_decoder_forward: src_rand_dev is required for the MRF decoder");

@@ -93,9 +93,19 @@ class Synthesizer:
         return self
 
     # ---- noise ----
+    def _adain_shapes(self, b, t):
+        """RefineGAN's 24 AdaIN draws, in call order (refinegan.py:111 via :155-162, :168-170)."""
+        shapes, length, ch = [], t, self.upsample_initial_channel
+        for r in self.upsample_rates:
+            length *= r
+            ch //= 2
+            shapes += [(b, ch, length)] * (2 * len(self.resblock_kernel_sizes))
+        return shapes
+
     def _draw(self, noise, b, t):
         L = t * self.upp
         dim = 9 if self.vocoder == "MRF HiFi-GAN" else 1
+        refine = self.vocoder == "RefineGAN"
         dev = self.device
         if isinstance(noise, dict):
             return {k: (v.to(dev) if v is not None else None) for k, v in noise.items()}
@@ -105,12 +115,18 @@ class Synthesizer:
                 src_rand = torch.rand(1, 1, 1)                                # hifigan.py:189 (zeroed, consumes state)
                 src_randn = torch.randn(b, L, 1)                              # hifigan.py:223
             else:
-                src_rand = torch.rand(b, dim)                                 # hifigan_mrf.py:143
-                src_randn = torch.randn(b, L, dim)                            # hifigan_mrf.py:172
-            return {"z": z.to(dev), "src_rand": src_rand.to(dev), "src_randn": src_randn.to(dev)}
-        return {"z": torch.randn(b, self.inter_channels, t, device=dev),
-                "src_rand": torch.rand(b, dim, device=dev),
-                "src_randn": torch.randn(b, L, dim, device=dev)}
+                src_rand = torch.rand(b, dim)                                 # hifigan_mrf.py:143 / refinegan.py:229
+                src_randn = torch.randn(b, L, dim)                            # hifigan_mrf.py:172 / refinegan.py:258
+            out = {"z": z.to(dev), "src_rand": src_rand.to(dev), "src_randn": src_randn.to(dev)}
+            if refine:
+                out["adain_randn"] = torch.cat([torch.randn(*sh).reshape(-1) for sh in self._adain_shapes(b, t)]).to(dev)
+            return out
+        out = {"z": torch.randn(b, self.inter_channels, t, device=dev),
+               "src_rand": torch.rand(b, dim, device=dev),
+               "src_randn": torch.randn(b, L, dim, device=dev)}
+        if refine:
+            out["adain_randn"] = torch.randn(sum(int(np.prod(sh)) for sh in self._adain_shapes(b, t)), device=dev)
+        return out
 
     @torch.no_grad()
     def infer(self, phone, phone_lengths, pitch=None, nsff0=None, sid=None, rate=None, noise=None):
@@ -131,5 +147,6 @@ class Synthesizer:
             nz["src_randn"] = nz["src_randn"][:, head * self.upp:]
         z = flow_reverse(w, z_p, x_mask, g, half=self.inter_channels // 2, hidden=self.hidden_channels)
         o = self.dec.forward((z * x_mask).contiguous(), nsff0.float().contiguous(), g[:, :, 0].contiguous(),
-                             src_randn=nz["src_randn"].contiguous(), src_rand=nz.get("src_rand"))
+                             src_randn=nz["src_randn"].contiguous(), src_rand=nz.get("src_rand"),
+                             adain_randn=nz.get("adain_randn"))
         return o, x_mask, (z, z_p, m_p, logs_p)

@@ -128,7 +128,8 @@ def _decoder_inputs(ref_inputs, T, batch=1):
 
 
 @pytest.mark.parametrize("tag,sr,voc", [("nsf48", 48000, "HiFi-GAN"), ("nsf40", 40000, "HiFi-GAN"),
-                                        ("nsf32", 32000, "HiFi-GAN"), ("mrf48", 48000, "MRF HiFi-GAN")])
+                                        ("nsf32", 32000, "HiFi-GAN"), ("mrf48", 48000, "MRF HiFi-GAN"),
+                                        ("refine48", 48000, "RefineGAN"), ("refine40", 40000, "RefineGAN")])
 def test_decoder_matches_oracle(native, dev, ref_inputs, tag, sr, voc):
     from oracle import rvc_oracle as O
     from rvc_amd.lib import synthetic as S
@@ -145,9 +146,19 @@ def test_decoder_matches_oracle(native, dev, ref_inputs, tag, sr, voc):
     dim = 9 if voc.startswith("MRF") else 1
     src_rand = torch.rand(batch, dim, generator=gen)
     src_randn = torch.randn(batch, T * upp, dim, generator=gen)
+    refine = voc == "RefineGAN"
+    adain = []
+    if refine:
+        length, ch = T, 512
+        for r in rates:
+            length, ch = length * r, ch // 2
+            adain += [torch.randn(batch, ch, length, generator=gen) for _ in range(6)]
     outs = []
     for b in range(batch):
-        if dim == 1:
+        if refine:
+            noise = O.ListNoise([src_rand[b:b + 1].clone(), src_randn[b:b + 1]] + [a[b:b + 1] for a in adain])
+            o = O.decoder_refine(w, z[b:b + 1], f0[b:b + 1], g[b:b + 1], rates, sr, noise)
+        elif dim == 1:
             noise = O.ListNoise([torch.zeros(1, 1, 1), src_randn[b:b + 1]])
             o = O.decoder_nsf(w, z[b:b + 1], f0[b:b + 1], g[b:b + 1], rates, ksizes, sr, noise)
         else:
@@ -159,8 +170,9 @@ def test_decoder_matches_oracle(native, dev, ref_inputs, tag, sr, voc):
     folded = {k[4:]: v for k, v in fold_weight_norm(cpt["weight"]).items() if k.startswith("dec.")}
     dec = native.Decoder(voc, sr, folded, upsample_rates=rates, upsample_kernel_sizes=ksizes)
     assert dec.upp == upp
+    adain_flat = torch.cat([a.reshape(-1) for a in adain]).to(dev) if refine else None
     out = dec.forward(z.to(dev), f0.to(dev), g[:, :, 0].to(dev), src_randn=src_randn.to(dev),
-                      src_rand=src_rand.to(dev)).cpu().numpy()
+                      src_rand=src_rand.to(dev), adain_randn=adain_flat).cpu().numpy()
     assert out.shape == ref.shape
     err = rms(out - ref)
     assert rms(ref) > 0.02
