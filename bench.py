@@ -34,6 +34,42 @@ import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = FP32 vector peak
 PEAK_HBM_GBS = 8000.0           # HBM3E spec
+# average HBM bytes per launch of the roofline kernel symbol at the cfg-2 shape, from the PMC passes committed under
+# profiles/ (cannot be collected inside bench.py: it needs rocprofv3)
+PMC_TRAFFIC_BYTES = 422.7e6
+PMC_TRAFFIC_SOURCE = ("profiles/r01_pmc_conv.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
+                      "tools/pmc_conv.py (this same launch mix); FETCH_SIZE calibrated on the same kernel at K=1 with known bytes")
+
+
+def roofline_mix(native, dev, T, rates, k=11):
+    """The launches of conv_mfma_kernel<11,2,2,2,2,4> in one utterance's vocoder forward: stages 0 and 1, for each
+    dilation d: conv1 (dilation d) then conv2 (dilation 1, + residual; the last one also + running sum, x 1/3).
+    Returns (callable, flops per call, launches per call, algorithmic HBM bytes per call)."""
+    shapes = [(256, T * rates[0]), (128, T * rates[0] * rates[1])]
+    state, flops, alg_bytes = [], 0.0, 0.0
+    gen = torch.Generator().manual_seed(1)
+    for C, L in shapes:
+        x = torch.randn(1, C, L, device=dev)
+        t1 = torch.empty_like(x)
+        y = torch.randn(1, C, L, device=dev)
+        acc = torch.randn(1, C, L, device=dev)
+        w1 = native.conv1d_pack_weight(torch.randn(C, C, k, generator=gen) * 0.02, dev)
+        w2 = native.conv1d_pack_weight(torch.randn(C, C, k, generator=gen) * 0.02, dev)
+        bias = torch.zeros(C, device=dev)
+        state.append((C, x, t1, y, acc, w1, w2, bias))
+        flops += 6 * 2.0 * C * C * k * L
+        tensor = C * L * 4.0
+        alg_bytes += 3 * (2 * tensor) + 2 * (3 * tensor) + 1 * (4 * tensor)   # conv1: r+w; conv2: r+res+w (+acc)
+
+    def run():
+        for C, x, t1, y, acc, w1, w2, bias in state:
+            for j, d in enumerate((1, 3, 5)):
+                native.conv1d_forward_into(x, w1, bias, C, k, d, 0.1, out=t1)
+                if j < 2:
+                    native.conv1d_forward_into(t1, w2, bias, C, k, 1, 0.1, res=x, out=y)
+                else:
+                    native.conv1d_forward_into(t1, w2, bias, C, k, 1, 0.1, res=x, acc=acc, out_scale=1 / 3, out=y)
+    return run, flops, 12, alg_bytes
 
 
 def decoder_flops(T, rates, ksizes, c0=512, cin=192, res_k=(3, 7, 11), n_dil=3):
@@ -129,34 +165,32 @@ def main():
             torch.distributed.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel: stage-1 ResBlock conv (C = 128, k = 11, d = 5) at the cfg-2 length ----
+    # ---- roofline of the dominant kernel symbol: conv_mfma_kernel<11,2,2,2,2,4> (11-tap ResBlock convs at C >= 128) ----
     rates, ksizes = cpt["config"][12], cpt["config"][14]
     n_pad = n_in + 32000                              # 1 s reflect pad each side (pipeline.py:581)
     T = min(n_pad // 160, 2 * ((n_pad - 400) // 320 + 1))   # synth frames (pipeline.py:467)
-    L1 = T * rates[0] * rates[1]
-    C, K, DIL = 128, 11, 5
-    gen = torch.Generator(device=dev).manual_seed(0)
-    x = torch.randn(1, C, L1, device=dev, generator=gen)
-    w = torch.randn(C, C, K, generator=torch.Generator().manual_seed(1)) * 0.03
-    wp = _native.conv1d_pack_weight(w, dev)
-    bias = torch.zeros(C, device=dev)
-    res = torch.randn(1, C, L1, device=dev, generator=gen)
-    for _ in range(3):
-        _native.conv1d_forward(x, wp, bias, C, K, DIL, 0.1, res=res)
-    reps = 20
+    run_mix, mix_flops, mix_launches, mix_alg_bytes = roofline_mix(_native, dev, T, rates)
+    for _ in range(2):
+        run_mix()
+    reps = 5
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        _native.conv1d_forward(x, wp, bias, C, K, DIL, 0.1, res=res)
+        run_mix()
     e1.record()
     torch.cuda.synchronize()
-    t_conv = e0.elapsed_time(e1) / reps * 1e-3
-    conv_flops = 2.0 * C * C * K * L1
-    roofline = {"kernel": "conv_mfma_kernel<KW=11,128x128> (vocoder stage-1 ResBlock conv, C=128, k=11, d=5, L=%d)" % L1,
-                "bound": "mfma", "achieved": round(conv_flops / t_conv / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(conv_flops / t_conv / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": None, "flops_per_launch": conv_flops, "avg_launch_ms": round(t_conv * 1e3, 4)}
-    del x, res
+    t_launch = e0.elapsed_time(e1) / (reps * mix_launches) * 1e-3
+    flops_launch = mix_flops / mix_launches
+    cfg2 = T == 3198 and list(rates[:2]) == [12, 10]
+    roofline = {"kernel": "rvc::conv_mfma_kernel<11,2,2,2,2,4>: the 12 launches per utterance of the 11-tap ResBlock convs of vocoder "
+                          "stages 0 (C=256) and 1 (C=128), in the decoder's own mix (dilations 1/3/5, residual on every second one)",
+                "bound": "mfma", "achieved": round(flops_launch / t_launch / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(flops_launch / t_launch / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                "traffic": PMC_TRAFFIC_BYTES if cfg2 else None,
+                "traffic_source": PMC_TRAFFIC_SOURCE if cfg2 else None,
+                "algorithmic_bytes_per_launch": round(mix_alg_bytes / mix_launches),
+                "flops_per_launch": flops_launch, "avg_launch_ms": round(t_launch * 1e3, 4), "launches_per_utterance": mix_launches}
+    del run_mix
 
     # whole vocoder, timed with events around rvc_decoder_forward
     z = torch.randn(1, 192, T, device=dev)

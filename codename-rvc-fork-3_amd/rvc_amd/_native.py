@@ -226,9 +226,13 @@ def conv1d_pack_weight(w: torch.Tensor, device) -> torch.Tensor:
 
 
 def conv1d_forward(x, w_packed, bias, c_out, k, dilation=1, slope_in=1.0, res=None, acc=None, out_scale=1.0):
+    return conv1d_forward_into(x, w_packed, bias, c_out, k, dilation, slope_in, res=res, acc=acc, out_scale=out_scale)
+
+
+def conv1d_forward_into(x, w_packed, bias, c_out, k, dilation=1, slope_in=1.0, res=None, acc=None, out_scale=1.0, out=None):
     x = _dev_f32(x, "x")
     b, c_in, length = x.shape
-    y = torch.empty((b, c_out, length), dtype=torch.float32, device=x.device)
+    y = out if out is not None else torch.empty((b, c_out, length), dtype=torch.float32, device=x.device)
     _check(_lib.rvc_conv1d_forward(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
                                    res.data_ptr() if res is not None else None,
                                    acc.data_ptr() if acc is not None else None, y.data_ptr(), b, c_in, c_out, length, k,
