@@ -73,15 +73,27 @@ ff_chunk_kernel(const double *__restrict__ x, int64_t n, const double *yf_in, in
         for (int k = 0; k < FF_ORD; ++k) z[k] = 0.0;
         i = w0;
     }
-    for (; i < i0; ++i) ff_step(c, ff_input(x, n, yf_in, i, backward), z);
-    for (; i < i1; ++i) {
-        const double y = ff_step(c, ff_input(x, n, yf_in, i, backward), z);
-        if (!backward) {
-            yf_out[i] = y;
-        } else {
-            const int64_t j = ne - 1 - i - FF_PAD;   // position in the un-reversed, cropped output
-            if (j >= 0 && j < n) out[j] = y;
+    // the recurrence is serial but its inputs are not: fetch 8 samples ahead so the loads overlap the dependent chain
+    constexpr int PF = 8;
+    while (i < i1) {
+        double xin[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) xin[u] = (i + u < i1) ? ff_input(x, n, yf_in, i + u, backward) : 0.0;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (i + u < i1) {
+                const double y = ff_step(c, xin[u], z);
+                if (i + u >= i0) {
+                    if (!backward) {
+                        yf_out[i + u] = y;
+                    } else {
+                        const int64_t j = ne - 1 - (i + u) - FF_PAD;   // position in the un-reversed, cropped output
+                        if (j >= 0 && j < n) out[j] = y;
+                    }
+                }
+            }
         }
+        i += PF;
     }
 }
 
@@ -89,7 +101,7 @@ ff_chunk_kernel(const double *__restrict__ x, int64_t n, const double *yf_in, in
 
 using namespace rvc;
 
-constexpr int FF_CHUNK = 2048;
+constexpr int FF_CHUNK = 512;
 constexpr int FF_WARM = 4096;
 
 extern "C" int rvc_filtfilt_workspace_bytes(int64_t n, size_t *bytes) {

@@ -236,8 +236,62 @@ def test_filtfilt_matches_scipy(native, dev, n):
     assert y.shape == ref.shape
     # the direct-form recurrence is ill-conditioned: the reference's own lfilter restarted 8192 samples earlier moves by
     # 2e-8 (csrc/filtfilt.hip); short inputs (single chunk, exact start state) reproduce SciPy's op sequence exactly
-    assert np.abs(y - ref).max() <= (2e-7 if n > 2048 else 0.0), np.abs(y - ref).max()   # single chunk: bit-exact
+    assert np.abs(y - ref).max() <= (2e-7 if n > 512 - 36 else 0.0), np.abs(y - ref).max()   # single chunk: bit-exact
     if n == 4000:
         g = load_golden("filtfilt")
         yg = native.filtfilt_order5(torch.from_numpy(g["x"]).to(dev), g["bh"], g["ah"]).cpu().numpy()
         assert np.abs(yg - g["y"]).max() <= 2e-7
+
+
+# ---- BASELINE cfg 4 / cfg 5 shapes ---------------------------------------------------------------------
+def test_cfg4_mrf_bf16_rounded_weights(native, dev, ref_inputs):
+    """cfg 4: MRF vocoder with bf16-stored weights.  Oracle = fp32 math on the SAME bf16-rounded tensors."""
+    from oracle import rvc_oracle as O
+    from rvc_amd.lib import synthetic as S
+    from rvc_amd.lib.algorithm.weights import fold_weight_norm
+    T = 48
+    cpt = S.make_synth_checkpoint(48000, "MRF HiFi-GAN", seed=0)
+    cpt["weight"] = {k: (v.to(torch.bfloat16).float() if v.is_floating_point() else v) for k, v in cpt["weight"].items()}
+    w = O.fold_weight_norm(cpt["weight"])
+    rates, ksizes = cpt["config"][12], cpt["config"][14]
+    gen = torch.Generator().manual_seed(3)
+    z, g = torch.randn(1, 192, T, generator=gen), torch.randn(1, 256, 1, generator=gen)
+    f0 = _decoder_inputs(ref_inputs, T)
+    src_rand, src_randn = torch.rand(1, 9, generator=gen), torch.randn(1, T * 480, 9, generator=gen)
+    ref = O.decoder_mrf(w, z, f0, g, rates, ksizes, 48000, O.ListNoise([src_rand.clone(), src_randn])).numpy()
+    folded = {k[4:]: v for k, v in fold_weight_norm(cpt["weight"]).items() if k.startswith("dec.")}
+    dec = native.Decoder("MRF HiFi-GAN", 48000, folded)
+    out = dec.forward(z.to(dev), f0.to(dev), g[:, :, 0].to(dev), src_randn=src_randn.to(dev), src_rand=src_rand.to(dev)).cpu().numpy()
+    assert rms(out - ref) <= 5e-5, rms(out - ref)
+
+
+def test_cfg5_two_million_row_index(native, dev):
+    """cfg 5: 2 M x 768 index (6.1 GB) searched brute-force in HBM.  Checked against a float64 torch search on the device
+    for a sample of queries, and against planted neighbours."""
+    n_rows, n_q = 2_000_000, 96
+    g = torch.Generator(device=dev).manual_seed(0)
+    centres = torch.randn(4096, 768, device=dev, generator=g) * 0.35
+    index = torch.empty(n_rows, 768, device=dev)
+    for s in range(0, n_rows, 250_000):
+        which = torch.randint(0, 4096, (250_000,), device=dev, generator=g)
+        index[s:s + 250_000] = centres[which] + 0.05 * torch.randn(250_000, 768, device=dev, generator=g)
+    planted = torch.randint(0, n_rows, (n_q,), device=dev, generator=g)
+    q = index[planted] + 0.01 * torch.randn(n_q, 768, device=dev, generator=g)
+    norms = native.knn_index_norms(index)
+    d2, ids = native.knn_search(index, norms, q)
+    assert (ids[:, 0] == planted).all()                      # the planted row is the nearest neighbour
+    assert (d2[:, 1:] >= d2[:, :-1]).all()
+    # exact float64 reference for the first 16 queries
+    q64 = q[:16].double()
+    best_d = torch.full((16, 8), float("inf"), dtype=torch.float64, device=dev)
+    best_i = torch.zeros((16, 8), dtype=torch.int64, device=dev)
+    for s in range(0, n_rows, 250_000):
+        x = index[s:s + 250_000].double()
+        d = (q64 * q64).sum(1)[:, None] - 2 * q64 @ x.T + (x * x).sum(1)[None, :]
+        cd = torch.cat([best_d, d], 1)
+        ci = torch.cat([best_i, torch.arange(s, s + x.shape[0], device=dev).expand(16, -1)], 1)
+        o = torch.argsort(cd, dim=1, stable=True)[:, :8]
+        best_d, best_i = torch.gather(cd, 1, o), torch.gather(ci, 1, o)
+    agree = (ids[:16] == best_i).float().mean().item()
+    assert agree >= 0.97, agree                              # near-ties may swap (see test_knn_ids_and_distances)
+    assert torch.allclose(d2[:16].double(), best_d, rtol=1e-3, atol=1e-3)

@@ -16,6 +16,13 @@ T = 3198
 dim = 9 if voc.startswith("MRF") else 1
 z = torch.randn(1, 192, T, device=dev); f0 = torch.full((1, T), 220.0, device=dev); g = torch.randn(1, 256, device=dev)
 nz = torch.randn(1, T * 480, dim, device=dev); rnd = torch.rand(1, dim, device=dev)
+adain = None
+if voc == "RefineGAN":
+    n, length, ch = 0, T, 512
+    for r in (12, 10, 2, 2):
+        length, ch = length * r, ch // 2
+        n += 6 * ch * length
+    adain = torch.randn(n, device=dev)
 for _ in range(int(os.environ.get("REPS", "3"))):
-    dec.forward(z, f0, g, src_randn=nz, src_rand=rnd)
+    dec.forward(z, f0, g, src_randn=nz, src_rand=rnd, adain_randn=adain)
 torch.cuda.synchronize()
