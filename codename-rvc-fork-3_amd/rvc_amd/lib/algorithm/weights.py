@@ -2,7 +2,7 @@
 
 The reference keeps weight-norm parametrised at inference and recomputes ``w = g * v / ||v||`` on
 every forward (``remove_weight_norm`` is never called on the inference path).  Here the
-fold happens once at load, in fp32, with the same formula torch's ``_weight_norm`` uses.
+fold happens once at load, in fp32, through ``torch._weight_norm`` itself.
 """
 from __future__ import annotations
 
@@ -26,8 +26,9 @@ def fold_weight_norm(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
                 base = key[: -len(v_sfx)]
                 g = sd[base + g_sfx].float()
                 vf = v.float()
-                dims = [d for d in range(vf.dim()) if g.shape[d] == 1]
-                out[base + ".weight"] = vf * (g / vf.norm(2, dim=dims, keepdim=True))
+                keep = [d for d in range(vf.dim()) if g.shape[d] != 1]
+                # the very op the reference's parametrization executes per forward (torch._weight_norm), run once
+                out[base + ".weight"] = torch._weight_norm(vf, g, keep[0] if keep else 0)
                 consumed.update((key, base + g_sfx))
     for key, v in sd.items():
         if key not in consumed:

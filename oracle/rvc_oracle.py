@@ -39,7 +39,7 @@ Tensor = torch.Tensor
 
 
 def fold_weight_norm(sd: Dict[str, Tensor]) -> Dict[str, Tensor]:
-    """weight = v * (g / ||v||) exactly as torch's ``_weight_norm`` does on every forward
+    """weight = g * v / ||v|| through ``torch._weight_norm``, the op the reference's parametrization runs on every forward
     (the reference never removes weight-norm at inference: SURVEY §3.3).
 
     Accepts both the legacy export naming (``.weight_g/.weight_v``,
@@ -58,8 +58,9 @@ def fold_weight_norm(sd: Dict[str, Tensor]) -> Dict[str, Tensor]:
                 gk = base + ".parametrizations.weight.original0"
             g = sd[gk].float()
             v = val.float()
-            dims = [d for d in range(v.dim()) if g.shape[d] == 1]
-            out[base + ".weight"] = v * (g / v.norm(2, dim=dims, keepdim=True))
+            keep = [d for d in range(v.dim()) if g.shape[d] != 1]
+            # torch.nn.utils.parametrizations._WeightNorm.forward -> torch._weight_norm(v, g, dim): the op the reference runs
+            out[base + ".weight"] = torch._weight_norm(v, g, keep[0] if keep else 0)
             done.add(key)
             done.add(gk)
     for key, val in sd.items():
