@@ -38,6 +38,11 @@ struct ConvParams {
 // picks the tile configuration from m_total; returns non-zero and sets the error on unsupported shapes
 int launch_conv(const ConvParams &p, hipStream_t stream);
 
+// fused ResBlock layer (resblock.hip): y = conv2(leaky(conv1_d(leaky(x)))) + x [+ accin], * out_scale; x != y
+bool resblock_layer_supported(int c, int k);
+int launch_resblock_layer(const float *x, const float *w1, const float *b1, const float *w2, const float *b2, const float *accin,
+                          float *y, int batch, int c, int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream);
+
 // host-side repacks (return freshly hipMalloc'ed device buffers)
 // regular conv weight [c_out][c_in][k] -> [k][c_in][c_out]
 int pack_conv_weight(const float *w_host, int c_out, int c_in, int k, float **out_dev);

@@ -631,6 +631,22 @@ extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const flo
         for (int m = 0; m < nk; ++m) {
             const int k = c.res_kernel_sizes[m];
             const float *xin = X;
+            if (resblock_layer_supported(s.c_out, k)) {
+                // narrow stages: one fused launch per layer; no in-place update (blocks read neighbours' columns),
+                // so the layer outputs ping-pong between Y and T1
+                for (int j = 0; j < nd; ++j) {
+                    const bool last = j + 1 == nd;
+                    float *yout = last ? cur : (j % 2 == 0 ? Y : T1);
+                    const float *acc_in = (last && m > 0) ? cur : nullptr;
+                    const float scale = (last && m + 1 == nk) ? 1.f / (float)nk : 1.f;
+                    if (launch_resblock_layer(xin, s.c1[m * nd + j].w.p, s.c1[m * nd + j].b.p, s.c2[m * nd + j].w.p,
+                                              s.c2[m * nd + j].b.p, acc_in, yout, batch, s.c_out, len, k, c.res_dilations[j], 0.1f,
+                                              scale, stream))
+                        return 1;
+                    xin = yout;
+                }
+                continue;
+            }
             for (int j = 0; j < nd; ++j) {
                 const int dil = c.res_dilations[j];
                 ConvParams p;

@@ -1,0 +1,220 @@
+// Fused ResBlock layer for the narrow vocoder stages (C = 32, 64):
+//     y = conv2( leaky( conv1_d( leaky(x) ) ) ) + x  [+ running sum] [* 1/3]          (residuals.py:75-86, one dilation)
+// in ONE launch.  At C <= 64 the two convs of a layer are not MFMA-bound but latency-bound on their HBM phases
+// (measured with the unfused kernel: ~380 us of exposed load/store time per launch on 196 MB tensors, whatever the
+// FLOP count).  Fusing removes the intermediate's write + read and the separate residual read: per layer the
+// activation is read once and written once (2 tensor passes instead of 5), and the whole input tile is requested
+// in one burst so its HBM latency is paid once per block instead of once per 4-channel chunk.
+//
+// Block = 4 waves.  LDS holds the RAW input tile xs[C][N1 + (K-1)*dil] (leaky is applied when fragments are read,
+// 2 VALU ops per MFMA operand, because the residual needs the raw values), the intermediate tile ts[C][N1 + K - 1]
+// and a double-buffered slab of the current conv's weights.  N1 = columns of conv1 computed by the block (128 at
+// C = 32, 64 at C = 64: sized so that 2-3 blocks share a CU's 160 KB); the block emits BN = N1 - (K - 1) output
+// columns, i.e. both GEMMs run N1 wide and the K - 1 overlapping columns are recomputed by the neighbour.
+#include <stdlib.h>
+
+#include "conv.h"
+
+namespace rvc {
+
+// N1 = conv1 columns per block; the 4 waves are arranged WM (output-channel tiles) x WN (column tiles)
+template <int KW, int C, int N1, int WM>
+struct FusedCfg {
+    static constexpr int WN = 4 / WM;
+    static constexpr int MT = C / 32 / WM;            // row tiles per wave
+    static constexpr int NT = N1 / 32 / WN;           // column tiles per wave
+    static constexpr int CIC = KW <= 3 ? 16 : 4;      // input channels per weight slab
+    static constexpr int XW = N1 + (KW - 1) * 5;      // staged input row (dilation <= 5)
+    static constexpr int TW = N1 + (KW - 1);          // intermediate row
+    static constexpr int WSLAB = KW * CIC * C;
+    static_assert(MT >= 1 && NT >= 1, "tile split");
+};
+
+template <int KW, int C, int N1, int WM>
+__global__ void __launch_bounds__(256)
+resblock_layer_kernel(const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
+                      const float *__restrict__ w2, const float *__restrict__ b2, const float *accin,
+                      float *y, int64_t L, int dil, float slope, float out_scale) {
+    using F = FusedCfg<KW, C, N1, WM>;
+    constexpr int MT = F::MT, NT = F::NT, WN = F::WN, CIC = F::CIC, XW = F::XW, TW = F::TW, WSLAB = F::WSLAB;
+    constexpr int BN = N1 - (KW - 1);
+    constexpr int H2 = (KW - 1) / 2;
+    constexpr int W4 = WSLAB / 4;
+    constexpr int WN4 = (W4 + 255) / 256;
+    constexpr int NCH = C / CIC;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *ws = smem;                       // [2][WSLAB]
+    float *xs = ws + 2 * WSLAB;             // [C][XW]   raw input
+    float *ts = xs + C * XW;                // [C][TW]   leaky(conv1 + b1), zero outside [0, L)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+    const int row0 = wm * MT * 32, colw = wn * NT * 32;   // this wave's output-channel and column offsets
+    const int64_t b = blockIdx.y;
+    const int64_t t0 = (int64_t)blockIdx.x * BN;          // first output column of the block
+    const int h1 = H2 * dil;
+    const float *xb = x + b * C * L;
+    const int64_t x_time0 = t0 - H2 - h1;                 // time of xs[.][0]
+
+    // ---- stage the whole input tile (every load in flight at once) ----
+    for (int idx = tid; idx < C * XW; idx += 256) {
+        const int ci = idx / XW, v = idx - ci * XW;
+        const int64_t t = x_time0 + v;
+        xs[idx] = (t >= 0 && t < L) ? xb[(int64_t)ci * L + t] : 0.f;
+    }
+    for (int idx = tid; idx < C * (KW - 1); idx += 256) {  // tail columns of ts read by the wasted conv2 columns
+        const int ci = idx / (KW - 1), u = N1 + idx - ci * (KW - 1);
+        ts[ci * TW + u] = 0.f;
+    }
+
+    float4 wr[WN4];
+    auto load_w = [&](const float *w, int c) {
+#pragma unroll
+        for (int i = 0; i < WN4; ++i) {
+            const int idx4 = tid + i * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx4 < W4) {
+                const int row = idx4 / (C / 4), c4 = idx4 - row * (C / 4);   // row = tap * CIC + ci
+                const int tap = row / CIC, ci = row - tap * CIC;
+                v = *reinterpret_cast<const float4 *>(w + ((int64_t)tap * C + c * CIC + ci) * C + c4 * 4);
+            }
+            wr[i] = v;
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WN4; ++i) {
+            const int idx4 = tid + i * 256;
+            if (idx4 < W4) *reinterpret_cast<float4 *>(&ws[buf * WSLAB + idx4 * 4]) = wr[i];
+        }
+    };
+
+    f32x16 acc[MT][NT];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    };
+    // one conv as NCH weight slabs; B fragments come from `src` (row stride `sw`), tap offset `td`, leaky on read
+    auto run_conv = [&](const float *w, const float *src, int sw, int td, bool act) {
+        zero_acc();
+        load_w(w, 0);
+        store_w(0);
+        if (NCH > 1) load_w(w, 1);
+        __syncthreads();
+        for (int c = 0; c < NCH; ++c) {
+            const int buf = c & 1;
+            const float *wa = &ws[buf * WSLAB + half * C + row0 + l31];
+            const float *sb = &src[(c * CIC + half) * sw + colw + l31];
+#pragma unroll
+            for (int tap = 0; tap < KW; ++tap) {
+#pragma unroll
+                for (int kk = 0; kk < CIC / 2; ++kk) {
+                    float a[MT], bb[NT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) a[m] = wa[(tap * CIC + 2 * kk) * C + m * 32];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const float v = sb[(2 * kk) * sw + n * 32 + tap * td];
+                        bb[n] = act ? lrelu(v, slope) : v;
+                    }
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) acc[m][n] = mfma32(a[m], bb[n], acc[m][n]);
+                }
+            }
+            if (c + 1 < NCH) {
+                store_w(buf ^ 1);
+                if (c + 2 < NCH) load_w(w, c + 2);
+                __syncthreads();
+            }
+        }
+    };
+
+    // ---- conv1 (dilated) -> ts ----
+    run_conv(w1, xs, XW, dil, true);   // the barrier inside also publishes xs
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + m * 32 + mfma32_row(r, lane);
+            const float bv = b1[row];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int u = colw + n * 32 + l31;
+                const int64_t t = t0 - H2 + u;
+                // conv2 zero-pads ITS input: positions outside the signal are 0, not conv1 of the padding
+                ts[row * TW + u] = (t >= 0 && t < L) ? lrelu(acc[m][n][r] + bv, slope) : 0.f;
+            }
+        }
+    __syncthreads();   // ts complete; every wave is done with the conv1 weight slabs
+
+    // ---- conv2 (dilation 1) + bias + residual (+ running sum, scale) -> y ----
+    run_conv(w2, ts, TW, 1, false);
+    float *yb = y + b * C * L;
+    const float *ab = accin ? accin + b * C * L : nullptr;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + m * 32 + mfma32_row(r, lane);
+            const float bv = b2[row];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int j = colw + n * 32 + l31;
+                const int64_t t = t0 + j;
+                if (j < BN && t < L) {
+                    float v = acc[m][n][r] + bv + xs[row * XW + j + H2 + h1];
+                    if (ab) v += ab[(int64_t)row * L + t];
+                    yb[(int64_t)row * L + t] = v * out_scale;
+                }
+            }
+        }
+}
+
+template <int KW, int C, int N1, int WM>
+static int launch_fused(const float *x, const float *w1, const float *b1, const float *w2, const float *b2, const float *accin,
+                        float *y, int batch, int64_t L, int dil, float slope, float out_scale, hipStream_t stream) {
+    using F = FusedCfg<KW, C, N1, WM>;
+    constexpr int BN = N1 - (KW - 1);
+    const size_t lds = (size_t)(2 * F::WSLAB + C * F::XW + C * F::TW) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)resblock_layer_kernel<KW, C, N1, WM>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail("resblock_layer: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((resblock_layer_kernel<KW, C, N1, WM>), dim3((unsigned)ceil_div(L, BN), batch), dim3(256), lds, stream, x, w1,
+                       b1, w2, b2, accin, y, L, dil, slope, out_scale);
+    RVC_LAUNCH_CHECK();
+    return 0;
+}
+
+bool resblock_layer_supported(int c, int k) {
+    static const int off = getenv("RVC_NO_FUSED_RESBLOCK") ? atoi(getenv("RVC_NO_FUSED_RESBLOCK")) : 0;
+    // measured on MI355X (profiles/r01_decoder_kernels.txt): fused beats two launches for every k at C = 32 (-0.2..-0.28 ms per
+    // layer) and for k = 3 at C = 64; the 7/11-tap layers at C = 64 are MFMA-bound and lose to the wider unfused tiles
+    return !off && ((c == 32 && (k == 3 || k == 7 || k == 11)) || (c == 64 && k == 3));
+}
+
+// x, y: [batch][c][L] (must NOT alias: blocks read their neighbours' columns); w1/w2 packed [k][c][c]
+int launch_resblock_layer(const float *x, const float *w1, const float *b1, const float *w2, const float *b2, const float *accin,
+                          float *y, int batch, int c, int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream) {
+    if (x == y) return fail("resblock_layer: in-place operation is not supported");
+    if (dil < 1 || dil > 5) return fail("resblock_layer: dilation %d out of range", dil);
+    static const int wide64 = getenv("RVC_FUSED_C64_WIDE") ? atoi(getenv("RVC_FUSED_C64_WIDE")) : 0;
+#define RVC_FUSED_CASE(KW, CC, NN, WMM) if (k == KW && c == CC) return launch_fused<KW, CC, NN, WMM>(x, w1, b1, w2, b2, accin, y, batch, L, dil, slope, out_scale, stream)
+    RVC_FUSED_CASE(3, 32, 128, 1); RVC_FUSED_CASE(7, 32, 128, 1); RVC_FUSED_CASE(11, 32, 128, 1);
+    if (wide64) { RVC_FUSED_CASE(3, 64, 128, 1); RVC_FUSED_CASE(7, 64, 128, 1); RVC_FUSED_CASE(11, 64, 128, 1); }
+    RVC_FUSED_CASE(3, 64, 64, 2); RVC_FUSED_CASE(7, 64, 64, 2); RVC_FUSED_CASE(11, 64, 64, 2);
+#undef RVC_FUSED_CASE
+    return fail("resblock_layer: unsupported shape c=%d k=%d", c, k);
+}
+
+}  // namespace rvc
