@@ -395,7 +395,15 @@ int refine_forward(rvc_decoder *d, const float *z_dev, const float *f0_dev, cons
             RVC_LAUNCH_CHECK();
             nz += (size_t)batch * bs;
             const float *xin = A;
-            for (int j = 0; j < nd; ++j) {
+            const bool fused = resblock_layer_supported(s.ch_out, k) && nd == 3;
+            for (int j = 0; fused && j < nd; ++j) {   // A -> Y -> T1 -> Y (no in-place: blocks read neighbours' columns)
+                float *yout = (j == 1) ? T1 : Y;
+                if (launch_resblock_layer(xin, s.c1[m * nd + j].w.p, s.c1[m * nd + j].b.p, s.c2[m * nd + j].w.p, s.c2[m * nd + j].b.p,
+                                          nullptr, yout, batch, s.ch_out, lo, k, c.res_dilations[j], slope, 1.f, stream))
+                    return 1;
+                xin = yout;
+            }
+            for (int j = 0; !fused && j < nd; ++j) {
                 const int dil = c.res_dilations[j];
                 ConvParams p;
                 p.x1 = xin; p.c1 = s.ch_out; p.slope1 = slope; p.x1_bstride = bs; p.l_in = lo;
