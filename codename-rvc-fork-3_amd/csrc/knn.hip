@@ -18,6 +18,8 @@
 //   Partial lists ([query][slot][8], slot = stripe x wave-row x lane-half) are merged by one wave per query.
 //
 // d2 = ||x||^2 - 2 q.x + ||q||^2 is faiss' own BLAS formulation (IndexFlat, > 20 queries), clamped at 0.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace rvc {
@@ -193,50 +195,145 @@ knn_partial_kernel(const float *__restrict__ index, const float *__restrict__ no
     }
 }
 
+
+// ---- streaming variant for few queries (Q <= 64): HBM-bound ---------------------------------------------------
+// With one or two 32-query column tiles the GEMM is tiny (2*32*N*768 FLOP = 49 us of MFMA at N = 100 k) and the index
+// read (N*3072 B) is the bound, so the job is to keep HBM busy: a block still transposes 128 rows x 32 floats
+// through LDS per chunk, but THREE chunks of index data are in flight per block (register ring, 48 KB per block,
+// ~6 blocks per CU) instead of one, and stripes are short so that ~8 blocks per CU exist.  Each of the 4 waves owns
+// 32 of the block's 128 rows and one 32-query MFMA tile; per-lane sorted top-8 lists as in the batch kernel.
+constexpr int KNS_BQ = 32;
+constexpr int KNS_SLOTS_PER_STRIPE = 1;   // the block merges its 8 (wave, lane-half) lists before writing
+
+template <int KNS_PF>
+__global__ void __launch_bounds__(256)
+knn_stream_kernel(const float *__restrict__ index, const float *__restrict__ norms, int64_t n_rows, int dim,
+                  const float *__restrict__ queries, int64_t n_queries, int64_t stripe_rows, float *__restrict__ part_d,
+                  int *__restrict__ part_id, int n_slots) {
+    __shared__ float Xs[KNN_BN * KNN_LDS_STRIDE];
+    __shared__ float Qs[KNS_BQ * KNN_LDS_STRIDE];
+    __shared__ float xn_s[KNN_BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int64_t q0 = (int64_t)blockIdx.x * KNS_BQ;
+    const int64_t stripe_begin = (int64_t)blockIdx.y * stripe_rows;
+    const int64_t stripe_end = min(n_rows, stripe_begin + stripe_rows);
+    const int n_tiles = (int)((stripe_end - stripe_begin + KNN_BN - 1) / KNN_BN);
+    const int n_kc = dim / KNN_KC;
+    const int n_chunks = n_tiles * n_kc;
+    TopK best;
+    best.init();
+
+    float4 xr[KNS_PF][4];
+    float4 qr[KNS_PF];
+    const int srow = tid >> 3, sc4 = tid & 7;
+    auto load_chunk = [&](int slot, int c) {
+        const int tile = c / n_kc, kc = c - tile * n_kc;
+        const int64_t n_base = stripe_begin + (int64_t)tile * KNN_BN;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int64_t n = n_base + p * 32 + srow;
+            xr[slot][p] = (n < stripe_end) ? *reinterpret_cast<const float4 *>(index + n * dim + kc * KNN_KC + sc4 * 4)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const int64_t q = q0 + srow;
+        qr[slot] = (q < n_queries) ? *reinterpret_cast<const float4 *>(queries + q * dim + kc * KNN_KC + sc4 * 4)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto store_chunk = [&](int slot) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float *xd = &Xs[(p * 32 + srow) * KNN_LDS_STRIDE + sc4 * 4];
+            xd[0] = xr[slot][p].x; xd[1] = xr[slot][p].y; xd[2] = xr[slot][p].z; xd[3] = xr[slot][p].w;
+        }
+        float *qd = &Qs[srow * KNN_LDS_STRIDE + sc4 * 4];
+        qd[0] = qr[slot].x; qd[1] = qr[slot].y; qd[2] = qr[slot].z; qd[3] = qr[slot].w;
+    };
+
+#pragma unroll
+    for (int s = 0; s < KNS_PF; ++s)
+        if (s < n_chunks) load_chunk(s, s);
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    for (int c0 = 0; c0 < n_chunks; c0 += KNS_PF) {
+#pragma unroll
+        for (int s = 0; s < KNS_PF; ++s) {
+            const int c = c0 + s;
+            if (c < n_chunks) {   // block-uniform
+                const int tile = c / n_kc, kc = c - tile * n_kc;
+                const int64_t n_base = stripe_begin + (int64_t)tile * KNN_BN;
+                __syncthreads();
+                store_chunk(s);
+                if (kc == 0 && tid < KNN_BN) {
+                    const int64_t n = n_base + tid;
+                    xn_s[tid] = (n < stripe_end) ? norms[n] : INFINITY;
+                }
+                __syncthreads();
+                if (c + KNS_PF < n_chunks) load_chunk(s, c + KNS_PF);
+                const float *xa = &Xs[(wave * 32 + l31) * KNN_LDS_STRIDE + half];
+                const float *qb = &Qs[l31 * KNN_LDS_STRIDE + half];
+#pragma unroll
+                for (int kk = 0; kk < KNN_KC / 2; ++kk) acc = mfma32(xa[2 * kk], qb[2 * kk], acc);
+                if (kc == n_kc - 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wave * 32 + mfma32_row(r, lane);
+                        best.insert(fmaf(-2.f, acc[r], xn_s[row]), (int)(n_base + row));
+                        acc[r] = 0.f;
+                    }
+                }
+            }
+        }
+    }
+    // merge the block's 8 (wave, lane-half) lists per query in LDS -> ONE sorted list per (query, stripe)
+    __syncthreads();
+    float *md = Xs;                                        // [32 queries][64 candidates], reusing the staging tile
+    int *mi = reinterpret_cast<int *>(Xs + KNS_BQ * 64);
+#pragma unroll
+    for (int i = 0; i < KNN_K; ++i) {
+        md[l31 * 64 + (wave * 2 + half) * KNN_K + i] = best.d[i];
+        mi[l31 * 64 + (wave * 2 + half) * KNN_K + i] = best.id[i];
+    }
+    __syncthreads();
+    if (tid < KNS_BQ) {
+        TopK m;
+        m.init();
+        for (int c = 0; c < 64; ++c) {   // lists arrive in ascending row order within a slot; ties keep the lower id
+            const float v = md[tid * 64 + c];
+            const int n = mi[tid * 64 + c];
+            if (n < 0) continue;
+            if (v < m.d[KNN_K - 1] || (v == m.d[KNN_K - 1] && (unsigned)n < (unsigned)m.id[KNN_K - 1])) {
+#pragma unroll
+                for (int p = KNN_K - 1; p >= 1; --p) {
+                    const bool shift = v < m.d[p - 1] || (v == m.d[p - 1] && (unsigned)n < (unsigned)m.id[p - 1]);
+                    const bool here = v < m.d[p] || (v == m.d[p] && (unsigned)n < (unsigned)m.id[p]);
+                    const float nd = shift ? m.d[p - 1] : (here ? v : m.d[p]);
+                    const int ni = shift ? m.id[p - 1] : (here ? n : m.id[p]);
+                    m.d[p] = nd;
+                    m.id[p] = ni;
+                }
+                if (v < m.d[0] || (v == m.d[0] && (unsigned)n < (unsigned)m.id[0])) { m.d[0] = v; m.id[0] = n; }
+            }
+        }
+        const int64_t q = q0 + tid;
+        if (q < n_queries) {
+            float *pd = part_d + (q * n_slots + blockIdx.y) * KNN_K;
+            int *pi = part_id + (q * n_slots + blockIdx.y) * KNN_K;
+#pragma unroll
+            for (int i = 0; i < KNN_K; ++i) { pd[i] = m.d[i]; pi[i] = m.id[i]; }
+        }
+    }
+}
+
 __device__ __forceinline__ bool cand_less(float da, int ia, float db, int ib) {
     return (da < db) || (da == db && (unsigned)ia < (unsigned)ib);
 }
 
-// one wave per query: merge n_slots sorted lists of 8 into the final ascending top-8
-__global__ void __launch_bounds__(64)
-knn_merge_kernel(const float *__restrict__ part_d, const int *__restrict__ part_id, int n_slots,
-                 const float *__restrict__ queries, int dim, float *__restrict__ out_d2,
-                 int64_t *__restrict__ out_ids) {
-    const int64_t q = blockIdx.x;
-    const int lane = threadIdx.x;
-    // ||q||^2
-    float qn = 0.f;
-    for (int i = lane; i < dim; i += 64) {
-        const float v = queries[q * dim + i];
-        qn = fmaf(v, v, qn);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
-
-    // per-lane sorted top-8 over this lane's share of the candidates, ordered by (d, id)
-    float d[KNN_K];
-    int id[KNN_K];
-#pragma unroll
-    for (int i = 0; i < KNN_K; ++i) { d[i] = INFINITY; id[i] = 0x7fffffff; }
-    const int total = n_slots * KNN_K;
-    for (int c = lane; c < total; c += 64) {
-        const float v = part_d[q * total + c];
-        const int n = part_id[q * total + c];
-        if (n < 0) continue;
-        if (cand_less(v, n, d[KNN_K - 1], id[KNN_K - 1])) {
-#pragma unroll
-            for (int p = KNN_K - 1; p >= 1; --p) {
-                const bool shift = cand_less(v, n, d[p - 1], id[p - 1]);
-                const bool here = cand_less(v, n, d[p], id[p]);
-                const float nd = shift ? d[p - 1] : (here ? v : d[p]);
-                const int ni = shift ? id[p - 1] : (here ? n : id[p]);
-                d[p] = nd;
-                id[p] = ni;
-            }
-            if (cand_less(v, n, d[0], id[0])) { d[0] = v; id[0] = n; }
-        }
-    }
-    // 8 rounds of wave-wide arg-min over the lane heads
+// one block (4 waves) per query: merge n_slots sorted lists of 8 into the final ascending top-8
+__device__ __forceinline__ void wave_top8(float (&d)[KNN_K], int (&id)[KNN_K], int lane, float *out_d, int *out_i) {
+    // 8 rounds of wave-wide arg-min over the lane heads (lists sorted ascending by (d, id))
     for (int round = 0; round < KNN_K; ++round) {
         float bd = d[0];
         int bi = id[0];
@@ -248,15 +345,75 @@ knn_merge_kernel(const float *__restrict__ part_d, const int *__restrict__ part_
             const int ol = __shfl_xor(bl, o);
             if (cand_less(od, oi, bd, bi) || (od == bd && oi == bi && ol < bl)) { bd = od; bi = oi; bl = ol; }
         }
-        if (lane == 0) {
-            out_d2[q * KNN_K + round] = fmaxf(bd + qn, 0.f);
-            out_ids[q * KNN_K + round] = (bi == 0x7fffffff) ? -1 : (int64_t)bi;
-        }
+        if (lane == 0) { out_d[round] = bd; out_i[round] = bi; }
         if (lane == bl) {  // pop
 #pragma unroll
             for (int p = 0; p < KNN_K - 1; ++p) { d[p] = d[p + 1]; id[p] = id[p + 1]; }
             d[KNN_K - 1] = INFINITY;
             id[KNN_K - 1] = 0x7fffffff;
+        }
+    }
+}
+
+__device__ __forceinline__ void list_insert(float (&d)[KNN_K], int (&id)[KNN_K], float v, int n) {
+    if (cand_less(v, n, d[KNN_K - 1], id[KNN_K - 1])) {
+#pragma unroll
+        for (int p = KNN_K - 1; p >= 1; --p) {
+            const bool shift = cand_less(v, n, d[p - 1], id[p - 1]);
+            const bool here = cand_less(v, n, d[p], id[p]);
+            const float nd = shift ? d[p - 1] : (here ? v : d[p]);
+            const int ni = shift ? id[p - 1] : (here ? n : id[p]);
+            d[p] = nd;
+            id[p] = ni;
+        }
+        if (cand_less(v, n, d[0], id[0])) { d[0] = v; id[0] = n; }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+knn_merge_kernel(const float *__restrict__ part_d, const int *__restrict__ part_id, int n_slots,
+                 const float *__restrict__ queries, int dim, float *__restrict__ out_d2,
+                 int64_t *__restrict__ out_ids) {
+    __shared__ float wd[4 * KNN_K];
+    __shared__ int wi[4 * KNN_K];
+    __shared__ float qn_s[4];
+    const int64_t q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ||q||^2
+    float qn = 0.f;
+    for (int i = tid; i < dim; i += 256) {
+        const float v = queries[q * dim + i];
+        qn = fmaf(v, v, qn);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
+    if (lane == 0) qn_s[wave] = qn;
+
+    float d[KNN_K];
+    int id[KNN_K];
+#pragma unroll
+    for (int i = 0; i < KNN_K; ++i) { d[i] = INFINITY; id[i] = 0x7fffffff; }
+    const int total = n_slots * KNN_K;
+    for (int c = tid; c < total; c += 256) {
+        const int n = part_id[q * total + c];
+        if (n >= 0) list_insert(d, id, part_d[q * total + c], n);
+    }
+    wave_top8(d, id, lane, &wd[wave * KNN_K], &wi[wave * KNN_K]);
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < KNN_K; ++i) { d[i] = INFINITY; id[i] = 0x7fffffff; }
+        if (lane < 4 * KNN_K) { d[0] = wd[lane]; id[0] = wi[lane]; }
+        float fd[KNN_K];
+        int fi[KNN_K];
+        wave_top8(d, id, lane, fd, fi);
+        if (lane == 0) {
+            const float qq = (qn_s[0] + qn_s[1]) + (qn_s[2] + qn_s[3]);
+#pragma unroll
+            for (int r = 0; r < KNN_K; ++r) {
+                out_d2[q * KNN_K + r] = fmaxf(fd[r] + qq, 0.f);
+                out_ids[q * KNN_K + r] = (fi[r] == 0x7fffffff) ? -1 : (int64_t)fi[r];
+            }
         }
     }
 }
@@ -287,14 +444,32 @@ knn_blend_kernel(const float *__restrict__ index, int dim, const float *__restri
     }
 }
 
-static int knn_stripes(int64_t n_rows, int64_t n_queries) {
-    const int64_t q_tiles = ceil_div(n_queries, KNN_BQ);
-    // aim for >= 6 blocks per CU's worth of work items, but never stripes shorter than 4 tiles
-    int64_t want = ceil_div(256 * 6, q_tiles);
-    const int64_t max_stripes = ceil_div(n_rows, (int64_t)4 * KNN_BN);
+constexpr int64_t KNN_STREAM_MAX_Q = 64;   // at most two 32-query column tiles take the streaming kernel
+
+struct KnnPlan {
+    bool stream;
+    int stripes, slots_per_stripe, q_tile;
+    int64_t stripe_rows;
+    int n_slots() const { return stripes * slots_per_stripe; }
+};
+
+static KnnPlan knn_plan(int64_t n_rows, int64_t n_queries) {
+    static const int force_batch = getenv("RVC_KNN_NO_STREAM") ? atoi(getenv("RVC_KNN_NO_STREAM")) : 0;
+    KnnPlan p;
+    p.stream = n_queries <= KNN_STREAM_MAX_Q && !force_batch;
+    p.q_tile = p.stream ? KNS_BQ : KNN_BQ;
+    p.slots_per_stripe = p.stream ? KNS_SLOTS_PER_STRIPE : KNN_SLOTS_PER_STRIPE;
+    const int64_t q_tiles = ceil_div(n_queries, p.q_tile);
+    // batch kernel: >= 6 blocks per CU, stripes of >= 4 row tiles; streaming kernel: 2 blocks per CU (longer stripes
+    // amortise the per-block prologue and merge: 4.0 TB/s vs 3.4 TB/s at 8 per CU on a 2 M-row index)
+    static const int bpc = getenv("RVC_KNN_STREAM_BPC") ? atoi(getenv("RVC_KNN_STREAM_BPC")) : 2;
+    int64_t want = ceil_div(256 * (p.stream ? bpc : 6), q_tiles);
+    const int64_t max_stripes = ceil_div(n_rows, (int64_t)(p.stream ? 1 : 4) * KNN_BN);
     if (want > max_stripes) want = max_stripes;
     if (want < 1) want = 1;
-    return (int)want;
+    p.stripes = (int)want;
+    p.stripe_rows = ceil_div(ceil_div(n_rows, p.stripes), KNN_BN) * KNN_BN;
+    return p;
 }
 
 }  // namespace rvc
@@ -312,7 +487,7 @@ extern "C" int rvc_knn_index_norms(const float *index_dev, int64_t n_rows, int d
 
 extern "C" int rvc_knn_workspace_bytes(int64_t n_rows, int64_t n_queries, int k, size_t *bytes) {
     if (!bytes || k != KNN_K || n_rows <= 0 || n_queries <= 0) return fail("rvc_knn_workspace_bytes: bad argument (k must be 8)");
-    const size_t slots = (size_t)knn_stripes(n_rows, n_queries) * KNN_SLOTS_PER_STRIPE;
+    const size_t slots = (size_t)knn_plan(n_rows, n_queries).n_slots();
     *bytes = align_up((size_t)n_queries * slots * KNN_K * sizeof(float), 256) +
              align_up((size_t)n_queries * slots * KNN_K * sizeof(int), 256);
     return 0;
@@ -330,16 +505,26 @@ extern "C" int rvc_knn_search(const float *index_dev, const float *norms_dev, in
     size_t need = 0;
     if (rvc_knn_workspace_bytes(n_rows, n_queries, k, &need)) return 1;
     if (workspace_bytes < need) return fail("rvc_knn_search: workspace too small (%zu < %zu)", workspace_bytes, need);
-    const int stripes = knn_stripes(n_rows, n_queries);
-    const int n_slots = stripes * KNN_SLOTS_PER_STRIPE;
-    int64_t stripe_rows = ceil_div(ceil_div(n_rows, stripes), KNN_BN) * KNN_BN;
+    const KnnPlan plan = knn_plan(n_rows, n_queries);
+    const int n_slots = plan.n_slots();
     float *part_d = (float *)workspace_dev;
     int *part_id = (int *)((char *)workspace_dev + align_up((size_t)n_queries * n_slots * KNN_K * sizeof(float), 256));
-    dim3 grid((unsigned)ceil_div(n_queries, KNN_BQ), (unsigned)stripes);
-    hipLaunchKernelGGL(knn_partial_kernel, grid, dim3(256), 0, (hipStream_t)stream, index_dev, norms_dev, n_rows, dim,
-                       queries_dev, n_queries, stripe_rows, part_d, part_id, n_slots);
+    dim3 grid((unsigned)ceil_div(n_queries, plan.q_tile), (unsigned)plan.stripes);
+    static const int pf = getenv("RVC_KNN_STREAM_PF") ? atoi(getenv("RVC_KNN_STREAM_PF")) : 3;
+    if (plan.stream && pf == 2)
+        hipLaunchKernelGGL(knn_stream_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, index_dev, norms_dev, n_rows, dim,
+                           queries_dev, n_queries, plan.stripe_rows, part_d, part_id, n_slots);
+    else if (plan.stream && pf == 4)
+        hipLaunchKernelGGL(knn_stream_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, index_dev, norms_dev, n_rows, dim,
+                           queries_dev, n_queries, plan.stripe_rows, part_d, part_id, n_slots);
+    else if (plan.stream)
+        hipLaunchKernelGGL(knn_stream_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, index_dev, norms_dev, n_rows, dim,
+                           queries_dev, n_queries, plan.stripe_rows, part_d, part_id, n_slots);
+    else
+        hipLaunchKernelGGL(knn_partial_kernel, grid, dim3(256), 0, (hipStream_t)stream, index_dev, norms_dev, n_rows, dim,
+                           queries_dev, n_queries, plan.stripe_rows, part_d, part_id, n_slots);
     RVC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)n_queries), dim3(64), 0, (hipStream_t)stream, part_d, part_id,
+    hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)n_queries), dim3(256), 0, (hipStream_t)stream, part_d, part_id,
                        n_slots, queries_dev, dim, out_d2_dev, out_ids_dev);
     RVC_LAUNCH_CHECK();
     return 0;

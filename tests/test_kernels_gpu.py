@@ -81,7 +81,9 @@ def test_knn_ids_and_distances(native, dev, n_rows, n_q):
         scale = (q[qi].astype(np.float64) ** 2).sum(1) + (big[ids[qi, ki]].astype(np.float64) ** 2).sum(1)
         assert np.all(np.abs(true_d - d2_ref[qi, ki]) <= 8 * 1.1920929e-07 * scale), "id mismatch that is not a near-tie"
     assert mism.mean() <= 0.01
-    assert np.allclose(d2, d2_ref, rtol=2e-4, atol=1e-4)  # ||x||^2 - 2q.x + ||q||^2 in fp32 (faiss' own form)
+    # ||x||^2 - 2q.x + ||q||^2 in fp32 (faiss' own form) cancels at the scale of the norms (~190 + 190 here): the absolute
+    # error is a few ulp of that sum whatever d2 is
+    assert np.allclose(d2, d2_ref, rtol=2e-4, atol=1e-3)
 
 
 def test_knn_golden_and_blend(native, dev):
