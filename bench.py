@@ -227,6 +227,33 @@ def main():
                     "mfma_frac": round(knn_flops / t_knn / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                     "avg_launch_ms": round(t_knn * 1e3, 4)}
 
+    # the kernel's HBM-bound regime: <= 32 queries (one MFMA column tile) against a cfg-5-sized index that cannot sit in
+    # the 256 MB Infinity Cache; algorithmic bytes = one pass over the index
+    roofline_knn_stream = None
+    try:
+        n_big = 2_000_000
+        big_idx = torch.empty(n_big, 768, device=dev)
+        for s0 in range(0, n_big, 250_000):
+            big_idx[s0:s0 + 250_000].normal_(0, 0.35)
+        big_norms = _native.knn_index_norms(big_idx)
+        q32 = big_idx[torch.randint(0, n_big, (32,), device=dev)] + 0.03 * torch.randn(32, 768, device=dev)
+        for _ in range(2):
+            _native.knn_search(big_idx, big_norms, q32)
+        e0.record()
+        for _ in range(5):
+            _native.knn_search(big_idx, big_norms, q32)
+        e1.record()
+        torch.cuda.synchronize()
+        t_s = e0.elapsed_time(e1) / 5 * 1e-3
+        sbytes = n_big * 768 * 4.0
+        roofline_knn_stream = {"kernel": "knn_stream_kernel<3> + knn_merge_kernel, 32 queries x 2 000 000 rows (6.1 GB index)",
+                               "bound": "hbm", "achieved": round(sbytes / t_s / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": round(sbytes / t_s / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                               "avg_search_ms": round(t_s * 1e3, 4)}
+        del big_idx, big_norms
+    except torch.OutOfMemoryError:
+        pass
+
     # ---- CPU baseline: the oracle on the host cores, bounded sample ----
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
@@ -269,6 +296,7 @@ def main():
                    "index_broadcast_s": round(t_bcast, 4)},
         "roofline": roofline,
         "roofline_knn": roofline_knn,
+        "roofline_knn_stream": roofline_knn_stream,
         "decoder": {"tflops_per_utterance": round(dflops / 1e12, 4), "ms": round(t_dec * 1e3, 2),
                     "achieved_tflops": round(dflops / t_dec / 1e12, 2),
                     "frac_of_fp32_peak": round(dflops / t_dec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},

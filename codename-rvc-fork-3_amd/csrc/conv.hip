@@ -22,8 +22,9 @@ constexpr int CONV_CH_ALIGN = 8;  // input channel counts must be multiples of t
 constexpr int CONV_MAX_DIL = 5;
 
 // CONV_CIC = input channels per staged chunk
-template <int KW, int MT, int NT, int WM, int WN, int CONV_CIC>
-__global__ void __launch_bounds__(WM *WN * 64)
+// UP: scatter-mode epilogue (polyphase ConvTranspose1d), see conv.h
+template <int KW, int MT, int NT, int WM, int WN, int CONV_CIC, bool UP>
+__global__ void __launch_bounds__(WM *WN * 64) __attribute__((amdgpu_waves_per_eu(MT == 1 ? 2 : 3, MT == 1 ? 2 : 3)))
 conv_mfma_kernel(const ConvParams p) {
     constexpr int BM = 32 * MT * WM;
     constexpr int BN = 32 * NT * WN;
@@ -65,13 +66,14 @@ conv_mfma_kernel(const ConvParams p) {
     const int dil = p.dil;
 
     float xr[XN];
-    float4 wr[WN4];
+    f32x4 wr[WN4];  // native vector, not HIP's float4 struct: struct copies become memcpys that keep the array in scratch
 
-    auto load_chunk = [&](int c) {
+    // Every global load below is unconditional (clamped address, value masked later): a load inside a divergent
+    // branch makes the compiler wait for it (s_waitcnt vmcnt(0)) before the branch closes, which serialised the
+    // five loads of a chunk -- ~100 us per launch on the 196 MB ResBlock tensors.  The activation is applied when
+    // the chunk is stored to LDS, one chunk period later, so nothing here depends on the loaded values.
+    auto chunk_src = [&](int c, const float *&src, int64_t &l_in, float &slope) __attribute__((always_inline)) {
         const int ci0 = c * CONV_CIC;
-        const float *src;
-        float slope;
-        int64_t l_in;
         if (ci0 < c1) {
             l_in = l_in1;
             src = px1 + (int64_t)ci0 * l_in;
@@ -81,42 +83,52 @@ conv_mfma_kernel(const ConvParams p) {
             src = px2 + (int64_t)(ci0 - c1) * l_in;
             slope = slope2;
         }
+    };
+    auto load_chunk = [&](int c) __attribute__((always_inline)) {
+        const int ci0 = c * CONV_CIC;
+        const float *src;
+        float slope;
+        int64_t l_in;
+        chunk_src(c, src, l_in, slope);
 #pragma unroll
         for (int i = 0; i < XN; ++i) {
-            const int idx = tid + i * NTH;
-            float v = 0.f;
-            if (idx < XTOT) {
-                const int ci = idx / XW;
-                const int cc = idx - ci * XW;
-                const int64_t t = col0 + cc - padl;
-                if (t >= 0 && t < l_in && !(p.debug & 1)) v = lrelu(src[(int64_t)ci * l_in + t], slope);
-            }
-            xr[i] = v;
+            int idx = tid + i * NTH;
+            if ((i + 1) * NTH > XTOT) idx = idx < XTOT ? idx : XTOT - 1;
+            const int ci = idx / XW;
+            const int cc = idx - ci * XW;
+            int64_t t = col0 + cc - padl;
+            t = t < 0 ? 0 : (t >= l_in ? l_in - 1 : t);
+            xr[i] = src[(int64_t)ci * l_in + t];
         }
 #pragma unroll
         for (int i = 0; i < WN4; ++i) {
-            const int idx4 = tid + i * NTH;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx4 < W4TOT) {
-                const int row = idx4 / (BM / 4);          // (tap, ci) row of BM floats
-                const int c4 = idx4 - row * (BM / 4);
-                const int tap = row / CONV_CIC;
-                const int ci = row - tap * CONV_CIC;
-                v = *reinterpret_cast<const float4 *>(pw + ((int64_t)tap * ctot + ci0 + ci) * m_total + m0 + c4 * 4);
-            }
-            wr[i] = v;  // unconditional: a partially-defined register array is demoted to scratch
+            int idx4 = tid + i * NTH;
+            if ((i + 1) * NTH > W4TOT) idx4 = idx4 < W4TOT ? idx4 : W4TOT - 1;
+            const int row = idx4 / (BM / 4);          // (tap, ci) row of BM floats
+            const int c4 = idx4 - row * (BM / 4);
+            const int tap = row / CONV_CIC;
+            const int ci = row - tap * CONV_CIC;
+            wr[i] = *reinterpret_cast<const f32x4 *>(pw + ((int64_t)tap * ctot + ci0 + ci) * m_total + m0 + c4 * 4);
         }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, int c) __attribute__((always_inline)) {
+        const float *src;
+        float slope;
+        int64_t l_in;
+        chunk_src(c, src, l_in, slope);
 #pragma unroll
         for (int i = 0; i < XN; ++i) {
             const int idx = tid + i * NTH;
-            if (idx < XTOT) xs[buf * XTOT + idx] = xr[i];
+            if (idx < XTOT) {
+                const int ci = idx / XW;
+                const int64_t t = col0 + (idx - ci * XW) - padl;
+                xs[buf * XTOT + idx] = (t >= 0 && t < l_in) ? lrelu(xr[i], slope) : 0.f;
+            }
         }
 #pragma unroll
         for (int i = 0; i < WN4; ++i) {
             const int idx4 = tid + i * NTH;
-            if (idx4 < W4TOT) *reinterpret_cast<float4 *>(&ws[buf * WTOT + idx4 * 4]) = wr[i];
+            if (idx4 < W4TOT) *reinterpret_cast<f32x4 *>(&ws[buf * WTOT + idx4 * 4]) = wr[i];
         }
     };
 
@@ -129,7 +141,7 @@ conv_mfma_kernel(const ConvParams p) {
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
     load_chunk(0);
-    store_chunk(0);
+    store_chunk(0, 0);
     if (n_chunks > 1) load_chunk(1);
     __syncthreads();
     for (int c = 0; c < n_chunks; ++c) {
@@ -153,7 +165,7 @@ conv_mfma_kernel(const ConvParams p) {
         }
         if (c + 1 < n_chunks) {
             // buffer buf^1 was last read during chunk c-1; every wave passed the barrier that ended it
-            store_chunk(buf ^ 1);
+            store_chunk(buf ^ 1, c + 1);
             if (c + 2 < n_chunks) load_chunk(c + 2);
             __syncthreads();
         }
@@ -162,62 +174,131 @@ conv_mfma_kernel(const ConvParams p) {
     // ---- epilogue --------------------------------------------------------------------------------------
     const float *bias = p.bias ? p.bias + (int64_t)b * p.bias_bstride : nullptr;
     float *y = p.y + (int64_t)b * p.y_bstride;
-    if (p.up_stride == 0) {
+    if constexpr (!UP) {
         const float *res = p.res ? p.res + (int64_t)b * p.y_bstride : nullptr;
         const float *accin = p.accin ? p.accin + (int64_t)b * p.y_bstride : nullptr;
-        // Two passes.  res/accin may alias y (the ResBlock updates its state in place), so a fused
-        // load-add-store loop would have to wait for every load before the next store (measured: ~110 us per block,
-        // 380 us per launch); gathering all addends into the accumulators first keeps 64 loads per lane in flight.
-        if ((res || accin) && !(p.debug & 4)) {
+        const int64_t n_cols = p.n_cols, l_out = p.l_out;
+        const float out_scale = p.out_scale;
+        const int row0 = m0 + wm * MT * 32;
+        // Element addresses as uniform base + 32-bit byte offset (launch_conv checks that one [C_out, L] slab stays
+        // below 4 GB): global_load/store take the base from SGPRs and one VGPR offset, so 64 loads in flight cost 64
+        // destination registers, not 64 + 128 for 64-bit addresses (that version ran at one wave per SIMD).
+        const int64_t cbase = col0 + wn * NT * 32 + l31;
+        const int64_t base = (int64_t)(row0 + 4 * half) * l_out + cbase;
+        const uint32_t base_b = (uint32_t)base * 4u;
+        const uint32_t lrow_b = (uint32_t)l_out * 4u;
+        auto boff = [&](int m, int r, int n) __attribute__((always_inline)) {
+            return base_b + (uint32_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * lrow_b + (uint32_t)(n * 128);
+        };
+        auto ld = [](const float *q, uint32_t byte_off) __attribute__((always_inline)) {
+            return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(q) + byte_off);
+        };
+        // reference order of the adds: (conv + bias) + residual, then the running sum of the parallel ResBlocks
+        if (bias) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * MT * 32 + m * 32 + mfma32_row(r, lane);
+                    const float bv = bias[row0 + m * 32 + mfma32_row(r, lane)];
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        const int64_t col = col0 + wn * NT * 32 + n * 32 + l31;
-                        if (col < p.n_cols) {
-                            const int64_t o = (int64_t)row * p.l_out + col;
-                            float add = 0.f;
-                            if (res) add = res[o];
-                            if (accin) add += accin[o];
-                            acc[m][n][r] += add;
-                        }
-                    }
+                    for (int n = 0; n < NT; ++n) acc[m][n][r] += bv;
                 }
         }
+        if (col0 + BN <= n_cols) {
+            // interior tile: no bounds checks, so the 64 loads per addend are issued back to back and stay in
+            // flight together (a load inside a divergent branch is waited for before the branch closes).
+            // res/accin may alias y (the ResBlock updates its state in place): all loads precede all stores.
+            if (!(p.debug & 4)) {
+                if (res) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+                    for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * MT * 32 + m * 32 + mfma32_row(r, lane);
-                const float bv = bias ? bias[row] : 0.f;
+                        for (int r = 0; r < 16; ++r)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const int64_t col = col0 + wn * NT * 32 + n * 32 + l31;
-                    if (col < p.n_cols && (!(p.debug & 2) || acc[m][n][r] == 12345.678f)) y[(int64_t)row * p.l_out + col] = (acc[m][n][r] + bv) * p.out_scale;
+                            for (int n = 0; n < NT; ++n) acc[m][n][r] += ld(res, boff(m, r, n));
+                }
+                if (accin) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+#pragma unroll
+                            for (int n = 0; n < NT; ++n) acc[m][n][r] += ld(accin, boff(m, r, n));
                 }
             }
+            if (!(p.debug & 2)) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            *reinterpret_cast<float *>(reinterpret_cast<char *>(y) + boff(m, r, n)) = acc[m][n][r] * out_scale;
+            } else {  // experiment knob: keep every accumulator live without storing the tile
+                float sum = 0.f;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sum += acc[m][n][r];
+                if (sum == 12345.678f) y[0] = sum;
+            }
+        } else {
+            // the last tile of a row: same arithmetic, per-element bounds checks (one block column per launch)
+            bool ok[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) ok[n] = cbase + n * 32 < n_cols;
+            if (res) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            if (ok[n]) acc[m][n][r] += ld(res, boff(m, r, n));
+            }
+            if (accin) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            if (ok[n]) acc[m][n][r] += ld(accin, boff(m, r, n));
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        if (ok[n]) *reinterpret_cast<float *>(reinterpret_cast<char *>(y) + boff(m, r, n)) = acc[m][n][r] * out_scale;
         }
     } else {
+        // polyphase ConvTranspose1d: GEMM row = (phase, channel); output time = col * stride + phase - pad
+        const int c_out = p.c_out, up_stride = p.up_stride, up_pad = p.up_pad;
+        const int64_t n_cols = p.n_cols, l_out = p.l_out;
+        const float out_scale = p.out_scale;
+        const int64_t cbase = col0 + wn * NT * 32 + l31;
+        const float *bsrc = bias ? bias : p.w;  // always a valid address: the loads below stay unconditional
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * MT * 32 + m * 32 + mfma32_row(r, lane);
-                const int phase = row / p.c_out;
-                const int co = row - phase * p.c_out;
-                const float bv = bias ? bias[co] : 0.f;
+                const int phase = row / c_out;
+                const int co = row - phase * c_out;
+                float bv = bsrc[co];
+                bv = bias ? bv : 0.f;
+                float *q = y + (int64_t)co * l_out + phase - up_pad;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    const int64_t col = col0 + wn * NT * 32 + n * 32 + l31;
-                    const int64_t t = col * p.up_stride + phase - p.up_pad;
-                    if (col < p.n_cols && t >= 0 && t < p.l_out)
-                        y[(int64_t)co * p.l_out + t] = (acc[m][n][r] + bv) * p.out_scale;
+                    const int64_t col = cbase + n * 32;
+                    const int64_t t = col * up_stride + phase - up_pad;
+                    if (col < n_cols && t >= 0 && t < l_out) q[col * up_stride] = (acc[m][n][r] + bv) * out_scale;
                 }
             }
-        }
     }
 }
 
@@ -226,7 +307,15 @@ static int launch_cfg(const ConvParams &p, hipStream_t stream) {
     constexpr int BM = 32 * MT * WM;
     constexpr int BN = 32 * NT * WN;
     dim3 grid((unsigned)ceil_div(p.n_cols, BN), (unsigned)(p.m_total / BM), (unsigned)p.batch);
-    hipLaunchKernelGGL((conv_mfma_kernel<KW, MT, NT, WM, WN, CIC>), grid, dim3(64 * WM * WN), 0, stream, p);
+    if (p.up_stride > 0) {
+        if constexpr (KW == 2) {
+            hipLaunchKernelGGL((conv_mfma_kernel<KW, MT, NT, WM, WN, CIC, true>), grid, dim3(64 * WM * WN), 0, stream, p);
+        } else {
+            return fail("conv: scatter mode is built for 2-tap (polyphase) kernels only, got %d taps", KW);
+        }
+    } else {
+        hipLaunchKernelGGL((conv_mfma_kernel<KW, MT, NT, WM, WN, CIC, false>), grid, dim3(64 * WM * WN), 0, stream, p);
+    }
     RVC_LAUNCH_CHECK();
     return 0;
 }
@@ -270,6 +359,9 @@ int launch_conv(const ConvParams &p_in, hipStream_t stream) {
         return fail("conv: input channels (%d + %d) must be multiples of %d", p.c1, p.c2, CONV_CH_ALIGN);
     if (p.dil < 1 || p.dil > CONV_MAX_DIL) return fail("conv: dilation %d out of range 1..%d", p.dil, CONV_MAX_DIL);
     if (p.n_cols <= 0 || p.batch <= 0) return 0;
+    if (p.up_stride == 0 && (int64_t)p.m_total * p.l_out >= ((int64_t)1 << 30))
+        return fail("conv: one output slab of %d x %lld floats exceeds the 4 GB the epilogue addresses", p.m_total,
+                    (long long)p.l_out);
     switch (p.kw) {
         case 1: return launch_kw<1>(p, stream);
         case 2: return launch_kw<2>(p, stream);

@@ -57,41 +57,64 @@ resblock_layer_kernel(const float *__restrict__ x, const float *__restrict__ w1,
     const float *xb = x + b * C * L;
     const int64_t x_time0 = t0 - H2 - h1;                 // time of xs[.][0]
 
-    // ---- stage the whole input tile (every load in flight at once) ----
-    for (int idx = tid; idx < C * XW; idx += 256) {
-        const int ci = idx / XW, v = idx - ci * XW;
-        const int64_t t = x_time0 + v;
-        xs[idx] = (t >= 0 && t < L) ? xb[(int64_t)ci * L + t] : 0.f;
+    // ---- stage the input tile: wave w takes rows w, w+4, ...; lanes run along time (256 B per load instruction) ----
+    // Loads are unconditional (clamped address, masked at the LDS store) and issued RB rows at a time, so RB * CJ of
+    // them are in flight per lane; a load inside a divergent branch would be waited for before the branch closes.
+    {
+        constexpr int RPW = C / 4;                 // rows per wave
+        constexpr int CJ = (XW + 63) / 64;         // 64-column pieces per row
+        constexpr int RB = 8;
+        static_assert(RPW % RB == 0, "row batches");
+        const int xw_need = N1 + (KW - 1) * dil;   // columns the two convs and the residual actually read
+#pragma unroll 1
+        for (int rb = 0; rb < RPW; rb += RB) {
+            float v[RB][CJ];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const float *rowp = xb + (int64_t)(wave + 4 * (rb + r)) * L;
+#pragma unroll
+                for (int j = 0; j < CJ; ++j) {
+                    int64_t t = x_time0 + lane + 64 * j;
+                    t = t < 0 ? 0 : (t >= L ? L - 1 : t);
+                    v[r][j] = rowp[t];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int j = 0; j < CJ; ++j) {
+                    const int col = lane + 64 * j;
+                    const int64_t t = x_time0 + col;
+                    if (col < xw_need) xs[(wave + 4 * (rb + r)) * XW + col] = (t >= 0 && t < L) ? v[r][j] : 0.f;
+                }
+        }
     }
     for (int idx = tid; idx < C * (KW - 1); idx += 256) {  // tail columns of ts read by the wasted conv2 columns
         const int ci = idx / (KW - 1), u = N1 + idx - ci * (KW - 1);
         ts[ci * TW + u] = 0.f;
     }
 
-    float4 wr[WN4];
-    auto load_w = [&](const float *w, int c) {
+    f32x4 wr[WN4];  // native vector type: copies of HIP's float4 struct become memcpys that pin the array in scratch
+    auto load_w = [&](const float *w, int c) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < WN4; ++i) {
-            const int idx4 = tid + i * 256;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx4 < W4) {
-                const int row = idx4 / (C / 4), c4 = idx4 - row * (C / 4);   // row = tap * CIC + ci
-                const int tap = row / CIC, ci = row - tap * CIC;
-                v = *reinterpret_cast<const float4 *>(w + ((int64_t)tap * C + c * CIC + ci) * C + c4 * 4);
-            }
-            wr[i] = v;
+            int idx4 = tid + i * 256;
+            if ((i + 1) * 256 > W4) idx4 = idx4 < W4 ? idx4 : W4 - 1;
+            const int row = idx4 / (C / 4), c4 = idx4 - row * (C / 4);   // row = tap * CIC + ci
+            const int tap = row / CIC, ci = row - tap * CIC;
+            wr[i] = *reinterpret_cast<const f32x4 *>(w + ((int64_t)tap * C + c * CIC + ci) * C + c4 * 4);
         }
     };
-    auto store_w = [&](int buf) {
+    auto store_w = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < WN4; ++i) {
             const int idx4 = tid + i * 256;
-            if (idx4 < W4) *reinterpret_cast<float4 *>(&ws[buf * WSLAB + idx4 * 4]) = wr[i];
+            if (idx4 < W4) *reinterpret_cast<f32x4 *>(&ws[buf * WSLAB + idx4 * 4]) = wr[i];
         }
     };
 
     f32x16 acc[MT][NT];
-    auto zero_acc = [&]() {
+    auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -100,7 +123,7 @@ resblock_layer_kernel(const float *__restrict__ x, const float *__restrict__ w1,
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
     };
     // one conv as NCH weight slabs; B fragments come from `src` (row stride `sw`), tap offset `td`, leaky on read
-    auto run_conv = [&](const float *w, const float *src, int sw, int td, bool act) {
+    auto run_conv = [&](const float *w, const float *src, int sw, int td, bool act) __attribute__((always_inline)) {
         zero_acc();
         load_w(w, 0);
         store_w(0);
@@ -158,6 +181,7 @@ resblock_layer_kernel(const float *__restrict__ x, const float *__restrict__ w1,
     run_conv(w2, ts, TW, 1, false);
     float *yb = y + b * C * L;
     const float *ab = accin ? accin + b * C * L : nullptr;
+    // (conv2 + bias) + x, the residual read back from the staged raw tile
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -165,16 +189,41 @@ resblock_layer_kernel(const float *__restrict__ x, const float *__restrict__ w1,
             const int row = row0 + m * 32 + mfma32_row(r, lane);
             const float bv = b2[row];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const int j = colw + n * 32 + l31;
-                const int64_t t = t0 + j;
-                if (j < BN && t < L) {
-                    float v = acc[m][n][r] + bv + xs[row * XW + j + H2 + h1];
-                    if (ab) v += ab[(int64_t)row * L + t];
-                    yb[(int64_t)row * L + t] = v * out_scale;
-                }
-            }
+            for (int n = 0; n < NT; ++n)
+                acc[m][n][r] = acc[m][n][r] + bv + xs[row * XW + colw + n * 32 + l31 + H2 + h1];
         }
+    // uniform base + 32-bit byte offsets (launch checks C * L < 2^30), see conv.hip's epilogue
+    const uint32_t lrow_b = (uint32_t)L * 4u;
+    bool ok[NT];
+    uint32_t cb[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int j = colw + n * 32 + l31;
+        ok[n] = j < BN && t0 + j < L;
+        // clamped column: loads of masked-off lanes stay inside the row, so they can be unconditional
+        int64_t tc = t0 + (j < BN ? j : BN - 1);
+        tc = tc < L ? tc : L - 1;
+        cb[n] = (uint32_t)tc * 4u;
+    }
+    auto boff = [&](int m, int r, int n) __attribute__((always_inline)) {
+        return (uint32_t)(row0 + 4 * half + m * 32 + (r & 3) + 8 * (r >> 2)) * lrow_b + cb[n];
+    };
+    if (ab) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n][r] += *reinterpret_cast<const float *>(reinterpret_cast<const char *>(ab) + boff(m, r, n));
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                if (ok[n]) *reinterpret_cast<float *>(reinterpret_cast<char *>(yb) + boff(m, r, n)) = acc[m][n][r] * out_scale;
 }
 
 template <int KW, int C, int N1, int WM>
@@ -208,6 +257,7 @@ int launch_resblock_layer(const float *x, const float *w1, const float *b1, cons
                           float *y, int batch, int c, int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream) {
     if (x == y) return fail("resblock_layer: in-place operation is not supported");
     if (dil < 1 || dil > 5) return fail("resblock_layer: dilation %d out of range", dil);
+    if ((int64_t)c * L >= ((int64_t)1 << 30)) return fail("resblock_layer: a %d x %lld slab exceeds the 4 GB the kernel addresses", c, (long long)L);
     static const int wide64 = getenv("RVC_FUSED_C64_WIDE") ? atoi(getenv("RVC_FUSED_C64_WIDE")) : 0;
 #define RVC_FUSED_CASE(KW, CC, NN, WMM) if (k == KW && c == CC) return launch_fused<KW, CC, NN, WMM>(x, w1, b1, w2, b2, accin, y, batch, L, dil, slope, out_scale, stream)
     RVC_FUSED_CASE(3, 32, 128, 1); RVC_FUSED_CASE(7, 32, 128, 1); RVC_FUSED_CASE(11, 32, 128, 1);

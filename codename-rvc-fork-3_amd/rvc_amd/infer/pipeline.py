@@ -86,6 +86,7 @@ class Pipeline:
         self._index_cache = {}
         self._preset_index = None
         self._f0_stream = None
+        self._coarse_thr = None
 
     # ---- additions -------------------------------------------------------------------------------------
     def load_rmvpe_state_dict(self, sd):
@@ -139,6 +140,37 @@ class Pipeline:
         f0_mel[f0_mel > 255] = 255
         return np.rint(f0_mel).astype(int), f0bak
 
+    def _coarse_thresholds(self) -> np.ndarray:
+        """thr[b-2] = the smallest float64 f0 that `_postprocess_f0` maps to coarse bin >= b (b = 2..255).
+
+        The quantiser (pipeline.py:402-408) is a monotone step function of f0, so its 254 step positions pin it
+        completely: they are located once on the host by bisection over the float64 bit patterns with the very
+        NumPy expression the reference evaluates, and the device then only compares (no device log involved)."""
+        def coarse(f0):
+            f0_mel = 1127 * np.log(1 + f0 / 700)
+            f0_mel[f0_mel > 0] = (f0_mel[f0_mel > 0] - self.f0_mel_min) * 254 / (self.f0_mel_max - self.f0_mel_min) + 1
+            f0_mel[f0_mel <= 1] = 1
+            f0_mel[f0_mel > 255] = 255
+            return np.rint(f0_mel).astype(np.int64)
+
+        want = np.arange(2, 256, dtype=np.int64)
+        lo = np.zeros(254, dtype=np.int64)                                  # bits of 0.0   -> bin 1
+        hi = np.full(254, np.float64(1e6).view(np.int64), dtype=np.int64)   # bits of 1e6   -> bin 255
+        while np.any(hi - lo > 1):
+            mid = lo + (hi - lo) // 2
+            ge = coarse(mid.view(np.float64).copy()) >= want
+            hi, lo = np.where(ge, mid, hi), np.where(ge, lo, mid)
+        return hi.view(np.float64)
+
+    def _postprocess_f0_device(self, f0, pitch):
+        """`_postprocess_f0` without leaving HBM (no f0 file, no autotune): same key shift (one float64 multiply) and
+        the same coarse integers, read off the threshold table instead of re-evaluating log on the device."""
+        if self._coarse_thr is None:
+            self._coarse_thr = torch.from_numpy(self._coarse_thresholds()).to(self.device)
+        f0 = f0 * pow(2, pitch / 12)
+        coarse = torch.searchsorted(self._coarse_thr, f0, right=True) + 1
+        return coarse, f0
+
     # ---- per-segment conversion -------------------------------------------------------------------------
     def _extract_features(self, model, audio0, index, big_npy, index_rate, version):
         """pipeline.py:445-465: HuBERT features, retrieval blend, x2 nearest upsampling (pitch-independent half)."""
@@ -163,13 +195,14 @@ class Pipeline:
         pitch, pitchf = pitch[:, :p_len], pitchf[:, :p_len]
         if protect < 0.5:  # pipeline.py:474-481
             feats0 = F.interpolate(feats0.permute(0, 2, 1), scale_factor=2).permute(0, 2, 1)
-            pitchff = pitchf.clone()
-            pitchff[pitchf > 0] = 1
-            pitchff[pitchf < 1] = protect
+            # pitchff[pitchf > 0] = 1; pitchff[pitchf < 1] = protect -- as selects (boolean-mask stores sync the host)
+            pitchff = torch.where(pitchf < 1, torch.full_like(pitchf, protect),
+                                  torch.where(pitchf > 0, torch.ones_like(pitchf), pitchf))
             feats = feats * pitchff.unsqueeze(-1) + feats0 * (1 - pitchff.unsqueeze(-1))
             feats = feats.to(feats0.dtype)
-        p_len_t = torch.tensor([p_len], device=self.device).long()
-        return net_g.infer(feats.float(), p_len_t, pitch, pitchf.float(), sid, noise=noise)[0][0, 0]
+        p_len_t = torch.full((1,), p_len, device=self.device, dtype=torch.long)
+        return net_g.infer(feats.float(), p_len_t, pitch, pitchf.float(), sid, noise=noise,
+                           phone_lengths_host=[p_len])[0][0, 0]
 
     def voice_conversion(self, model, net_g, sid, audio0, pitch, pitchf, index, big_npy, index_rate, version, protect,
                          noise=None, as_tensor=False):
@@ -245,7 +278,7 @@ class Pipeline:
                 inp_f0 = np.array([[float(i) for i in line.split(",")] for line in lines], dtype="float32")
             except Exception as error:
                 print(f"An error occurred reading the F0 file: {error}")
-        sid = torch.tensor(sid, device=self.device).unsqueeze(0).long()
+        sid = torch.full((1,), int(sid), device=self.device, dtype=torch.long)  # a fill, not a blocking H2D copy
         audio_dev = audio_pad.float()  # segments are views of it
 
         noise = None
@@ -270,17 +303,28 @@ class Pipeline:
             side = self._f0_stream
             side.wait_stream(main)
             audio_dev.record_stream(side)
-            with torch.cuda.stream(side):
-                f0_dev = self.model_rmvpe.infer_from_audio_device(audio_dev, thred=0.03)
-            feats_list = [self._extract_features(model, audio_dev[a], index, big_npy, index_rate, version) for a, _ in plan]
-            with torch.cuda.stream(side):
-                f0_host = f0_dev.cpu().numpy()  # waits for the side stream only
             if f0_method != "rmvpe":
                 raise NotImplementedError(f"f0_method={f0_method!r}: only 'rmvpe' is implemented")
-            pitch, pitchf = self._postprocess_f0(f0_host, pitch, f0_autotune, inp_f0)
-            pitch, pitchf = pitch[:p_len], pitchf[:p_len]
-            pitch = torch.tensor(pitch, device=self.device).unsqueeze(0).long()
-            pitchf = torch.tensor(pitchf, device=self.device).unsqueeze(0).float()
+            with torch.cuda.stream(side):
+                f0_dev = self.model_rmvpe.infer_from_audio_device(audio_dev, thred=0.03)
+                if inp_f0 is None and f0_autotune is not True:
+                    # the contour never leaves HBM and the host never waits for it: everything below is enqueued
+                    # while the GPU is still busy with HuBERT
+                    pitch, pitchf = self._postprocess_f0_device(f0_dev, pitch)
+                    pitch = pitch[:p_len].unsqueeze(0)
+                    pitchf = pitchf[:p_len].unsqueeze(0).float()
+            feats_list = [self._extract_features(model, audio_dev[a], index, big_npy, index_rate, version) for a, _ in plan]
+            if inp_f0 is None and f0_autotune is not True:
+                main.wait_stream(side)
+                pitch.record_stream(main)
+                pitchf.record_stream(main)
+            else:  # f0-file override: the reference's host code, on the host
+                with torch.cuda.stream(side):
+                    f0_host = f0_dev.cpu().numpy()  # waits for the side stream only
+                pitch, pitchf = self._postprocess_f0(f0_host, pitch, f0_autotune, inp_f0)
+                pitch, pitchf = pitch[:p_len], pitchf[:p_len]
+                pitch = torch.tensor(pitch, device=self.device).unsqueeze(0).long()
+                pitchf = torch.tensor(pitchf, device=self.device).unsqueeze(0).float()
             for (feats, feats0, n_audio), (_, ps) in zip(feats_list, plan):
                 if noise_seed is not None:
                     for _ in range(12):  # transformers' HuBERT LayerDrop draws, made per segment before the synthesizer's

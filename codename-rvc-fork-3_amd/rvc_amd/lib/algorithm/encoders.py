@@ -56,7 +56,8 @@ def rel_attention(x, w: Dict[str, torch.Tensor], p: str, n_heads: int, attn_mask
 
 
 def text_encoder(w: Dict[str, torch.Tensor], phone, pitch, lengths, *, hidden=192, out_channels=192, n_heads=2,
-                 n_layers=6, kernel_size=3):
+                 n_layers=6, kernel_size=3, lengths_host=None):
+    """``lengths_host``: the same lengths as Python ints when the caller has them (saves a device->host read)."""
     x = F.linear(phone, w["enc_p.emb_phone.weight"], w["enc_p.emb_phone.bias"])
     if pitch is not None:
         x = x + F.embedding(pitch, w["enc_p.emb_pitch.weight"])
@@ -64,7 +65,7 @@ def text_encoder(w: Dict[str, torch.Tensor], phone, pitch, lengths, *, hidden=19
     x = x.transpose(1, -1)
     t = x.size(2)
     x_mask = (torch.arange(t, device=x.device)[None, :] < lengths[:, None]).unsqueeze(1).to(x.dtype)
-    full = bool((lengths == t).all())
+    full = all(int(n) == t for n in lengths_host) if lengths_host is not None else bool((lengths == t).all())
     attn_mask = None if full else x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
     pad = (kernel_size - 1) // 2
     x = x * x_mask

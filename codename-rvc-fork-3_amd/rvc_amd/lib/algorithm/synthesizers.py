@@ -129,14 +129,16 @@ class Synthesizer:
         return out
 
     @torch.no_grad()
-    def infer(self, phone, phone_lengths, pitch=None, nsff0=None, sid=None, rate=None, noise=None):
+    def infer(self, phone, phone_lengths, pitch=None, nsff0=None, sid=None, rate=None, noise=None, *,
+              phone_lengths_host=None):
         if self.dec is None:
             raise RuntimeError("Synthesizer.infer before load_state_dict(...).to('cuda:N')")
         w = self.w
         g = F.embedding(sid, w["emb_g.weight"]).unsqueeze(-1)
         m_p, logs_p, x_mask = text_encoder(w, phone, pitch, phone_lengths, hidden=self.hidden_channels,
                                            out_channels=self.inter_channels, n_heads=self.n_heads,
-                                           n_layers=self.n_layers, kernel_size=self.kernel_size)
+                                           n_layers=self.n_layers, kernel_size=self.kernel_size,
+                                           lengths_host=phone_lengths_host)
         b, _, t = m_p.shape
         nz = self._draw(noise, b, t)
         z_p = (m_p + torch.exp(logs_p) * nz["z"] * 0.66666) * x_mask

@@ -60,6 +60,26 @@ def test_f0_postprocess_bit_exact_vs_reference_golden():
         assert np.array_equal(f0bak, g[f"f0bak_{shift}"])
 
 
+def test_f0_postprocess_device_table_equals_host_formula():
+    """The HBM-resident quantiser (threshold table + searchsorted) against the reference's NumPy expression: on the
+    golden contours, on random contours, and on both sides of every one of the 254 step positions."""
+    import torch
+    g = load_golden("f0_coarse")
+    p = _pipeline_cpu()
+    p.device, p._coarse_thr = "cpu", None
+    thr = p._coarse_thresholds()
+    assert thr.shape == (254,) and np.all(np.diff(thr) > 0)
+    rng = np.random.default_rng(0)
+    edge = np.concatenate([thr, np.nextafter(thr, -np.inf), np.nextafter(thr, np.inf)])
+    cases = [g["f0"], np.concatenate([[0.0, 1e-300, 49.9, 1100.0, 5000.0], rng.uniform(0, 1500, 20000), edge])]
+    for f0 in cases:
+        for shift in (0, 5, -7):
+            want_c, want_f = p._postprocess_f0(f0.copy(), shift)
+            got_c, got_f = p._postprocess_f0_device(torch.from_numpy(f0.copy()), shift)
+            assert np.array_equal(got_c.numpy(), want_c.astype(np.int64))
+            assert np.array_equal(got_f.numpy(), want_f)
+
+
 def test_f0_file_override():
     p = _pipeline_cpu()
     f0 = np.full(400, 100.0)

@@ -8,7 +8,9 @@ from rvc_amd import _native
 dev = "cuda:0"
 tot = 0.0
 print("env", {k: v for k, v in os.environ.items() if k.startswith("RVC_")})
+only = int(os.environ.get("BENCH_C", "0"))
 for C, L in ((256, 38376), (128, 383760), (64, 767520), (32, 1535040)):
+    if only and C != only: continue
     x = torch.randn(1, C, L, device=dev); res = torch.randn(1, C, L, device=dev); bias = torch.zeros(C, device=dev)
     for K in (3, 7, 11):
         w = _native.conv1d_pack_weight(torch.randn(C, C, K) * 0.03, dev)
