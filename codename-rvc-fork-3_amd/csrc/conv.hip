@@ -345,7 +345,14 @@ static int launch_kw(const ConvParams &p, hipStream_t stream) {
     int cic = KW >= 7 ? 4 : 8;
     if (cic_env) cic = cic_env;
     if ((p.c1 % cic) || (p.c2 % cic)) cic = 8;
-    if (p.m_total % 128 == 0) return launch_cic<KW, 2, 2, 2, 2>(p, stream, cic);   // 128 x 128
+    if (p.m_total % 128 == 0) {
+        // few 128 x 128 tiles (the 38k-column first vocoder stage: 600 tiles over 768 block slots, 3 on some CUs and 2
+        // on the others) -> halve the tile width so the CUs finish together
+        static const int narrow_env = env_int("RVC_CONV_NARROW", 1);
+        const int64_t tiles = ceil_div(p.n_cols, 128) * (p.m_total / 128) * p.batch;
+        if (narrow_env && tiles < 1536) return launch_cic<KW, 2, 1, 2, 2>(p, stream, cic);   // 128 x 64
+        return launch_cic<KW, 2, 2, 2, 2>(p, stream, cic);                                   // 128 x 128
+    }
     if (p.m_total % 64 == 0) return launch_cic<KW, 2, 2, 1, 4>(p, stream, cic);    //  64 x 256
     if (p.m_total % 32 == 0) return launch_cic<KW, 1, 4, 1, 4>(p, stream, cic);    //  32 x 512
     return fail("conv: GEMM rows (%d) must be a multiple of 32", p.m_total);

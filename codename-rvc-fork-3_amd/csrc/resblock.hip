@@ -247,9 +247,10 @@ static int launch_fused(const float *x, const float *w1, const float *b1, const 
 
 bool resblock_layer_supported(int c, int k) {
     static const int off = getenv("RVC_NO_FUSED_RESBLOCK") ? atoi(getenv("RVC_NO_FUSED_RESBLOCK")) : 0;
-    // measured on MI355X (profiles/r01_decoder_kernels.txt): fused beats two launches for every k at C = 32 (-0.2..-0.28 ms per
-    // layer) and for k = 3 at C = 64; the 7/11-tap layers at C = 64 are MFMA-bound and lose to the wider unfused tiles
-    return !off && ((c == 32 && (k == 3 || k == 7 || k == 11)) || (c == 64 && k == 3));
+    // measured on MI355X (profiles/r01_decoder_kernels.txt): fused beats two launches for every k at C = 32 (238 vs 2 x 187 us at
+    // k = 3, 453 vs 2 x 272 at k = 7, 676 vs 2 x 356 at k = 11); at C = 64 the wider unfused tiles win (k = 3: 464 vs 2 x 211 us)
+    static const int c64 = getenv("RVC_FUSED_C64") ? atoi(getenv("RVC_FUSED_C64")) : 0;
+    return !off && ((c == 32 && (k == 3 || k == 7 || k == 11)) || (c64 && c == 64 && k == 3));
 }
 
 // x, y: [batch][c][L] (must NOT alias: blocks read their neighbours' columns); w1/w2 packed [k][c][c]
