@@ -327,6 +327,161 @@ knn_stream_kernel(const float *__restrict__ index, const float *__restrict__ nor
     }
 }
 
+// ---- streaming kernel, second form: operands straight from HBM into the MFMA, no LDS staging, no barriers ----------
+// For <= 32 queries the search is one pass over the index and is bound by how fast a CU can pull rows out of HBM
+// while keeping its matrix cores fed (16 flop per index byte at 32 queries: 6.3 TB/s needs ~100 TFLOP/s of fp32
+// MFMA).  The LDS-staged form above spends two block barriers per 16 KB chunk and tops out at ~4.2 TB/s.  Here:
+//   * the 32 (zero-padded) queries sit in LDS once per block, rows padded to dim + 4 floats so that the
+//     ds_read_b128 fragment reads are conflict-free;
+//   * every wave owns whole 32-row tiles and feeds the MFMA "A" operand directly from its global loads.  The dot
+//     product does not care in which order k is walked as long as both operands agree, so a lane (row i, half h)
+//     takes the 64 contiguous bytes [32 j + 16 h, +16) floats of its row per 128-byte line group j -- four dwordx4
+//     loads -- and the k-pair of MFMA (t, e) is (32 j + 4 t + e, 32 j + 16 + 4 t + e); the query fragment is the
+//     same 16 floats of the query row, one ds_read_b128 per four MFMAs;
+//   * KND_NB line groups (12 dwordx4 per lane) are kept in flight per wave; waves never synchronise until the end.
+constexpr int KND_BQ = 32;
+
+template <int NW, int KND_NB>
+__global__ void __launch_bounds__(NW * 64)
+knn_direct_kernel(const float *__restrict__ index, const float *__restrict__ norms, int64_t n_rows, int dim,
+                  const float *__restrict__ queries, int64_t n_queries, int64_t stripe_rows, float *__restrict__ part_d,
+                  int *__restrict__ part_id, int n_slots) {
+    extern __shared__ __attribute__((aligned(16))) float knd_smem[];
+    float *qs = knd_smem;                    // [32][dim + 4]
+    const int qstride = dim + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int64_t q0 = (int64_t)blockIdx.x * KND_BQ;
+    const int d4 = dim / 4;
+    for (int idx = tid; idx < KND_BQ * d4; idx += NW * 64) {
+        const int q = idx / d4, c4 = idx - q * d4;
+        const int64_t qq = q0 + q < n_queries ? q0 + q : n_queries - 1;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(queries + qq * dim + c4 * 4);
+        if (q0 + q >= n_queries) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4 *>(qs + q * qstride + c4 * 4) = v;
+    }
+    __syncthreads();
+
+    const int64_t stripe_begin = (int64_t)blockIdx.y * stripe_rows;
+    const int64_t stripe_end = min(n_rows, stripe_begin + stripe_rows);
+    const int n_tiles = stripe_end > stripe_begin ? (int)((stripe_end - stripe_begin + 31) / 32) : 0;
+    const int n_my = wave < n_tiles ? (n_tiles - wave + NW - 1) / NW : 0;   // tiles wave, wave + NW, ...
+    const int lgpr = dim / 32;                                               // line groups per row
+    const int n_groups = n_my * lgpr;
+    const float *qb = qs + l31 * qstride + half * 16;
+
+    TopK best;
+    best.init();
+    f32x4 buf[KND_NB][4];
+    f32x4 xn[4];
+    // issue side: (tile, line group) of the next load
+    int it = 0, ij = 0;
+    const float *irow = nullptr;
+    auto tile_row = [&](int t) __attribute__((always_inline)) {
+        int64_t n = stripe_begin + (int64_t)(wave + t * NW) * 32 + l31;
+        n = n < n_rows ? n : n_rows - 1;
+        return index + n * dim + half * 16;
+    };
+    auto issue = [&](int slot) __attribute__((always_inline)) {
+        if (ij == 0) irow = tile_row(it);
+        const float *p = irow + ij * 32;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) buf[slot][t] = *reinterpret_cast<const f32x4 *>(p + 4 * t);
+        if (++ij == lgpr) { ij = 0; ++it; }
+    };
+    auto load_norms = [&](int t) __attribute__((always_inline)) {
+        const int64_t n_base = stripe_begin + (int64_t)(wave + t * NW) * 32;
+        if (n_base + 32 <= stripe_end) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xn[g] = *reinterpret_cast<const f32x4 *>(norms + n_base + 8 * g + 4 * half);
+        } else {   // the stripe's last, partial tile: rows past the end can never be selected
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int64_t n = n_base + 8 * g + 4 * half + e;
+                    xn[g][e] = n < stripe_end ? norms[n] : INFINITY;
+                }
+        }
+    };
+
+#pragma unroll
+    for (int s = 0; s < KND_NB; ++s)
+        if (s < n_groups) issue(s);
+    if (n_groups > 0) load_norms(0);
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    int cj = 0, ct = 0;   // consume side
+    for (int g0 = 0; g0 < n_groups; g0 += KND_NB) {
+#pragma unroll
+        for (int s = 0; s < KND_NB; ++s) {
+            const int g = g0 + s;
+            if (g < n_groups) {   // wave-uniform
+                f32x4 b[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const f32x4 *>(qb + cj * 32 + 4 * t);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = mfma32(buf[s][t][e], b[t][e], acc);
+                if (g + KND_NB < n_groups) issue(s);
+                if (++cj == lgpr) {
+                    const int n_base = (int)(stripe_begin + (int64_t)(wave + ct * NW) * 32);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        best.insert(fmaf(-2.f, acc[r], xn[r >> 2][r & 3]), n_base + mfma32_row(r, lane));
+                        acc[r] = 0.f;
+                    }
+                    cj = 0;
+                    ++ct;
+                    if (ct < n_my) load_norms(ct);
+                }
+            }
+        }
+    }
+
+    // merge the block's 2 NW (wave, lane-half) lists per query in LDS -> ONE sorted list per (query, stripe)
+    __syncthreads();
+    constexpr int NC = 2 * NW * KNN_K;           // candidates per query
+    float *md = qs;                              // [32][NC]   (dim >= 256: the query tile is at least this large)
+    int *mi = reinterpret_cast<int *>(qs + KND_BQ * NC);
+#pragma unroll
+    for (int i = 0; i < KNN_K; ++i) {
+        md[l31 * NC + (wave * 2 + half) * KNN_K + i] = best.d[i];
+        mi[l31 * NC + (wave * 2 + half) * KNN_K + i] = best.id[i];
+    }
+    __syncthreads();
+    if (tid < KND_BQ) {
+        TopK m;
+        m.init();
+        for (int c = 0; c < NC; ++c) {
+            const float v = md[tid * NC + c];
+            const int n = mi[tid * NC + c];
+            if (n < 0) continue;
+            if (v < m.d[KNN_K - 1] || (v == m.d[KNN_K - 1] && (unsigned)n < (unsigned)m.id[KNN_K - 1])) {
+#pragma unroll
+                for (int p = KNN_K - 1; p >= 1; --p) {
+                    const bool shift = v < m.d[p - 1] || (v == m.d[p - 1] && (unsigned)n < (unsigned)m.id[p - 1]);
+                    const bool here = v < m.d[p] || (v == m.d[p] && (unsigned)n < (unsigned)m.id[p]);
+                    const float nd = shift ? m.d[p - 1] : (here ? v : m.d[p]);
+                    const int ni = shift ? m.id[p - 1] : (here ? n : m.id[p]);
+                    m.d[p] = nd;
+                    m.id[p] = ni;
+                }
+                if (v < m.d[0] || (v == m.d[0] && (unsigned)n < (unsigned)m.id[0])) { m.d[0] = v; m.id[0] = n; }
+            }
+        }
+        const int64_t q = q0 + tid;
+        if (q < n_queries) {
+            float *pd = part_d + (q * n_slots + blockIdx.y) * KNN_K;
+            int *pi = part_id + (q * n_slots + blockIdx.y) * KNN_K;
+#pragma unroll
+            for (int i = 0; i < KNN_K; ++i) { pd[i] = m.d[i]; pi[i] = m.id[i]; }
+        }
+    }
+}
+
 __device__ __forceinline__ bool cand_less(float da, int ia, float db, int ib) {
     return (da < db) || (da == db && (unsigned)ia < (unsigned)ib);
 }
@@ -446,14 +601,18 @@ knn_blend_kernel(const float *__restrict__ index, int dim, const float *__restri
 
 constexpr int64_t KNN_STREAM_MAX_Q = 64;   // at most two 32-query column tiles take the streaming kernel
 
+constexpr int KND_WAVES = 8;
+static size_t knd_lds_bytes(int dim) { return (size_t)KND_BQ * (dim + 4) * sizeof(float); }
+
 struct KnnPlan {
     bool stream;
+    bool direct = false;   // streaming regime, second form (knn_direct_kernel)
     int stripes, slots_per_stripe, q_tile;
     int64_t stripe_rows;
     int n_slots() const { return stripes * slots_per_stripe; }
 };
 
-static KnnPlan knn_plan(int64_t n_rows, int64_t n_queries) {
+static KnnPlan knn_plan(int64_t n_rows, int64_t n_queries, int dim = 768) {
     static const int force_batch = getenv("RVC_KNN_NO_STREAM") ? atoi(getenv("RVC_KNN_NO_STREAM")) : 0;
     KnnPlan p;
     p.stream = n_queries <= KNN_STREAM_MAX_Q && !force_batch;
@@ -462,13 +621,20 @@ static KnnPlan knn_plan(int64_t n_rows, int64_t n_queries) {
     const int64_t q_tiles = ceil_div(n_queries, p.q_tile);
     // batch kernel: >= 6 blocks per CU, stripes of >= 4 row tiles; streaming kernel: 2 blocks per CU (longer stripes
     // amortise the per-block prologue and merge: 4.0 TB/s vs 3.4 TB/s at 8 per CU on a 2 M-row index)
-    static const int bpc = getenv("RVC_KNN_STREAM_BPC") ? atoi(getenv("RVC_KNN_STREAM_BPC")) : 2;
+    static const int bpc_env = getenv("RVC_KNN_STREAM_BPC") ? atoi(getenv("RVC_KNN_STREAM_BPC")) : 0;
+    static const int old_stream = getenv("RVC_KNN_STREAM_OLD") ? atoi(getenv("RVC_KNN_STREAM_OLD")) : 0;
+    p.direct = p.stream && !old_stream && dim >= 256 && dim % 32 == 0;
+    // direct form: the query tile's LDS footprint decides how many blocks share a CU (1 at dim 768, 4 at dim 256)
+    int bpc = p.direct ? (int)((size_t)(160 * 1024) / knd_lds_bytes(dim)) : 2;
+    if (bpc > 4) bpc = 4;
+    if (bpc_env) bpc = bpc_env;
     int64_t want = ceil_div(256 * (p.stream ? bpc : 6), q_tiles);
     const int64_t max_stripes = ceil_div(n_rows, (int64_t)(p.stream ? 1 : 4) * KNN_BN);
     if (want > max_stripes) want = max_stripes;
     if (want < 1) want = 1;
     p.stripes = (int)want;
-    p.stripe_rows = ceil_div(ceil_div(n_rows, p.stripes), KNN_BN) * KNN_BN;
+    const int64_t unit = p.direct ? 32 * KND_WAVES : KNN_BN;
+    p.stripe_rows = ceil_div(ceil_div(n_rows, p.stripes), unit) * unit;
     return p;
 }
 
@@ -487,7 +653,10 @@ extern "C" int rvc_knn_index_norms(const float *index_dev, int64_t n_rows, int d
 
 extern "C" int rvc_knn_workspace_bytes(int64_t n_rows, int64_t n_queries, int k, size_t *bytes) {
     if (!bytes || k != KNN_K || n_rows <= 0 || n_queries <= 0) return fail("rvc_knn_workspace_bytes: bad argument (k must be 8)");
-    const size_t slots = (size_t)knn_plan(n_rows, n_queries).n_slots();
+    // the ABI carries no dim here: size for the larger of the two plans (dim 256 packs more blocks per CU)
+    size_t slots = (size_t)knn_plan(n_rows, n_queries, 768).n_slots();
+    const size_t slots_v1 = (size_t)knn_plan(n_rows, n_queries, 256).n_slots();
+    if (slots_v1 > slots) slots = slots_v1;
     *bytes = align_up((size_t)n_queries * slots * KNN_K * sizeof(float), 256) +
              align_up((size_t)n_queries * slots * KNN_K * sizeof(int), 256);
     return 0;
@@ -505,13 +674,33 @@ extern "C" int rvc_knn_search(const float *index_dev, const float *norms_dev, in
     size_t need = 0;
     if (rvc_knn_workspace_bytes(n_rows, n_queries, k, &need)) return 1;
     if (workspace_bytes < need) return fail("rvc_knn_search: workspace too small (%zu < %zu)", workspace_bytes, need);
-    const KnnPlan plan = knn_plan(n_rows, n_queries);
+    const KnnPlan plan = knn_plan(n_rows, n_queries, dim);
     const int n_slots = plan.n_slots();
     float *part_d = (float *)workspace_dev;
     int *part_id = (int *)((char *)workspace_dev + align_up((size_t)n_queries * n_slots * KNN_K * sizeof(float), 256));
     dim3 grid((unsigned)ceil_div(n_queries, plan.q_tile), (unsigned)plan.stripes);
     static const int pf = getenv("RVC_KNN_STREAM_PF") ? atoi(getenv("RVC_KNN_STREAM_PF")) : 3;
-    if (plan.stream && pf == 2)
+    if (plan.direct) {
+        const size_t lds = knd_lds_bytes(dim);
+        static size_t lds_set = 0;
+        if (lds > lds_set) {
+            hipError_t e = hipFuncSetAttribute((const void *)knn_direct_kernel<KND_WAVES, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return fail("rvc_knn_search: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+            lds_set = lds;
+        }
+        static const int waves_env = getenv("RVC_KNN_DIRECT_WAVES") ? atoi(getenv("RVC_KNN_DIRECT_WAVES")) : 0;
+        if (waves_env == 84) {   // RVC_KNN_DIRECT_WAVES=84: 4 line groups in flight (+1.5 % on a 2 M-row index)
+            static bool set84 = false;
+            if (!set84) {
+                (void)hipFuncSetAttribute((const void *)knn_direct_kernel<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                set84 = true;
+            }
+            hipLaunchKernelGGL((knn_direct_kernel<8, 4>), grid, dim3(512), lds, (hipStream_t)stream, index_dev, norms_dev,
+                               n_rows, dim, queries_dev, n_queries, plan.stripe_rows, part_d, part_id, n_slots);
+        } else
+        hipLaunchKernelGGL((knn_direct_kernel<KND_WAVES, 3>), grid, dim3(KND_WAVES * 64), lds, (hipStream_t)stream, index_dev, norms_dev,
+                           n_rows, dim, queries_dev, n_queries, plan.stripe_rows, part_d, part_id, n_slots);
+    } else if (plan.stream && pf == 2)
         hipLaunchKernelGGL(knn_stream_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, index_dev, norms_dev, n_rows, dim,
                            queries_dev, n_queries, plan.stripe_rows, part_d, part_id, n_slots);
     else if (plan.stream && pf == 4)
