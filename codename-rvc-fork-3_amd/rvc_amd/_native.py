@@ -59,6 +59,7 @@ SYMBOLS = {
     "rvc_bigru_workspace_bytes": (c_int, [c_int, POINTER(c_size_t)]),
     "rvc_bigru_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_size_t,
                                   c_void_p]),
+    "rvc_attention_qkv_f32": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_float, c_void_p]),
     "rvc_decoder_create": (c_int, [POINTER(DecoderConfig), POINTER(c_void_p)]),
     "rvc_decoder_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]),
     "rvc_decoder_finalize": (c_int, [c_void_p]),
@@ -213,6 +214,18 @@ def bigru_forward(gi: torch.Tensor, whh_t: torch.Tensor, bhh: torch.Tensor, mult
         ws_ptr, ws_bytes = ws.data_ptr(), ws.numel()
     _check(_lib.rvc_bigru_forward(gi.data_ptr(), whh_t.data_ptr(), bhh.data_ptr(), out.data_ptr(), b, t, 256, ws_ptr,
                                   ws_bytes, _stream()), "rvc_bigru_forward")
+    return out
+
+
+# ---- HuBERT attention -------------------------------------------------------------------------------
+def attention_qkv(qkv: torch.Tensor, n_heads: int, scale: float) -> torch.Tensor:
+    """qkv [B, T, 3 * n_heads * 64] (fused projection output) -> softmax(q k^T * scale) v as [B, T, n_heads * 64]."""
+    assert qkv.is_cuda and qkv.dtype == torch.float32 and qkv.is_contiguous() and qkv.dim() == 3
+    b, t, c = qkv.shape
+    hd = c // (3 * n_heads)
+    out = torch.empty(b, t, n_heads * hd, dtype=torch.float32, device=qkv.device)
+    _check(_lib.rvc_attention_qkv_f32(qkv.data_ptr(), out.data_ptr(), b, t, n_heads, hd, float(scale), _stream()),
+           "rvc_attention_qkv_f32")
     return out
 
 

@@ -88,9 +88,13 @@ class HubertModelWithFinalProj:
             if self.consume_layerdrop_rng:
                 torch.rand([])
             wqkv, bqkv, scale = self._qkv[i]
-            qkv = F.linear(x, wqkv, bqkv).view(b, t, 3, h, hd).permute(2, 0, 3, 1, 4)
-            a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], scale=scale)
-            a = a.transpose(1, 2).reshape(b, t, d)
+            qkv = F.linear(x, wqkv, bqkv)
+            if qkv.is_cuda:   # librvc_amd K7: reads the fused projection in place, writes the layout out_proj consumes
+                from rvc_amd import _native
+                a = _native.attention_qkv(qkv, h, scale)
+            else:             # CPU tensors only occur in the host-logic tests
+                qkv = qkv.view(b, t, 3, h, hd).permute(2, 0, 3, 1, 4)
+                a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], scale=scale).transpose(1, 2).reshape(b, t, d)
             a = F.linear(a, w[L + ".attention.out_proj.weight"], w[L + ".attention.out_proj.bias"])
             x = F.layer_norm(x + a, (d,), w[L + ".layer_norm.weight"], w[L + ".layer_norm.bias"], 1e-5)
             f = F.gelu(F.linear(x, w[L + ".feed_forward.intermediate_dense.weight"],

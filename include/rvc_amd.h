@@ -95,6 +95,15 @@ int rvc_bigru_workspace_bytes(int batch, size_t *bytes);
 int rvc_bigru_forward(const float *gi_dev, const float *whhT_dev, const float *bhh_dev, float *out_dev,
                       int batch, int64_t n_steps, int hidden, void *workspace_dev, size_t workspace_bytes, void *stream);
 
+/* ---- K7: HuBERT self-attention ---------------------------------------------------------------- *
+ * Replaces the softmax(Q K^T * scale) V of transformers' HubertAttention inside `model(feats)["last_hidden_state"]`
+ * (call site rvc/infer/pipeline.py:450, wrapper rvc/lib/utils.py:31-34; third-party arithmetic, no mask, no dropout at
+ * inference).  qkv_dev [batch][n_frames][3][n_heads][head_dim] is the output of ONE fused q/k/v projection GEMM (the
+ * caller's); out_dev [batch][n_frames][n_heads * head_dim] is the layout out_proj consumes.  head_dim must be 64.
+ * fp32 throughout (matrix cores in exact-fp32 mode); exp is evaluated as 2^(x log2 e) on the hardware exp unit. */
+int rvc_attention_qkv_f32(const float *qkv_dev, float *out_dev, int batch, int64_t n_frames, int n_heads, int head_dim,
+                          float scale, void *stream);
+
 /* ---- K2/K3: vocoder ("dec" of Synthesizer) ---------------------------------------------------- *
  * Replaces `self.dec(z * x_mask, nsff0, g=g)` at rvc/lib/algorithm/synthesizers.py:254-258, i.e.
  *   RVC_DEC_NSF    HiFiGANNSFGenerator.forward  rvc/lib/algorithm/generators/hifigan_nsf.py:173-207

@@ -226,6 +226,21 @@ def test_bigru_matches_torch_gru(native, dev, batch, steps, multi_cu):
     assert (out - ref).abs().max().item() <= 2e-5
 
 
+# ---- K7 HuBERT attention -----------------------------------------------------------------------------
+@pytest.mark.parametrize("batch,frames,heads", [(1, 1, 12), (1, 31, 2), (2, 97, 12), (1, 1599, 12), (1, 64, 3)])
+def test_attention_matches_float64_softmax(native, dev, batch, frames, heads):
+    """softmax(q k^T / 8) v against a float64 evaluation of the same formula (what transformers' HubertAttention
+    computes, modeling_hubert.py eager path), on the fused-projection layout [B, T, 3, H, 64]."""
+    torch.manual_seed(frames)
+    qkv = torch.randn(batch, frames, 3 * heads * 64) * 1.5
+    got = native.attention_qkv(qkv.to(dev), heads, 0.125).cpu()
+    v = qkv.double().view(batch, frames, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(v[0] @ v[1].transpose(-1, -2) * 0.125, -1) @ v[2]).transpose(1, 2).reshape(batch, frames, -1)
+    assert got.shape == ref.shape and torch.isfinite(got).all()
+    # tolerance: fp32 dot products of 64 terms and a 2^x hardware exp (1 ulp) under a row sum -> a few 1e-6 relative
+    assert (got.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
 # ---- K6 filtfilt -------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n", [4000, 480_000, 19, 257])
 def test_filtfilt_matches_scipy(native, dev, n):
