@@ -36,16 +36,17 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = 
 PEAK_HBM_GBS = 8000.0           # HBM3E spec
 # average HBM bytes per launch of the roofline kernel symbol at the cfg-2 shape, from the PMC passes committed under
 # profiles/ (cannot be collected inside bench.py: it needs rocprofv3)
-PMC_TRAFFIC_BYTES = 422.7e6
+PMC_TRAFFIC_BYTES = 656.3e6
 PMC_TRAFFIC_SOURCE = ("profiles/r01_pmc_conv.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
                       "tools/pmc_conv.py (this same launch mix); FETCH_SIZE calibrated on the same kernel at K=1 with known bytes")
 
 
 def roofline_mix(native, dev, T, rates, k=11):
-    """The launches of conv_mfma_kernel<11,2,2,2,2,4> in one utterance's vocoder forward: stages 0 and 1, for each
-    dilation d: conv1 (dilation d) then conv2 (dilation 1, + residual; the last one also + running sum, x 1/3).
+    """The launches of conv_mfma_kernel<11,2,2,2,2,4,false> in one utterance's vocoder forward: the 11-tap ResBlock of
+    stage 1 (C = 128; the 38k-column stage 0 takes the 128x64-tile symbol), for each dilation d: conv1 (dilation d) then
+    conv2 (dilation 1, + residual; the last one also + running sum, x 1/3).
     Returns (callable, flops per call, launches per call, algorithmic HBM bytes per call)."""
-    shapes = [(256, T * rates[0]), (128, T * rates[0] * rates[1])]
+    shapes = [(128, T * rates[0] * rates[1])]
     state, flops, alg_bytes = [], 0.0, 0.0
     gen = torch.Generator().manual_seed(1)
     for C, L in shapes:
@@ -69,7 +70,7 @@ def roofline_mix(native, dev, T, rates, k=11):
                     native.conv1d_forward_into(t1, w2, bias, C, k, 1, 0.1, res=x, out=y)
                 else:
                     native.conv1d_forward_into(t1, w2, bias, C, k, 1, 0.1, res=x, acc=acc, out_scale=1 / 3, out=y)
-    return run, flops, 12, alg_bytes
+    return run, flops, 6, alg_bytes
 
 
 def decoder_flops(T, rates, ksizes, c0=512, cin=192, res_k=(3, 7, 11), n_dil=3):
@@ -165,7 +166,7 @@ def main():
             torch.distributed.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel symbol: conv_mfma_kernel<11,2,2,2,2,4> (11-tap ResBlock convs at C >= 128) ----
+    # ---- roofline of the dominant kernel symbol: conv_mfma_kernel<11,2,2,2,2,4,false> (stage-1 11-tap ResBlock convs) ----
     rates, ksizes = cpt["config"][12], cpt["config"][14]
     n_pad = n_in + 32000                              # 1 s reflect pad each side (pipeline.py:581)
     T = min(n_pad // 160, 2 * ((n_pad - 400) // 320 + 1))   # synth frames (pipeline.py:467)
@@ -182,8 +183,8 @@ def main():
     t_launch = e0.elapsed_time(e1) / (reps * mix_launches) * 1e-3
     flops_launch = mix_flops / mix_launches
     cfg2 = T == 3198 and list(rates[:2]) == [12, 10]
-    roofline = {"kernel": "rvc::conv_mfma_kernel<11,2,2,2,2,4>: the 12 launches per utterance of the 11-tap ResBlock convs of vocoder "
-                          "stages 0 (C=256) and 1 (C=128), in the decoder's own mix (dilations 1/3/5, residual on every second one)",
+    roofline = {"kernel": "rvc::conv_mfma_kernel<11,2,2,2,2,4,false>: the 6 launches per utterance of the 11-tap ResBlock convs of vocoder "
+                          "stage 1 (C=128, 383 760 columns), in the decoder's own mix (dilations 1/3/5, residual on every second one)",
                 "bound": "mfma", "achieved": round(flops_launch / t_launch / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(flops_launch / t_launch / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                 "traffic": PMC_TRAFFIC_BYTES if cfg2 else None,
@@ -246,7 +247,7 @@ def main():
         torch.cuda.synchronize()
         t_s = e0.elapsed_time(e1) / 5 * 1e-3
         sbytes = n_big * 768 * 4.0
-        roofline_knn_stream = {"kernel": "knn_stream_kernel<3> + knn_merge_kernel, 32 queries x 2 000 000 rows (6.1 GB index)",
+        roofline_knn_stream = {"kernel": "knn_direct_kernel<8,3> + knn_merge_kernel, 32 queries x 2 000 000 rows (6.1 GB index), one pass",
                                "bound": "hbm", "achieved": round(sbytes / t_s / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": round(sbytes / t_s / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
                                "avg_search_ms": round(t_s * 1e3, 4)}

@@ -10,7 +10,7 @@ def sel(rows, pred):
 KiB = 1024.0
 out = []
 cal = {}
-for C, L in ((256, 38376), (128, 383760)):
+for C, L in ((128, 383760),):
     tensor = C * L * 4
     grid = str(((L + 127) // 128) * (C // 128) * 256)
     k1 = lambda r: "conv_mfma_kernel<1," in r["Kernel_Name"] and r["Grid_Size"] == grid
@@ -18,15 +18,14 @@ for C, L in ((256, 38376), (128, 383760)):
     cal[C] = f1 / (2 * tensor)
     out.append(f"calibration K=1 C={C} L={L}: known reads {2*tensor/1e6:.1f} MB -> FETCH_SIZE {f1/1e6:.1f} MB (factor {cal[C]:.3f}); "
                f"known writes {tensor/1e6:.1f} MB -> WRITE_SIZE {w1/1e6:.1f} MB (factor {w1/tensor:.3f})")
-k11 = lambda r: "conv_mfma_kernel<11, 2, 2, 2, 2, 4>" in r["Kernel_Name"]
+k11 = lambda r: "conv_mfma_kernel<11, 2, 2, 2, 2, 4, false>" in r["Kernel_Name"]
 f = [ (float(r["Counter_Value"]) * KiB, r["Grid_Size"]) for r in F if k11(r)]
 w = [ float(r["Counter_Value"]) * KiB for r in W if k11(r)]
-g2c = {str(((38376 + 127) // 128) * 2 * 256): 256, str(((383760 + 127) // 128) * 256): 128}
-# the C=256 tensors (39 MB) sit inside the 256 MB Infinity Cache, which makes their FETCH_SIZE calibration meaningless
-# (MI355X_MICROARCH.md: scale past L3 before reading FETCH_SIZE); the factor of the 196 MB shape is used for both
+# FETCH_SIZE is calibrated on the same kernel family and tensor size (196 MB, past the 256 MB Infinity Cache once x, res
+# and y are counted) with known byte counts, as MI355X_MICROARCH.md prescribes
 reads = sum(v / cal[128] for v, g in f) / len(f)
 writes = sum(w) / len(w)
-out.append(f"roofline kernel conv_mfma_kernel<11,2,2,2,2,4>: {len(f)} launches profiled; mean FETCH_SIZE raw {sum(v for v,_ in f)/len(f)/1e6:.1f} MB, "
+out.append(f"roofline kernel conv_mfma_kernel<11,2,2,2,2,4,false>: {len(f)} launches profiled; mean FETCH_SIZE raw {sum(v for v,_ in f)/len(f)/1e6:.1f} MB, "
            f"calibrated reads {reads/1e6:.1f} MB, writes {writes/1e6:.1f} MB per launch")
 out.append(f"TRAFFIC_BYTES_PER_LAUNCH {reads + writes:.0f}")
 print("\n".join(out))
