@@ -28,6 +28,56 @@ SAMPLE_RATE = 16000  # Hz
 bh, ah = signal.butter(N=FILTER_ORDER, Wn=CUTOFF_FREQUENCY, btype="high", fs=SAMPLE_RATE)  # pipeline.py:23-28
 
 
+# pipeline.py:149-204: the note table of Autotune (G1 .. C6, two decimals)
+REF_FREQS = [49.00, 51.91, 55.00, 58.27, 61.74, 65.41, 69.30, 73.42, 77.78, 82.41, 87.31, 92.50, 98.00, 103.83, 110.00,
+             116.54, 123.47, 130.81, 138.59, 146.83, 155.56, 164.81, 174.61, 185.00, 196.00, 207.65, 220.00, 233.08,
+             246.94, 261.63, 277.18, 293.66, 311.13, 329.63, 349.23, 369.99, 392.00, 415.30, 440.00, 466.16, 493.88,
+             523.25, 554.37, 587.33, 622.25, 659.25, 698.46, 739.99, 783.99, 830.61, 880.00, 932.33, 987.77, 1046.50]
+
+
+class Autotune:
+    """pipeline.py:88-114."""
+
+    def __init__(self, ref_freqs):
+        self.ref_freqs = ref_freqs
+        self.note_dict = self.ref_freqs
+
+    def autotune_f0(self, f0, f0_autotune_strength):
+        """Every frame (unvoiced zeros included, as in the reference) moves towards its nearest note; argmin keeps the
+        first of two equidistant notes, like the reference's min(..., key=...)."""
+        notes = np.asarray(self.note_dict, dtype=np.float64)
+        f0 = np.asarray(f0, dtype=np.float64)
+        closest = notes[np.argmin(np.abs(notes[None, :] - f0[:, None]), axis=1)]
+        return f0 + (closest - f0) * f0_autotune_strength
+
+
+class AudioProcessor:
+    """pipeline.py:33-85, on the device."""
+
+    @staticmethod
+    def _rms(y: torch.Tensor, frame_length: int, hop_length: int) -> torch.Tensor:
+        # librosa.feature.rms (0.11): zero centre-padding, frames of frame_length every hop_length, sqrt(mean(x^2))
+        y = F.pad(y, (frame_length // 2, frame_length // 2))
+        return y.unfold(0, frame_length, hop_length).pow(2).mean(-1).sqrt()
+
+    @staticmethod
+    def change_rms(source_audio, source_rate: int, target_audio, target_rate: int, rate: float):
+        """Tensors in (source float64 as the pipeline holds it, target float32) -> float32 tensor; NumPy in -> NumPy out."""
+        as_numpy = not torch.is_tensor(target_audio)
+        if as_numpy:
+            target_audio = torch.from_numpy(np.ascontiguousarray(target_audio))
+        if not torch.is_tensor(source_audio):
+            source_audio = torch.from_numpy(np.ascontiguousarray(source_audio)).to(target_audio.device)
+        n = target_audio.shape[0]
+        rms1 = AudioProcessor._rms(source_audio, source_rate // 2 * 2, source_rate // 2).float()
+        rms2 = AudioProcessor._rms(target_audio, target_rate // 2 * 2, target_rate // 2).float()
+        rms1 = F.interpolate(rms1.view(1, 1, -1), size=n, mode="linear").view(-1)
+        rms2 = F.interpolate(rms2.view(1, 1, -1), size=n, mode="linear").view(-1)
+        rms2 = torch.maximum(rms2, torch.zeros_like(rms2) + 1e-6)
+        out = target_audio * (torch.pow(rms1, 1 - rate) * torch.pow(rms2, rate - 1))
+        return out.numpy() if as_numpy else out
+
+
 class FeatureIndex:
     """Device-resident replacement of the faiss index + ``big_npy`` pair (pipeline.py:553-556).
 
@@ -87,6 +137,9 @@ class Pipeline:
         self._preset_index = None
         self._f0_stream = None
         self._coarse_thr = None
+        self.ref_freqs = REF_FREQS
+        self.autotune = Autotune(self.ref_freqs)
+        self.note_dict = self.autotune.note_dict
 
     # ---- additions -------------------------------------------------------------------------------------
     def load_rmvpe_state_dict(self, sd):
@@ -120,12 +173,12 @@ class Pipeline:
             f0 = self.model_rmvpe.infer_from_audio_device(x, thred=0.03).cpu().numpy()
         else:
             f0 = self.model_rmvpe.infer_from_audio(x, thred=0.03)
-        return self._postprocess_f0(f0, pitch, f0_autotune, inp_f0)
+        return self._postprocess_f0(f0, pitch, f0_autotune, inp_f0, f0_autotune_strength)
 
-    def _postprocess_f0(self, f0, pitch, f0_autotune=False, inp_f0=None):
-        """pipeline.py:385-410 on a float64 host contour: key shift, optional f0-file override, coarse bins 1..255."""
+    def _postprocess_f0(self, f0, pitch, f0_autotune=False, inp_f0=None, f0_autotune_strength=1):
+        """pipeline.py:385-410 on a float64 host contour: autotune, key shift, optional f0-file override, coarse bins."""
         if f0_autotune is True:
-            raise NotImplementedError("f0_autotune is not implemented")
+            f0 = Autotune.autotune_f0(self, f0, f0_autotune_strength)
         f0 *= pow(2, pitch / 12)
         tf0 = self.sample_rate // self.window
         if inp_f0 is not None:  # pipeline.py:390-400
@@ -235,8 +288,6 @@ class Pipeline:
         noise_seed: None -> noise is drawn on the device; int -> parity mode: seed torch's CPU generator and
         draw every random tensor in the reference's order (including the 12 LayerDrop draws transformers'
         HuBERT makes per forward), so the result matches the reference CPU path run under the same seed."""
-        if volume_envelope != 1:
-            raise NotImplementedError("volume_envelope != 1 (change_rms) is not implemented (SURVEY §8 a19)")
         if not pitch_guidance:
             raise NotImplementedError("models without pitch guidance are not supported (SURVEY §2 item 3b)")
         index = self._get_index(file_index, index_rate)
@@ -321,7 +372,7 @@ class Pipeline:
             else:  # f0-file override: the reference's host code, on the host
                 with torch.cuda.stream(side):
                     f0_host = f0_dev.cpu().numpy()  # waits for the side stream only
-                pitch, pitchf = self._postprocess_f0(f0_host, pitch, f0_autotune, inp_f0)
+                pitch, pitchf = self._postprocess_f0(f0_host, pitch, f0_autotune, inp_f0, f0_autotune_strength)
                 pitch, pitchf = pitch[:p_len], pitchf[:p_len]
                 pitch = torch.tensor(pitch, device=self.device).unsqueeze(0).long()
                 pitchf = torch.tensor(pitchf, device=self.device).unsqueeze(0).float()
@@ -332,6 +383,8 @@ class Pipeline:
                 seg = self._synthesize(net_g, sid, feats, feats0, n_audio, pitch[:, ps], pitchf[:, ps], protect, noise)
                 audio_opt.append(seg[self.t_pad_tgt: -self.t_pad_tgt])
         out = torch.cat(audio_opt) if len(audio_opt) > 1 else audio_opt[0]
+        if volume_envelope != 1:  # pipeline.py:682-685 (both rates are passed as 16000 there, too)
+            out = AudioProcessor.change_rms(audio, self.sample_rate, out, self.sample_rate, volume_envelope)
         audio_max = out.abs().max() / 0.99  # pipeline.py:686-688
         out = torch.where(audio_max > 1, out / audio_max, out)
         return out if as_tensor else out.cpu().numpy()

@@ -291,8 +291,47 @@ F0_MEL_MIN = 1127 * np.log(1 + 50 / 700)  # pipeline.py:144-147
 F0_MEL_MAX = 1127 * np.log(1 + 1100 / 700)
 
 
-def f0_to_coarse(f0: np.ndarray, pitch: float = 0):
-    """pipeline.py:388, 401-410.  Returns (coarse int array 1..255, shifted f0)."""
+# pipeline.py:149-204: G1 .. C6, two decimals
+REF_FREQS = [49.00, 51.91, 55.00, 58.27, 61.74, 65.41, 69.30, 73.42, 77.78, 82.41, 87.31, 92.50, 98.00, 103.83, 110.00,
+             116.54, 123.47, 130.81, 138.59, 146.83, 155.56, 164.81, 174.61, 185.00, 196.00, 207.65, 220.00, 233.08,
+             246.94, 261.63, 277.18, 293.66, 311.13, 329.63, 349.23, 369.99, 392.00, 415.30, 440.00, 466.16, 493.88,
+             523.25, 554.37, 587.33, 622.25, 659.25, 698.46, 739.99, 783.99, 830.61, 880.00, 932.33, 987.77, 1046.50]
+
+
+def autotune_f0(f0: np.ndarray, strength: float) -> np.ndarray:
+    """Autotune.autotune_f0, pipeline.py:103-114: every frame -- unvoiced zeros included -- is pulled towards the
+    nearest listed note (first one wins a tie, as Python's min does)."""
+    out = np.zeros_like(f0)
+    for i, freq in enumerate(f0):
+        closest = min(REF_FREQS, key=lambda x: abs(x - freq))
+        out[i] = freq + (closest - freq) * strength
+    return out
+
+
+def librosa_rms(y: np.ndarray, frame_length: int, hop_length: int) -> np.ndarray:
+    """librosa.feature.rms (librosa 0.11.0 as pinned by requirements.txt; absent here -> restated from its published
+    algorithm, parity unpinned): centre-pad with zeros, frame, sqrt(mean(|x|^2)).  Returns [1, n_frames]."""
+    y = np.pad(y, (frame_length // 2, frame_length // 2), mode="constant")
+    n_frames = 1 + (y.shape[0] - frame_length) // hop_length
+    frames = np.lib.stride_tricks.as_strided(y, shape=(frame_length, n_frames),
+                                             strides=(y.strides[0], y.strides[0] * hop_length), writeable=False)
+    return np.sqrt(np.mean(np.abs(frames) ** 2, axis=-2, keepdims=True))
+
+
+def change_rms(source_audio: np.ndarray, source_rate: int, target_audio: np.ndarray, target_rate: int, rate: float):
+    """AudioProcessor.change_rms, pipeline.py:38-85 (the caller passes 16000 for BOTH rates, :682-685)."""
+    rms1 = librosa_rms(source_audio, source_rate // 2 * 2, source_rate // 2)
+    rms2 = librosa_rms(target_audio, target_rate // 2 * 2, target_rate // 2)
+    rms1 = F.interpolate(torch.from_numpy(rms1).float().unsqueeze(0), size=target_audio.shape[0], mode="linear").squeeze()
+    rms2 = F.interpolate(torch.from_numpy(rms2).float().unsqueeze(0), size=target_audio.shape[0], mode="linear").squeeze()
+    rms2 = torch.maximum(rms2, torch.zeros_like(rms2) + 1e-6)
+    return target_audio * (torch.pow(rms1, 1 - rate) * torch.pow(rms2, rate - 1)).numpy()
+
+
+def f0_to_coarse(f0: np.ndarray, pitch: float = 0, f0_autotune: bool = False, f0_autotune_strength: float = 1):
+    """pipeline.py:385-388, 401-410.  Returns (coarse int array 1..255, shifted f0)."""
+    if f0_autotune is True:
+        f0 = autotune_f0(f0, f0_autotune_strength)
     f0 = f0 * pow(2, pitch / 12)
     f0bak = f0.copy()
     f0_mel = 1127 * np.log(1 + f0 / 700)
@@ -738,8 +777,9 @@ def voice_conversion(hubert_sd, cpt, w, sid: Tensor, audio0: np.ndarray, pitch: 
 
 
 def pipeline(hubert_sd, rmvpe_sd, cpt, audio: np.ndarray, *, sid=0, pitch=0, big_npy=None, index_rate=0.0,
-             protect=0.5, noise=None, knn_dtype=np.float64, taps=None) -> np.ndarray:
-    """Pipeline.pipeline, pipeline.py:509-694, rmvpe branch, volume_envelope == 1."""
+             protect=0.5, noise=None, knn_dtype=np.float64, taps=None, volume_envelope=1, f0_autotune=False,
+             f0_autotune_strength=1) -> np.ndarray:
+    """Pipeline.pipeline, pipeline.py:509-694, rmvpe branch."""
     tgt_sr = cpt["config"][-1]
     w = fold_weight_norm(cpt["weight"])
     t_pad, t_pad_tgt = 16000 * X_PAD, tgt_sr * X_PAD
@@ -749,7 +789,7 @@ def pipeline(hubert_sd, rmvpe_sd, cpt, audio: np.ndarray, *, sid=0, pitch=0, big
     p_len = audio_pad.shape[0] // WINDOW
     sid_t = torch.tensor(sid).unsqueeze(0).long()
     f0 = rmvpe_infer_from_audio(audio_pad, rmvpe_sd)
-    coarse, f0bak = f0_to_coarse(f0, pitch)
+    coarse, f0bak = f0_to_coarse(f0, pitch, f0_autotune, f0_autotune_strength)
     coarse, f0bak = coarse[:p_len], f0bak[:p_len]
     pitch_t = torch.tensor(coarse).unsqueeze(0).long()
     pitchf_t = torch.tensor(f0bak).unsqueeze(0).float()
@@ -761,6 +801,8 @@ def pipeline(hubert_sd, rmvpe_sd, cpt, audio: np.ndarray, *, sid=0, pitch=0, big
                                big_npy, index_rate, protect, noise=noise, knn_dtype=knn_dtype, taps=taps)
         out.append(seg[t_pad_tgt:-t_pad_tgt])
     audio_opt = np.concatenate(out)
+    if volume_envelope != 1:  # pipeline.py:682-685
+        audio_opt = change_rms(audio, 16000, audio_opt, 16000, volume_envelope)
     audio_max = np.abs(audio_opt).max() / 0.99
     if audio_max > 1:
         audio_opt /= audio_max

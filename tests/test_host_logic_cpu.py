@@ -80,6 +80,29 @@ def test_f0_postprocess_device_table_equals_host_formula():
             assert np.array_equal(got_f.numpy(), want_f)
 
 
+def test_autotune_and_change_rms_match_reference_golden():
+    """The optional branches of SURVEY §8 a19 in the product's host mirror (pipeline.py:38-114, 385-386, 682-685)."""
+    import torch
+    from rvc_amd.infer.pipeline import AudioProcessor, Autotune, REF_FREQS
+    g = load_golden("autotune")
+    assert np.array_equal(np.array(REF_FREQS), g["ref_freqs"])
+    p = _pipeline_cpu()
+    p.note_dict = Autotune(REF_FREQS).note_dict
+    for strength in (1.0, 0.4):
+        assert np.array_equal(Autotune.autotune_f0(p, g["f0"].copy(), strength), g[f"tuned_{strength}"])
+    coarse, f0bak = p._postprocess_f0(g["f0"].copy(), 3, True, None, 0.4)
+    want = p._postprocess_f0(g["tuned_0.4"].copy(), 3)
+    assert np.array_equal(coarse, want[0]) and np.array_equal(f0bak, want[1])
+    c = load_golden("change_rms")
+    for rate in (0.25, 0.0):
+        out = AudioProcessor.change_rms(torch.from_numpy(c["source"]), 16000, torch.from_numpy(c["target"]), 16000, rate)
+        ref = c[f"out_{rate}"]
+        assert out.dtype == torch.float32
+        # the frame means are summed in torch's order, not NumPy's pairwise order: a few float32 ulps on the envelope
+        assert np.abs(out.numpy() - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
+        assert np.array_equal(AudioProcessor.change_rms(c["source"], 16000, c["target"], 16000, rate), out.numpy())
+
+
 def test_f0_file_override():
     p = _pipeline_cpu()
     f0 = np.full(400, 100.0)

@@ -52,6 +52,30 @@ def test_f0_coarse_bit_exact():
         assert coarse.min() >= 1 and coarse.max() <= 255
 
 
+def test_autotune_bit_exact_and_coarse_ints():
+    """Autotune.autotune_f0 (pipeline.py:103-114), fixture from tests/golden/make_golden_a19.py."""
+    g = load_golden("autotune")
+    assert np.array_equal(np.array(O.REF_FREQS), g["ref_freqs"])
+    for strength in (1.0, 0.4):
+        assert np.array_equal(O.autotune_f0(g["f0"].copy(), strength), g[f"tuned_{strength}"])
+    coarse, f0bak = O.f0_to_coarse(g["f0"].copy(), 3, True, 0.4)
+    want_c, want_f = O.f0_to_coarse(g["tuned_0.4"].copy(), 3)
+    assert np.array_equal(coarse, want_c) and np.array_equal(f0bak, want_f)
+
+
+def test_change_rms_matches_reference():
+    """AudioProcessor.change_rms (pipeline.py:38-85) run by the reference over the oracle's librosa.feature.rms
+    restatement: same float32 ops in the same order -> bit-exact."""
+    g = load_golden("change_rms")
+    for rate in (0.25, 0.0):
+        out = O.change_rms(g["source"], 16000, g["target"], 16000, rate)
+        assert out.dtype == np.float32 and np.array_equal(out, g[f"out_{rate}"])
+    # librosa.feature.rms by hand on a tiny case: zero centre-padding, hop 2, frame 4
+    y = np.arange(1.0, 9.0)
+    want = [np.sqrt(np.mean(np.array(f) ** 2)) for f in ([0, 0, 1, 2], [1, 2, 3, 4], [3, 4, 5, 6], [5, 6, 7, 8], [7, 8, 0, 0])]
+    assert np.allclose(O.librosa_rms(y, 4, 2)[0], want, rtol=0, atol=1e-15)
+
+
 def test_mel_filterbank_and_logmel():
     g = load_golden("logmel")
     fb = O.mel_filterbank()
