@@ -17,6 +17,7 @@ from rvc_amd.configs.config import Config
 from rvc_amd.infer.pipeline import Pipeline as VC
 from rvc_amd.lib.algorithm.synthesizers import Synthesizer
 from rvc_amd.lib.hubert import HubertModelWithFinalProj
+from rvc_amd.lib.tools.split_audio import merge_audio, process_audio
 
 
 def _read_wav_16k_mono(path):
@@ -113,7 +114,8 @@ class VoiceConverter:
     def convert_array(self, audio: np.ndarray, *, index_path: str = "", pitch: int = 0, f0_file=None,
                       f0_method: str = "rmvpe", index_rate: float = 0.75, volume_envelope: float = 1,
                       protect: float = 0.5, hop_length: int = 128, f0_autotune: bool = False,
-                      f0_autotune_strength: float = 1, filter_radius: float = 3.0, sid: int = 0, noise_seed=None):
+                      f0_autotune_strength: float = 1, filter_radius: float = 3.0, sid: int = 0, noise_seed=None,
+                      split_audio: bool = False):
         """The array-level core of convert_audio (infer.py:262-311): 16 kHz float array in, float32 @tgt_sr out."""
         if torch.is_tensor(audio):  # HBM-resident entry: same peak limiting on the device
             audio = audio.to(device=self.config.device, dtype=torch.float64)
@@ -125,12 +127,28 @@ class VoiceConverter:
             if audio_max > 1:
                 audio /= audio_max
         file_index = index_path.strip().strip('"').strip("\n").strip('"').strip().replace("trained", "added")
-        return self.vc.pipeline(model=self.hubert_model, net_g=self.net_g, sid=sid, audio=audio, pitch=pitch,
-                                f0_method=f0_method, file_index=file_index, index_rate=index_rate,
-                                pitch_guidance=self.use_f0, filter_radius=filter_radius,
-                                volume_envelope=volume_envelope, version=self.version, protect=protect,
-                                hop_length=hop_length, f0_autotune=f0_autotune,
-                                f0_autotune_strength=f0_autotune_strength, f0_file=f0_file, noise_seed=noise_seed)
+
+        def run(chunk):
+            return self.vc.pipeline(model=self.hubert_model, net_g=self.net_g, sid=sid, audio=chunk, pitch=pitch,
+                                    f0_method=f0_method, file_index=file_index, index_rate=index_rate,
+                                    pitch_guidance=self.use_f0, filter_radius=filter_radius,
+                                    volume_envelope=volume_envelope, version=self.version, protect=protect,
+                                    hop_length=hop_length, f0_autotune=f0_autotune,
+                                    f0_autotune_strength=f0_autotune_strength, f0_file=f0_file, noise_seed=noise_seed)
+
+        if not split_audio:
+            return run(audio)
+        # infer.py:283-318: cut at silences (host, on the 16 kHz input), convert the chunks, put them back on the time line
+        host = audio.cpu().numpy() if torch.is_tensor(audio) else audio
+        chunks, intervals = process_audio(host, 16000)
+        print(f"Audio split into {len(chunks)} chunks for processing.")
+        converted = []
+        for c in chunks:
+            out = run(torch.from_numpy(np.ascontiguousarray(c)).to(audio.device) if torch.is_tensor(audio) else c)
+            converted.append(out.cpu().numpy() if torch.is_tensor(out) else out)
+            print(f"Converted audio chunk {len(converted)}")
+        merged = merge_audio(chunks, converted, intervals, 16000, self.tgt_sr)
+        return torch.from_numpy(merged).to(audio.device) if torch.is_tensor(audio) else merged
 
     def convert_audio(self, audio_input_path: str, audio_output_path: str, model_path: str, index_path: str,
                       pitch: int = 0, f0_file: str = None, f0_method: str = "rmvpe", index_rate: float = 0.75,
@@ -148,9 +166,9 @@ class VoiceConverter:
         try:
             start_time = time.time()
             print(f"Converting audio '{audio_input_path}'...")
-            if split_audio or clean_audio or post_process or export_format != "WAV":
-                raise NotImplementedError("split_audio / clean_audio / post_process / non-WAV export are outside "
-                                          "the hot path (SURVEY §2 items 2, 9)")
+            if clean_audio or post_process or export_format != "WAV":
+                raise NotImplementedError("clean_audio / post_process / non-WAV export are outside the hot path "
+                                          "(SURVEY §2 items 2, 9)")
             audio = _read_wav_16k_mono(audio_input_path)
             if not self.hubert_model or embedder_model != self.last_embedder_model:
                 self.load_hubert(embedder_model, embedder_model_custom)
@@ -161,7 +179,7 @@ class VoiceConverter:
                                            f0_method=f0_method, index_rate=index_rate,
                                            volume_envelope=volume_envelope, protect=protect, hop_length=hop_length,
                                            f0_autotune=f0_autotune, f0_autotune_strength=f0_autotune_strength,
-                                           filter_radius=filter_radius, sid=sid)
+                                           filter_radius=filter_radius, sid=sid, split_audio=split_audio)
             _write_wav(audio_output_path, audio_opt, self.tgt_sr)
             print(f"Conversion completed at '{audio_output_path}' in {time.time() - start_time:.2f} seconds.")
         except Exception as error:

@@ -103,6 +103,23 @@ def test_autotune_and_change_rms_match_reference_golden():
         assert np.array_equal(AudioProcessor.change_rms(c["source"], 16000, c["target"], 16000, rate), out.numpy())
 
 
+def test_split_and_merge_match_reference_golden():
+    """rvc/lib/tools/split_audio.py:5-79.  merge_audio is pinned bit-exactly by the reference's own output; the silence
+    detector restates librosa.effects.split (absent here, `parity unpinned`) and is checked against hand-derived edges."""
+    from rvc_amd.lib.tools.split_audio import merge_audio, process_audio
+    g = load_golden("split_merge")
+    chunks, intervals = process_audio(g["signal"], 16000)
+    assert np.array_equal(np.asarray(intervals), g["intervals"])
+    # frames of 4000 every 2000, centred: the first frame holding signal (>= sample 5000) is centred at 4000, the last
+    # one before the pause (< 15000) at 16000 -> [4000, 18000); then [22000, 46000)
+    assert np.asarray(intervals).tolist() == [[4000, 18000], [22000, 46000]]
+    conv = [np.full(int(n), 0.01 * (i + 1), dtype=np.float32) for i, n in enumerate(g["conv_lengths"])]
+    merged = merge_audio(chunks, conv, intervals, 16000, 48000)
+    assert merged.dtype == np.float32 and np.array_equal(merged, g["merged"])
+    # levels are relative to the loudest frame (librosa's ref=np.max): an all-zero input is one single interval
+    assert np.asarray(process_audio(np.zeros(16000), 16000)[1]).tolist() == [[0, 16000]]
+
+
 def test_f0_file_override():
     p = _pipeline_cpu()
     f0 = np.full(400, 100.0)
