@@ -346,18 +346,21 @@ class Pipeline:
         plan.append((slice(t, None), slice(t // self.window if t is not None else None, None)))
 
         with torch.no_grad():
-            # F0 (RMVPE) is independent of HuBERT + retrieval until the synthesizer: run it on a side stream.  Its
-            # BiGRU recurrence occupies two CUs for ~6 us x 3232 steps; the other 254 take the features meanwhile.
+            # F0 (RMVPE) is independent of HuBERT + retrieval until the synthesizer.  Its U-Net is throughput-bound like
+            # HuBERT, its BiGRU is latency-bound (3232 sequential steps on 8 CUs, ~5.5 ms): the U-Net goes FIRST on the
+            # main stream, then the recurrence + decode + pitch quantisation run on a side stream underneath HuBERT
+            # and the retrieval, so f0 is ready before the synthesizer needs it and no CU idles waiting for the GRU.
             main = torch.cuda.current_stream()
             if self._f0_stream is None:
                 self._f0_stream = torch.cuda.Stream(device=self.device)
             side = self._f0_stream
-            side.wait_stream(main)
-            audio_dev.record_stream(side)
             if f0_method != "rmvpe":
                 raise NotImplementedError(f"f0_method={f0_method!r}: only 'rmvpe' is implemented")
+            gi, n_f0 = self.model_rmvpe.front_half_device(audio_dev)
+            side.wait_stream(main)
+            gi.record_stream(side)
             with torch.cuda.stream(side):
-                f0_dev = self.model_rmvpe.infer_from_audio_device(audio_dev, thred=0.03)
+                f0_dev = self.model_rmvpe.back_half_device(gi, n_f0, thred=0.03)
                 if inp_f0 is None and f0_autotune is not True:
                     # the contour never leaves HBM and the host never waits for it: everything below is enqueued
                     # while the GPU is still busy with HuBERT

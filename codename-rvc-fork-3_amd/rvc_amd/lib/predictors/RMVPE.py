@@ -84,6 +84,11 @@ class RMVPE0Predictor:
     @torch.no_grad()
     def mel2hidden(self, mel: torch.Tensor, n_frames: int) -> torch.Tensor:
         """mel [B,128,T32] (frame axis already reflect-padded to a multiple of 32) -> salience [B,n_frames,360]."""
+        return self.gru_head(self.unet_features(mel), n_frames)
+
+    @torch.no_grad()
+    def unet_features(self, mel: torch.Tensor) -> torch.Tensor:
+        """The throughput-bound half: U-Net + output conv + the GRU's input projections -> gi [B,T32,2,768]."""
         w = self.w
         x = mel.transpose(-1, -2).unsqueeze(1)
         x = x * w["in.scale"] + w["in.shift"]
@@ -105,8 +110,13 @@ class RMVPE0Predictor:
                 x = self._block(x, f"{p}.conv2.{m}")
         x = F.conv2d(x, w["cnn.w"], w["cnn.b"], 1, 1)
         x = x.transpose(1, 2).flatten(-2)
+        return F.linear(x, w["gru.wih"], w["gru.bih"]).view(x.shape[0], x.shape[1], 2, 768)
+
+    @torch.no_grad()
+    def gru_head(self, gi: torch.Tensor, n_frames: int) -> torch.Tensor:
+        """The latency-bound half: the BiGRU recurrence (8 workgroups, ~1.7 us per step) + classifier -> salience."""
         from rvc_amd import _native
-        gi = F.linear(x, w["gru.wih"], w["gru.bih"]).view(x.shape[0], x.shape[1], 2, 768)
+        w = self.w
         x = _native.bigru_forward(gi, w["gru.whhT"], w["gru.bhh"])
         return torch.sigmoid(F.linear(x, w["fc.w"], w["fc.b"]))[:, :n_frames]
 
@@ -136,6 +146,19 @@ class RMVPE0Predictor:
         mel, n_frames = _native.logmel_rmvpe(audio.float(), pad_to=32)
         hidden = self.mel2hidden(mel, n_frames)
         return self.decode(hidden[0], thred)
+
+    @torch.no_grad()
+    def front_half_device(self, audio: torch.Tensor):
+        """log-mel + U-Net + GRU input projections; returns (gi, n_frames) for `back_half_device`."""
+        from rvc_amd import _native
+        if audio.dim() == 1:
+            audio = audio.unsqueeze(0)
+        mel, n_frames = _native.logmel_rmvpe(audio.float(), pad_to=32)
+        return self.unet_features(mel), n_frames
+
+    @torch.no_grad()
+    def back_half_device(self, gi: torch.Tensor, n_frames: int, thred=0.03) -> torch.Tensor:
+        return self.decode(self.gru_head(gi, n_frames)[0], thred)
 
     def infer_from_audio(self, audio, thred=0.03) -> np.ndarray:
         """Reference signature (RMVPE.py:472-485): NumPy audio in, NumPy float64 f0 out."""

@@ -12,6 +12,8 @@ from rvc_amd.lib.algorithm.residuals import flow_reverse
 from rvc_amd.lib.algorithm.weights import fold_weight_norm
 from rvc_amd.lib.predictors.RMVPE import RMVPE0Predictor
 dev = "cuda:0"
+if os.environ.get("CUDNN_BENCHMARK"):
+    torch.backends.cudnn.benchmark = True
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 hub = HubertModelWithFinalProj(S.make_hubert_state_dict(1), device=dev)
 w = {k: v.to(dev) for k, v in fold_weight_norm(S.make_synth_checkpoint(48000, "HiFi-GAN", 0)["weight"]).items() if not k.startswith("dec.")}
@@ -31,3 +33,12 @@ for it in range(3):
         if which in ("all", "flow"): flow_reverse(w, zp, mask, g)
         if which in ("all", "rmvpe"): rm.mel2hidden(mel, 3201)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+with torch.no_grad():
+    if which in ("all", "hubert"): hub(wav)
+    if which in ("all", "enc"): text_encoder(w, phone, pitch, lens)
+    if which in ("all", "flow"): flow_reverse(w, zp, mask, g)
+    if which in ("all", "rmvpe"): rm.mel2hidden(mel, 3201)
+e1.record(); torch.cuda.synchronize()
+print(f"{which}: {e0.elapsed_time(e1):.2f} ms (one more pass, HIP events)")
