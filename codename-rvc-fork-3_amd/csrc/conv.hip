@@ -148,20 +148,28 @@ conv_mfma_kernel(const ConvParams p) {
         const int buf = c & 1;
         const float *wa = &ws[buf * WTOT + half * BM + wm * MT * 32 + l31];
         const float *xb = &xs[buf * XTOT + half * XW + wn * NT * 32 + l31];
+        // fragments of k-step s+1 are read from LDS before the MFMAs of step s are issued (register double buffer):
+        // left to itself the compiler emits read, s_waitcnt lgkmcnt(0), 4 x MFMA per step and every step eats the
+        // LDS latency
+        constexpr int STEPS = KW * (CONV_CIC / 2);
+        float a[2][MT], bb[2][NT];
+        auto frag = [&](int s, float (&av)[MT], float (&bv)[NT]) __attribute__((always_inline)) {
+            const int tap = s / (CONV_CIC / 2), kk = s - tap * (CONV_CIC / 2);
 #pragma unroll
-        for (int tap = 0; tap < KW; ++tap) {
+            for (int m = 0; m < MT; ++m) av[m] = wa[(tap * CONV_CIC + 2 * kk) * BM + m * 32];
 #pragma unroll
-            for (int kk = 0; kk < CONV_CIC / 2; ++kk) {
-                float a[MT], bb[NT];
+            for (int n = 0; n < NT; ++n) bv[n] = xb[(2 * kk) * XW + n * 32 + tap * dil];
+        };
+        frag(0, a[0], bb[0]);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) a[m] = wa[(tap * CONV_CIC + 2 * kk) * BM + m * 32];
+        for (int st = 0; st < STEPS; ++st) {
+            if (st + 1 < STEPS) frag(st + 1, a[(st + 1) & 1], bb[(st + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);   // keep the reads of step st+1 ahead of the MFMAs of step st
 #pragma unroll
-                for (int n = 0; n < NT; ++n) bb[n] = xb[(2 * kk) * XW + n * 32 + tap * dil];
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) acc[m][n] = mfma32(a[m], bb[n], acc[m][n]);
-            }
+                for (int n = 0; n < NT; ++n) acc[m][n] = mfma32(a[st & 1][m], bb[st & 1][n], acc[m][n]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (c + 1 < n_chunks) {
             // buffer buf^1 was last read during chunk c-1; every wave passed the barrier that ended it
