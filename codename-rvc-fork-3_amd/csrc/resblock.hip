@@ -133,23 +133,28 @@ resblock_layer_kernel(const float *__restrict__ x, const float *__restrict__ w1,
             const int buf = c & 1;
             const float *wa = &ws[buf * WSLAB + half * C + row0 + l31];
             const float *sb = &src[(c * CIC + half) * sw + colw + l31];
+            // LDS fragments one k-step ahead of the MFMAs (see conv.hip)
+            constexpr int STEPS = KW * (CIC / 2);
+            float a[2][MT], bb[2][NT];
+            auto frag = [&](int st, float (&av)[MT], float (&bv)[NT]) __attribute__((always_inline)) {
+                const int tap = st / (CIC / 2), kk = st - tap * (CIC / 2);
 #pragma unroll
-            for (int tap = 0; tap < KW; ++tap) {
+                for (int m = 0; m < MT; ++m) av[m] = wa[(tap * CIC + 2 * kk) * C + m * 32];
 #pragma unroll
-                for (int kk = 0; kk < CIC / 2; ++kk) {
-                    float a[MT], bb[NT];
+                for (int n = 0; n < NT; ++n) bv[n] = sb[(2 * kk) * sw + n * 32 + tap * td];
+            };
+            frag(0, a[0], bb[0]);
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) a[m] = wa[(tap * CIC + 2 * kk) * C + m * 32];
+            for (int st = 0; st < STEPS; ++st) {
+                if (st + 1 < STEPS) frag(st + 1, a[(st + 1) & 1], bb[(st + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        const float v = sb[(2 * kk) * sw + n * 32 + tap * td];
-                        bb[n] = act ? lrelu(v, slope) : v;
-                    }
+                for (int n = 0; n < NT; ++n) bb[st & 1][n] = act ? lrelu(bb[st & 1][n], slope) : bb[st & 1][n];
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
-                        for (int n = 0; n < NT; ++n) acc[m][n] = mfma32(a[m], bb[n], acc[m][n]);
-                }
+                    for (int n = 0; n < NT; ++n) acc[m][n] = mfma32(a[st & 1][m], bb[st & 1][n], acc[m][n]);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (c + 1 < NCH) {
                 store_w(buf ^ 1);
