@@ -86,6 +86,43 @@ def test_knn_ids_and_distances(native, dev, n_rows, n_q):
     assert np.allclose(d2, d2_ref, rtol=2e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("dim,n_rows,n_q", [(256, 3000, 20), (256, 3000, 200), (768, 777, 33), (768, 5, 3), (768, 40, 64)])
+def test_knn_edge_shapes_and_ties(native, dev, dim, n_rows, n_q):
+    """v1 models (256-dim features), row counts that are not tile multiples, fewer rows than k, and exact duplicates:
+    equal distances keep the lower row id first (faiss' IndexFlat order), missing neighbours come back as id -1."""
+    g = torch.Generator().manual_seed(dim + n_rows + n_q)
+    index = torch.randn(n_rows, dim, generator=g) * 0.4
+    if n_rows >= 40:
+        index[n_rows // 2] = index[3]            # exact duplicates of rows 3 and 7 further down
+        index[n_rows - 1] = index[7]
+    q = index[torch.randint(0, n_rows, (n_q,), generator=g)] + 0.02 * torch.randn(n_q, dim, generator=g)
+    if n_rows >= 40:
+        q[0], q[1] = index[3], index[7]          # distance 0 to both copies
+    ix = index.to(dev)
+    d2, ids = native.knn_search(ix, native.knn_index_norms(ix), q.to(dev))
+    d2, ids = d2.cpu(), ids.cpu()
+    # explicit sum of squared differences in float64: duplicates get EXACTLY equal distances (cdist's GEMM form does not)
+    d_ref = torch.stack([((qi.double()[None, :] - index.double()) ** 2).sum(1) for qi in q])
+    k_eff = min(8, n_rows)
+    full = torch.argsort(d_ref, dim=1, stable=True)
+    order = full[:, :k_eff]
+    d_sorted = torch.gather(d_ref, 1, order)
+    assert torch.allclose(d2[:, :k_eff].double(), d_sorted, rtol=2e-4, atol=2e-3)
+    if n_rows < 8:
+        assert (ids[:, n_rows:] == -1).all() and torch.isinf(d2[:, n_rows:]).all()
+        assert (torch.sort(ids[:, :n_rows], 1).values == torch.arange(n_rows)).all()
+    else:
+        # ids equal wherever the float64 distances are separated by more than fp32 resolution of the norms
+        d9 = torch.gather(d_ref, 1, full[:, :min(9, n_rows)])
+        gaps = d9[:, 1:] - d9[:, :-1]
+        gaps = torch.where(gaps == 0, torch.full_like(gaps, 1.0), gaps)      # exact ties are decided by the id rule
+        gap_ok = gaps.min(1).values > 5e-3
+        assert gap_ok.float().mean() > 0.5
+        assert (ids[gap_ok] == order[gap_ok]).all()
+    if n_rows >= 40:
+        assert ids[0, 0] == 3 and ids[0, 1] == n_rows // 2 and ids[1, 0] == 7 and ids[1, 1] == n_rows - 1
+
+
 def test_knn_golden_and_blend(native, dev):
     from rvc_amd.lib import synthetic as S
     g = load_golden("knn")
