@@ -21,91 +21,158 @@
 
 namespace rvc {
 
-constexpr int ATT_D = 64;
+constexpr int ATT_W = 10;            // relative-position window of the TextEncoder (attentions.py:94-100)
+constexpr int ATT_NREL = 2 * ATT_W + 1;
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// Software pipeline (per wave, one 32-key tile per step): the 32 score MFMAs of tile t+1 are issued BEFORE the softmax of
+struct AttParams {
+    const float *qkv;      // [B][T][3][H][D]
+    const float *emb_k;    // [2W+1][D] or null   (REL)
+    const float *emb_v;    // [2W+1][D] or null   (REL)
+    float *out;            // [B][T][H*D]                         (n_splits == 1)
+    float *part_o;         // [B][H][n_splits][T][D]  unnormalised (n_splits > 1)
+    float *part_ml;        // [B][H][n_splits][T][2]  running max (log2 domain), row sum
+    int64_t T;
+    int n_heads, n_splits, tiles_per_split;
+    float scale_log2e;
+};
+
+// Software pipeline (per wave, one 32-key tile per step): the score MFMAs of tile t+1 are issued BEFORE the softmax of
 // tile t, which does not depend on them, so the scheduler can fill the matrix pipe's 64-cycle slots with the softmax
 // VALU work; K fragments are loaded two tiles ahead, V fragments one step ahead of their use.  The running max is
 // applied lazily: the accumulators are rescaled only when some query's max grew by more than 2^8 since the last
 // rescale (after the first tiles: almost never), which is exact in real arithmetic and saves ~80 register moves and
 // multiplies per tile.  Addresses are a uniform base plus per-lane 32-bit byte offsets computed once.
+//
+// D = head dim (64: HuBERT, 96: TextEncoder).  blockIdx.z selects a contiguous range of key tiles ("split"): with few
+// (query tile, head) pairs -- the TextEncoder has 100 x 2 -- the keys are cut so that ~1000 waves exist, each split
+// writes its unnormalised accumulator + (max, sum) and attention_combine_kernel merges them.
+//
+// REL: the window-10 relative-position terms of VITS' MultiHeadAttention (attentions.py:115-141, 156-180):
+//   score[i][j] += q_i . emb_k[j - i + W]   and   out_i += sum_r p[i][i + r - W] emb_v[r]     for |j - i| <= W.
+// The 21 logits per query are one extra 32x32 MFMA tile (emb_k zero-padded to 32 rows against the query fragment),
+// parked in LDS; the band of probabilities is written to LDS as the diagonal tiles pass and contracted with emb_v by
+// 16 more MFMA steps at the end.  Only the split that owns the diagonal sees non-zero band entries.
+template <int D, bool REL>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
-attention_qkv_kernel(const float *__restrict__ qkv, float *__restrict__ out, int64_t T, int n_heads, float scale_log2e) {
+attention_qkv_kernel(const AttParams p) {
+    constexpr int NJ = D / 8;       // dwordx4 pieces of a K/Q row per lane
+    constexpr int ND = D / 32;      // output row tiles
+    __shared__ float rel_s[REL ? 32 * 33 : 1];    // [query][r]  logits q . emb_k[r] (scaled, log2 domain)
+    __shared__ float band_s[REL ? 32 * 33 : 1];   // [query][r]  p[query][query + r - W], scaled like the accumulators
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    const int64_t T = p.T;
+    const int n_heads = p.n_heads;
     const int64_t q0 = (int64_t)blockIdx.x * 32;
-    const int head = blockIdx.y;
-    const int64_t b = blockIdx.z;
-    const int64_t rs = (int64_t)3 * n_heads * ATT_D;                 // floats between consecutive frames
-    const float *qp = qkv + b * T * rs + (int64_t)head * ATT_D;
-    const char *kp = reinterpret_cast<const char *>(qp + (int64_t)n_heads * ATT_D);
-    const char *vp = reinterpret_cast<const char *>(qp + (int64_t)2 * n_heads * ATT_D);
+    const int head = blockIdx.y % n_heads;
+    const int64_t b = blockIdx.y / n_heads;
+    const int split = blockIdx.z;
+    const int64_t rs = (int64_t)3 * n_heads * D;                      // floats between consecutive frames
+    const float *qp = p.qkv + b * T * rs + (int64_t)head * D;
+    const char *kp = reinterpret_cast<const char *>(qp + (int64_t)n_heads * D);
+    const char *vp = reinterpret_cast<const char *>(qp + (int64_t)2 * n_heads * D);
     const uint32_t rs_b = (uint32_t)rs * 4u;                          // bytes per frame (host checks T * rs_b < 4 GB)
-    const int nt = (int)((T + 31) / 32);
+    const int nt_all = (int)((T + 31) / 32);
+    const int t_begin = split * p.tiles_per_split;
+    const int t_end = min(nt_all, t_begin + p.tiles_per_split);
     const bool partial = (T & 31) != 0;
 
     // query fragment: lane (query j, half h) holds Q[q0 + j][8 jj + 4 h + e], pre-scaled by scale * log2(e)
-    f32x4 qf[8];
+    f32x4 qf[NJ];
     {
         const int64_t q = q0 + j < T ? q0 + j : T - 1;
-        const float *p = qp + q * rs + 4 * h;
+        const float *ptr = qp + q * rs + 4 * h;
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) qf[jj] = *reinterpret_cast<const f32x4 *>(p + 8 * jj) * scale_log2e;
+        for (int jj = 0; jj < NJ; ++jj) qf[jj] = *reinterpret_cast<const f32x4 *>(ptr + 8 * jj) * p.scale_log2e;
     }
     // K fragment of tile t: lane (key i = j, half h) reads K[32 t + i][8 jj + 4 h + e]; the row is clamped (masked later)
-    auto load_k = [&](f32x4 (&ka)[8], int t) __attribute__((always_inline)) {
+    auto load_k = [&](f32x4 (&ka)[NJ], int t) __attribute__((always_inline)) {
         const int64_t key = (int64_t)t * 32 + j;
         const uint32_t off = (uint32_t)(key < T ? key : T - 1) * rs_b + 16u * h;
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) ka[jj] = *reinterpret_cast<const f32x4 *>(kp + off + 32u * jj);
+        for (int jj = 0; jj < NJ; ++jj) ka[jj] = *reinterpret_cast<const f32x4 *>(kp + off + 32u * jj);
     };
-    // V^T fragment of step r: lane (dim i = j, half h) reads V[32 t + key_r(h)][i] and [i + 32]
+    // V^T fragment of step r: lane (dim i = j, half h) reads V[32 t + key_r(h)][i + 32 dt]
     uint32_t voff[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) voff[r] = (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * h) * rs_b + 4u * j;
-    auto load_v = [&](float (&va)[16][2], int t) __attribute__((always_inline)) {
+    auto load_v = [&](float (&va)[16][ND], int t) __attribute__((always_inline)) {
         const char *vt = vp + (int64_t)t * 32 * rs_b;                // uniform
-        if (t + 1 < nt || !partial) {
+        if (t + 1 < nt_all || !partial) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                va[r][0] = *reinterpret_cast<const float *>(vt + voff[r]);
-                va[r][1] = *reinterpret_cast<const float *>(vt + voff[r] + 128u);
-            }
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt) va[r][dt] = *reinterpret_cast<const float *>(vt + voff[r] + 128u * dt);
         } else {   // last, partial tile: rows past the end are clamped (their probability is exactly 0)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t key = (int64_t)t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const uint32_t off = (uint32_t)(key < T ? key : T - 1) * rs_b + 4u * j;
-                va[r][0] = *reinterpret_cast<const float *>(vp + off);
-                va[r][1] = *reinterpret_cast<const float *>(vp + off + 128u);
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt) va[r][dt] = *reinterpret_cast<const float *>(vp + off + 128u * dt);
             }
         }
     };
-    auto scores = [&](const f32x4 (&ka)[8]) __attribute__((always_inline)) {
+    auto scores = [&](const f32x4 (&ka)[NJ]) __attribute__((always_inline)) {
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj)
+        for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
             for (int e = 0; e < 4; ++e) s = mfma32(ka[jj][e], qf[jj][e], s);
         return s;
     };
 
-    f32x16 o0, o1;
+    f32x16 o[ND];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m = -INFINITY, l = 0.f;     // m: the max the accumulators are currently scaled by
 
+    if constexpr (REL) {
+        // rel_s[query][r] = (scaled q) . emb_k[r]: one MFMA tile with emb_k (zero rows beyond 2W) as the "A" operand
+        f32x4 ek[NJ];
+        const float *eptr = p.emb_k + (int64_t)(j < ATT_NREL ? j : 0) * D + 4 * h;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            ek[jj] = *reinterpret_cast<const f32x4 *>(eptr + 8 * jj);
+            if (j >= ATT_NREL) ek[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const f32x16 rl = scores(ek);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+            rel_s[j * 33 + rr] = rl[r];
+            band_s[j * 33 + rr] = 0.f;
+        }
+        __syncthreads();   // single-wave block: orders the LDS writes before the reads below
+    }
+
     // one step: S(t+1) from k_next into s_next, softmax + PV of tile t from s_cur; k_cur is refilled with K(t+2)
-    auto step = [&](int t, f32x4 (&k_cur)[8], const f32x4 (&k_next)[8], f32x16 &s_cur, f32x16 &s_next)
+    auto step = [&](int t, f32x4 (&k_cur)[NJ], const f32x4 (&k_next)[NJ], f32x16 &s_cur, f32x16 &s_next)
                     __attribute__((always_inline)) {
-        float va[16][2];
+        float va[16][ND];
         load_v(va, t);
-        if (t + 2 < nt) load_k(k_cur, t + 2);
-        if (t + 1 < nt) s_next = scores(k_next);
-        if (t + 1 == nt && partial) {
+        if (t + 2 < t_end) load_k(k_cur, t + 2);
+        if (t + 1 < t_end) s_next = scores(k_next);
+        // tiles whose keys can lie within W of one of this block's queries (wave-uniform)
+        const bool near_diag = REL && (int64_t)t * 32 + 31 + ATT_W >= q0 && (int64_t)t * 32 <= q0 + 31 + ATT_W;
+        int rr[16];
+        if constexpr (REL) {
+            if (near_diag) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    rr[r] = (int)((int64_t)t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h - (q0 + j)) + ATT_W;
+                    const bool in = rr[r] >= 0 && rr[r] < ATT_NREL;
+                    const float add = rel_s[j * 33 + (in ? rr[r] : 0)];
+                    s_cur[r] += in ? add : 0.f;
+                }
+            }
+        }
+        if (t + 1 == nt_all && partial) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 s_cur[r] = (int64_t)t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < T ? s_cur[r] : -INFINITY;
@@ -119,7 +186,13 @@ attention_qkv_kernel(const float *__restrict__ qkv, float *__restrict__ out, int
             const float alpha = fast_exp2(m - m_new);
             l *= alpha;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            if constexpr (REL) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) band_s[j * 33 + 2 * r + h] *= alpha;   // 32 entries per query, one half each
+            }
             m = m_new;
         }
         float psum = 0.f;
@@ -129,51 +202,161 @@ attention_qkv_kernel(const float *__restrict__ qkv, float *__restrict__ out, int
             psum += s_cur[r];
         }
         l += psum;
+        if constexpr (REL) {
+            if (near_diag) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            o0 = mfma32(va[r][0], s_cur[r], o0);
-            o1 = mfma32(va[r][1], s_cur[r], o1);
+                for (int r = 0; r < 16; ++r)
+                    if (rr[r] >= 0 && rr[r] < ATT_NREL) band_s[j * 33 + rr[r]] = s_cur[r];
+            }
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) o[dt] = mfma32(va[r][dt], s_cur[r], o[dt]);
     };
 
-    f32x4 ka[8], kb[8];
-    f32x16 sa, sb;
-    load_k(ka, 0);
-    if (nt > 1) load_k(kb, 1);
-    sa = scores(ka);
-    for (int t = 0; t < nt; t += 2) {
-        step(t, ka, kb, sa, sb);
-        if (t + 1 < nt) step(t + 1, kb, ka, sb, sa);
-    }
-    l += __shfl_xor(l, 32);
-    const float inv = 1.f / l;
-    if (q0 + j < T) {
-        float *op = out + (b * T + q0 + j) * (int64_t)n_heads * ATT_D + (int64_t)head * ATT_D + 4 * h;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 v0 = {o0[4 * g], o0[4 * g + 1], o0[4 * g + 2], o0[4 * g + 3]};
-            f32x4 v1 = {o1[4 * g], o1[4 * g + 1], o1[4 * g + 2], o1[4 * g + 3]};
-            *reinterpret_cast<f32x4 *>(op + 8 * g) = v0 * inv;
-            *reinterpret_cast<f32x4 *>(op + 32 + 8 * g) = v1 * inv;
+    if (t_begin < t_end) {
+        f32x4 ka[NJ], kb[NJ];
+        f32x16 sa, sb;
+        load_k(ka, t_begin);
+        if (t_begin + 1 < t_end) load_k(kb, t_begin + 1);
+        sa = scores(ka);
+        for (int t = t_begin; t < t_end; t += 2) {
+            step(t, ka, kb, sa, sb);
+            if (t + 1 < t_end) step(t + 1, kb, ka, sb, sa);
         }
     }
+    if constexpr (REL) {
+        // out += emb_v^T . band^T: k-pair of step s is (r = 2 s, r = 2 s + 1); rows r >= 2W+1 of the band are zero
+        __syncthreads();
+#pragma unroll
+        for (int sidx = 0; sidx < 16; ++sidx) {
+            const int r = 2 * sidx + h;
+            const float bval = band_s[j * 33 + r];
+            const float *ev = p.emb_v + (int64_t)(r < ATT_NREL ? r : 0) * D + j;
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) o[dt] = mfma32(ev[32 * dt], bval, o[dt]);
+        }
+    }
+    l += __shfl_xor(l, 32);
+    if (q0 + j < T) {
+        if (p.n_splits == 1) {
+            const float inv = 1.f / l;
+            float *op = p.out + (b * T + q0 + j) * (int64_t)n_heads * D + (int64_t)head * D + 4 * h;
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
+                    *reinterpret_cast<f32x4 *>(op + 32 * dt + 8 * g) = v * inv;
+                }
+        } else {
+            const int64_t row = ((b * n_heads + head) * p.n_splits + split) * T + q0 + j;
+            float *op = p.part_o + row * D + 4 * h;
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
+                    *reinterpret_cast<f32x4 *>(op + 32 * dt + 8 * g) = v;
+                }
+            if (h == 0) {
+                p.part_ml[row * 2] = m;
+                p.part_ml[row * 2 + 1] = l;
+            }
+        }
+    }
+}
+
+// out[b][t][head][:] = sum_s 2^(m_s - m*) O_s / sum_s 2^(m_s - m*) l_s over the key splits (an empty split has m = -inf)
+__global__ void __launch_bounds__(256)
+attention_combine_kernel(const float *__restrict__ part_o, const float *__restrict__ part_ml, float *__restrict__ out,
+                         int64_t T, int n_heads, int n_splits, int D) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;        // over (b, head, t, d / 4)
+    const int d4n = D / 4;
+    const int64_t total = (int64_t)gridDim.y * n_heads * T * d4n;
+    (void)total;
+    const int64_t b = blockIdx.y;
+    if (idx >= (int64_t)n_heads * T * d4n) return;
+    const int d4 = (int)(idx % d4n);
+    const int64_t t = (idx / d4n) % T;
+    const int head = (int)(idx / d4n / T);
+    float mstar = -INFINITY;
+    for (int s = 0; s < n_splits; ++s) mstar = fmaxf(mstar, part_ml[(((b * n_heads + head) * n_splits + s) * T + t) * 2]);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float lsum = 0.f;
+    for (int s = 0; s < n_splits; ++s) {
+        const int64_t row = ((b * n_heads + head) * n_splits + s) * T + t;
+        const float wgt = fast_exp2(part_ml[row * 2] - mstar);
+        lsum += wgt * part_ml[row * 2 + 1];
+        acc += *reinterpret_cast<const f32x4 *>(part_o + row * D + 4 * d4) * wgt;
+    }
+    *reinterpret_cast<f32x4 *>(out + (b * T + t) * (int64_t)n_heads * D + (int64_t)head * D + 4 * d4) = acc * (1.f / lsum);
+}
+
+// key splits: enough waves to cover the chip's 1024 SIMDs once, never more than the key tiles allow
+static int choose_splits(int64_t n_frames, int n_heads, int batch) {
+    const int64_t nt = ceil_div(n_frames, 32);
+    const int64_t pairs = nt * n_heads * batch;
+    int splits = (int)(1024 / (pairs > 0 ? pairs : 1));
+    if (splits < 1) splits = 1;
+    if (splits > 8) splits = 8;
+    if (splits > nt) splits = (int)nt;
+    return splits;
 }
 
 }  // namespace rvc
 
 using namespace rvc;
 
-extern "C" int rvc_attention_qkv_f32(const float *qkv_dev, float *out_dev, int batch, int64_t n_frames, int n_heads,
-                                     int head_dim, float scale, void *stream) {
+extern "C" int rvc_attention_workspace_bytes(int batch, int64_t n_frames, int n_heads, int head_dim, size_t *bytes) {
+    if (!bytes || batch <= 0 || n_heads <= 0 || n_frames < 0 || head_dim <= 0) return fail("rvc_attention_workspace_bytes: bad argument");
+    const int splits = choose_splits(n_frames, n_heads, batch);
+    const size_t rows = (size_t)batch * n_heads * splits * (size_t)n_frames;
+    *bytes = splits == 1 ? 256 : align_up(rows * head_dim * sizeof(float), 256) + align_up(rows * 2 * sizeof(float), 256);
+    return 0;
+}
+
+template <int D, bool REL>
+static int launch_attention(AttParams &p, int batch, hipStream_t stream) {
+    dim3 grid((unsigned)ceil_div(p.T, 32), (unsigned)(p.n_heads * batch), (unsigned)p.n_splits);
+    hipLaunchKernelGGL((attention_qkv_kernel<D, REL>), grid, dim3(64), 0, stream, p);
+    RVC_LAUNCH_CHECK();
+    if (p.n_splits > 1) {
+        const int64_t work = (int64_t)p.n_heads * p.T * (D / 4);
+        hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)ceil_div(work, 256), (unsigned)batch), dim3(256), 0, stream,
+                           p.part_o, p.part_ml, p.out, p.T, p.n_heads, p.n_splits, D);
+        RVC_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int rvc_attention_qkv_f32(const float *qkv_dev, const float *emb_rel_k_dev, const float *emb_rel_v_dev,
+                                     float *out_dev, int batch, int64_t n_frames, int n_heads, int head_dim, float scale,
+                                     void *workspace_dev, size_t workspace_bytes, void *stream) {
     if (!qkv_dev || !out_dev) return fail("rvc_attention_qkv_f32: null pointer");
-    if (head_dim != ATT_D) return fail("rvc_attention_qkv_f32: head_dim must be %d, got %d", ATT_D, head_dim);
+    if (head_dim != 64 && head_dim != 96) return fail("rvc_attention_qkv_f32: head_dim must be 64 or 96, got %d", head_dim);
+    if ((emb_rel_k_dev == nullptr) != (emb_rel_v_dev == nullptr)) return fail("rvc_attention_qkv_f32: emb_rel_k and emb_rel_v go together");
     if (batch <= 0 || n_heads <= 0 || n_frames < 0) return fail("rvc_attention_qkv_f32: bad shape");
     if (n_frames == 0) return 0;
-    if ((int64_t)n_frames * 3 * n_heads * ATT_D * 4 >= ((int64_t)1 << 32))
+    if ((int64_t)n_frames * 3 * n_heads * head_dim * 4 >= ((int64_t)1 << 32))
         return fail("rvc_attention_qkv_f32: one batch element of %lld frames exceeds the 4 GB the kernel addresses", (long long)n_frames);
-    dim3 grid((unsigned)ceil_div(n_frames, 32), (unsigned)n_heads, (unsigned)batch);
-    hipLaunchKernelGGL(attention_qkv_kernel, grid, dim3(64), 0, (hipStream_t)stream, qkv_dev, out_dev, n_frames, n_heads,
-                       scale * 1.4426950408889634f);
-    RVC_LAUNCH_CHECK();
-    return 0;
+    AttParams p;
+    p.qkv = qkv_dev; p.emb_k = emb_rel_k_dev; p.emb_v = emb_rel_v_dev; p.out = out_dev;
+    p.T = n_frames; p.n_heads = n_heads; p.scale_log2e = scale * 1.4426950408889634f;
+    p.n_splits = choose_splits(n_frames, n_heads, batch);
+    p.tiles_per_split = (int)ceil_div(ceil_div(n_frames, 32), p.n_splits);
+    p.part_o = nullptr; p.part_ml = nullptr;
+    if (p.n_splits > 1) {
+        size_t need = 0;
+        if (rvc_attention_workspace_bytes(batch, n_frames, n_heads, head_dim, &need)) return 1;
+        if (!workspace_dev || workspace_bytes < need) return fail("rvc_attention_qkv_f32: workspace too small (%zu < %zu)", workspace_bytes, need);
+        const size_t rows = (size_t)batch * n_heads * p.n_splits * (size_t)n_frames;
+        p.part_o = (float *)workspace_dev;
+        p.part_ml = (float *)((char *)workspace_dev + align_up(rows * head_dim * sizeof(float), 256));
+    }
+    const bool rel = emb_rel_k_dev != nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    if (head_dim == 64) return rel ? launch_attention<64, true>(p, batch, st) : launch_attention<64, false>(p, batch, st);
+    return rel ? launch_attention<96, true>(p, batch, st) : launch_attention<96, false>(p, batch, st);
 }

@@ -59,7 +59,9 @@ SYMBOLS = {
     "rvc_bigru_workspace_bytes": (c_int, [c_int, POINTER(c_size_t)]),
     "rvc_bigru_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_size_t,
                                   c_void_p]),
-    "rvc_attention_qkv_f32": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_float, c_void_p]),
+    "rvc_attention_workspace_bytes": (c_int, [c_int, c_int64, c_int, c_int, POINTER(c_size_t)]),
+    "rvc_attention_qkv_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_float,
+                                      c_void_p, c_size_t, c_void_p]),
     "rvc_decoder_create": (c_int, [POINTER(DecoderConfig), POINTER(c_void_p)]),
     "rvc_decoder_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]),
     "rvc_decoder_finalize": (c_int, [c_void_p]),
@@ -218,14 +220,24 @@ def bigru_forward(gi: torch.Tensor, whh_t: torch.Tensor, bhh: torch.Tensor, mult
 
 
 # ---- HuBERT attention -------------------------------------------------------------------------------
-def attention_qkv(qkv: torch.Tensor, n_heads: int, scale: float) -> torch.Tensor:
-    """qkv [B, T, 3 * n_heads * 64] (fused projection output) -> softmax(q k^T * scale) v as [B, T, n_heads * 64]."""
+def attention_qkv(qkv: torch.Tensor, n_heads: int, scale: float, emb_rel_k: torch.Tensor = None,
+                  emb_rel_v: torch.Tensor = None) -> torch.Tensor:
+    """qkv [B, T, 3 * n_heads * d] (fused projection output, d = 64 or 96) -> softmax(q k^T * scale [+ rel]) v [+ rel]
+    as [B, T, n_heads * d].  emb_rel_k / emb_rel_v [21, d]: the TextEncoder's relative-position embeddings."""
     assert qkv.is_cuda and qkv.dtype == torch.float32 and qkv.is_contiguous() and qkv.dim() == 3
     b, t, c = qkv.shape
     hd = c // (3 * n_heads)
+    rel = emb_rel_k is not None
+    if rel:
+        for e in (emb_rel_k, emb_rel_v):
+            assert e.is_cuda and e.dtype == torch.float32 and e.is_contiguous() and tuple(e.shape) == (21, hd)
     out = torch.empty(b, t, n_heads * hd, dtype=torch.float32, device=qkv.device)
-    _check(_lib.rvc_attention_qkv_f32(qkv.data_ptr(), out.data_ptr(), b, t, n_heads, hd, float(scale), _stream()),
-           "rvc_attention_qkv_f32")
+    need = c_size_t()
+    _check(_lib.rvc_attention_workspace_bytes(b, t, n_heads, hd, ctypes.byref(need)), "rvc_attention_workspace_bytes")
+    ws = _ws.get("attention", need.value, qkv.device)
+    _check(_lib.rvc_attention_qkv_f32(qkv.data_ptr(), emb_rel_k.data_ptr() if rel else None,
+                                      emb_rel_v.data_ptr() if rel else None, out.data_ptr(), b, t, n_heads, hd,
+                                      float(scale), ws.data_ptr(), ws.numel(), _stream()), "rvc_attention_qkv_f32")
     return out
 
 

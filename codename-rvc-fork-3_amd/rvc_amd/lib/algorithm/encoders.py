@@ -22,7 +22,25 @@ def channel_layer_norm(x, gamma, beta, eps=1e-5):
     return F.layer_norm(x.transpose(1, -1), (x.shape[1],), gamma, beta, eps).transpose(1, -1)
 
 
+def _rel_attention_hip(x, w: Dict[str, torch.Tensor], p: str, n_heads: int):
+    """Unmasked layer on the GPU: one fused q/k/v GEMM, librvc_amd K7 (scores, relative terms, softmax, PV in one
+    launch + a split combine), output projection.  Time-major in between, so no [T, T] tensor is ever materialised."""
+    from rvc_amd import _native
+    if p + ".qkv.weight" not in w:   # fused once per state dict
+        w[p + ".qkv.weight"] = torch.cat([w[p + f".conv_{n}.weight"][:, :, 0] for n in "qkv"], 0).contiguous()
+        w[p + ".qkv.bias"] = torch.cat([w[p + f".conv_{n}.bias"] for n in "qkv"], 0).contiguous()
+        w[p + ".o.weight"] = w[p + ".conv_o.weight"][:, :, 0].contiguous()
+        w[p + ".ek"] = w[p + ".emb_rel_k"][0].contiguous()
+        w[p + ".ev"] = w[p + ".emb_rel_v"][0].contiguous()
+    d = x.shape[1]
+    qkv = F.linear(x.transpose(1, 2), w[p + ".qkv.weight"], w[p + ".qkv.bias"]).contiguous()
+    a = _native.attention_qkv(qkv, n_heads, 1.0 / math.sqrt(d // n_heads), w[p + ".ek"], w[p + ".ev"])
+    return F.linear(a, w[p + ".o.weight"], w[p + ".conv_o.bias"]).transpose(1, 2)
+
+
 def rel_attention(x, w: Dict[str, torch.Tensor], p: str, n_heads: int, attn_mask: Optional[torch.Tensor]):
+    if x.is_cuda and attn_mask is None and w[p + ".emb_rel_k"].shape[0] == 1 and (x.shape[1] // n_heads) in (64, 96):
+        return _rel_attention_hip(x, w, p, n_heads)
     q = F.conv1d(x, w[p + ".conv_q.weight"], w[p + ".conv_q.bias"])
     k = F.conv1d(x, w[p + ".conv_k.weight"], w[p + ".conv_k.bias"])
     v = F.conv1d(x, w[p + ".conv_v.weight"], w[p + ".conv_v.bias"])

@@ -95,14 +95,22 @@ int rvc_bigru_workspace_bytes(int batch, size_t *bytes);
 int rvc_bigru_forward(const float *gi_dev, const float *whhT_dev, const float *bhh_dev, float *out_dev,
                       int batch, int64_t n_steps, int hidden, void *workspace_dev, size_t workspace_bytes, void *stream);
 
-/* ---- K7: HuBERT self-attention ---------------------------------------------------------------- *
- * Replaces the softmax(Q K^T * scale) V of transformers' HubertAttention inside `model(feats)["last_hidden_state"]`
- * (call site rvc/infer/pipeline.py:450, wrapper rvc/lib/utils.py:31-34; third-party arithmetic, no mask, no dropout at
- * inference).  qkv_dev [batch][n_frames][3][n_heads][head_dim] is the output of ONE fused q/k/v projection GEMM (the
- * caller's); out_dev [batch][n_frames][n_heads * head_dim] is the layout out_proj consumes.  head_dim must be 64.
- * fp32 throughout (matrix cores in exact-fp32 mode); exp is evaluated as 2^(x log2 e) on the hardware exp unit. */
-int rvc_attention_qkv_f32(const float *qkv_dev, float *out_dev, int batch, int64_t n_frames, int n_heads, int head_dim,
-                          float scale, void *stream);
+/* ---- K7: softmax attention (HuBERT encoder layers, TextEncoder relative-position layers) ------- *
+ * Replaces (a) the softmax(Q K^T * scale) V of transformers' HubertAttention inside
+ * `model(feats)["last_hidden_state"]` (call site rvc/infer/pipeline.py:450, wrapper rvc/lib/utils.py:31-34; third-party
+ * arithmetic, no mask, no dropout at inference) and (b) `MultiHeadAttention.attention` of the TextEncoder
+ * (rvc/lib/algorithm/attentions.py:101-141 with the window-10 relative-position terms of :115-141, 143-180; unmasked,
+ * i.e. all frames valid).
+ * qkv_dev [batch][n_frames][3][n_heads][head_dim] is the output of ONE fused q/k/v projection GEMM (the caller's);
+ * out_dev [batch][n_frames][n_heads * head_dim] is the layout the output projection consumes.  head_dim: 64 or 96.
+ * emb_rel_k_dev / emb_rel_v_dev: [21][head_dim] relative-position embeddings shared by the heads (both or neither):
+ *   score[i][j] += scale * q_i . emb_rel_k[j - i + 10],  out_i += sum_r p[i][i + r - 10] emb_rel_v[r],  |j - i| <= 10.
+ * fp32 throughout (matrix cores in exact-fp32 mode); exp is evaluated as 2^(x log2 e) on the hardware exp unit.
+ * workspace_dev: rvc_attention_workspace_bytes() bytes (partial results when the keys are split across waves). */
+int rvc_attention_workspace_bytes(int batch, int64_t n_frames, int n_heads, int head_dim, size_t *bytes);
+int rvc_attention_qkv_f32(const float *qkv_dev, const float *emb_rel_k_dev, const float *emb_rel_v_dev, float *out_dev,
+                          int batch, int64_t n_frames, int n_heads, int head_dim, float scale, void *workspace_dev,
+                          size_t workspace_bytes, void *stream);
 
 /* ---- K2/K3: vocoder ("dec" of Synthesizer) ---------------------------------------------------- *
  * Replaces `self.dec(z * x_mask, nsff0, g=g)` at rvc/lib/algorithm/synthesizers.py:254-258, i.e.

@@ -263,19 +263,42 @@ def test_bigru_matches_torch_gru(native, dev, batch, steps, multi_cu):
     assert (out - ref).abs().max().item() <= 2e-5
 
 
-# ---- K7 HuBERT attention -----------------------------------------------------------------------------
-@pytest.mark.parametrize("batch,frames,heads", [(1, 1, 12), (1, 31, 2), (2, 97, 12), (1, 1599, 12), (1, 64, 3)])
-def test_attention_matches_float64_softmax(native, dev, batch, frames, heads):
-    """softmax(q k^T / 8) v against a float64 evaluation of the same formula (what transformers' HubertAttention
-    computes, modeling_hubert.py eager path), on the fused-projection layout [B, T, 3, H, 64]."""
+# ---- K7 attention ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("batch,frames,heads,hd", [(1, 1, 12, 64), (1, 31, 2, 64), (2, 97, 12, 64), (1, 1599, 12, 64),
+                                                   (1, 64, 3, 64), (1, 200, 2, 96), (2, 333, 2, 96)])
+def test_attention_matches_float64_softmax(native, dev, batch, frames, heads, hd):
+    """softmax(q k^T / sqrt(d)) v against a float64 evaluation of the same formula (what transformers' HubertAttention
+    computes, modeling_hubert.py eager path), on the fused-projection layout [B, T, 3, H, d]; key splits included."""
     torch.manual_seed(frames)
-    qkv = torch.randn(batch, frames, 3 * heads * 64) * 1.5
-    got = native.attention_qkv(qkv.to(dev), heads, 0.125).cpu()
-    v = qkv.double().view(batch, frames, 3, heads, 64).permute(2, 0, 3, 1, 4)
-    ref = (torch.softmax(v[0] @ v[1].transpose(-1, -2) * 0.125, -1) @ v[2]).transpose(1, 2).reshape(batch, frames, -1)
+    qkv = torch.randn(batch, frames, 3 * heads * hd) * 1.5
+    got = native.attention_qkv(qkv.to(dev), heads, hd ** -0.5).cpu()
+    v = qkv.double().view(batch, frames, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(v[0] @ v[1].transpose(-1, -2) * hd ** -0.5, -1) @ v[2]).transpose(1, 2).reshape(batch, frames, -1)
     assert got.shape == ref.shape and torch.isfinite(got).all()
     # tolerance: fp32 dot products of 64 terms and a 2^x hardware exp (1 ulp) under a row sum -> a few 1e-6 relative
     assert (got.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("batch,frames,heads,hd", [(1, 5, 2, 96), (1, 64, 2, 96), (2, 171, 2, 96), (1, 3198, 2, 96), (1, 100, 3, 64)])
+def test_relative_attention_matches_oracle(native, dev, batch, frames, heads, hd):
+    """TextEncoder attention with window-10 relative-position terms against the oracle's restatement of
+    attentions.py:101-180 (pad/reshape formulation, float64)."""
+    from oracle import rvc_oracle as O
+    torch.manual_seed(frames + hd)
+    c = heads * hd
+    x = torch.randn(batch, c, frames)
+    w = {"a.emb_rel_k": torch.randn(1, 21, hd) * hd ** -0.5, "a.emb_rel_v": torch.randn(1, 21, hd) * hd ** -0.5,
+         "a.conv_o.weight": torch.eye(c).unsqueeze(-1), "a.conv_o.bias": torch.zeros(c)}
+    for n in "qkv":
+        w[f"a.conv_{n}.weight"] = torch.randn(c, c, 1) * c ** -0.5
+        w[f"a.conv_{n}.bias"] = torch.randn(c) * 0.1
+    ref = O._rel_attention(x.double(), {k: v.double() for k, v in w.items()}, "a", n_heads=heads)
+    qkv = F.linear(x.transpose(1, 2), torch.cat([w[f"a.conv_{n}.weight"][:, :, 0] for n in "qkv"], 0),
+                   torch.cat([w[f"a.conv_{n}.bias"] for n in "qkv"], 0)).contiguous()
+    got = native.attention_qkv(qkv.to(dev), heads, hd ** -0.5, w["a.emb_rel_k"][0].contiguous().to(dev),
+                               w["a.emb_rel_v"][0].contiguous().to(dev)).cpu().transpose(1, 2)
+    assert got.shape == ref.shape and torch.isfinite(got).all()
+    assert (got.double() - ref).abs().max().item() <= 3e-5 * max(1.0, ref.abs().max().item())
 
 
 # ---- K6 filtfilt -------------------------------------------------------------------------------------
