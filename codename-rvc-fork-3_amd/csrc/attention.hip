@@ -17,6 +17,8 @@
 //
 // Work per wave: 64 MFMAs (4096 cycles) per 32 keys; a cfg-2 layer is 600 independent waves (50 query tiles x 12 heads)
 // for 1024 SIMDs, so a layer takes about one wave's time.  K/V of a head (2 x 409 KB) stay in L2.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace rvc {
@@ -294,15 +296,21 @@ attention_combine_kernel(const float *__restrict__ part_o, const float *__restri
     *reinterpret_cast<f32x4 *>(out + (b * T + t) * (int64_t)n_heads * D + (int64_t)head * D + 4 * d4) = acc * (1.f / lsum);
 }
 
-// key splits: enough waves to cover the chip's 1024 SIMDs once, never more than the key tiles allow
+// key splits: the kernel runs one wave per (query tile, head, split); a layer takes ceil(waves / 1024 SIMDs) rounds of
+// 1/splits of the keys each.  Pick the split count that minimises rounds / splits (fewer splits on a tie: each one
+// re-loads the query fragment and adds a partial to combine).
 static int choose_splits(int64_t n_frames, int n_heads, int batch) {
+    static const int forced = getenv("RVC_ATT_SPLITS") ? atoi(getenv("RVC_ATT_SPLITS")) : 0;
     const int64_t nt = ceil_div(n_frames, 32);
     const int64_t pairs = nt * n_heads * batch;
-    int splits = (int)(1024 / (pairs > 0 ? pairs : 1));
-    if (splits < 1) splits = 1;
-    if (splits > 8) splits = 8;
-    if (splits > nt) splits = (int)nt;
-    return splits;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= 8 && s <= nt; ++s) {
+        const double cost = (double)ceil_div(pairs * s, 1024) / s + 0.02 * s;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+    }
+    if (forced > 0 && forced <= nt) best = forced;
+    return best;
 }
 
 }  // namespace rvc
