@@ -31,69 +31,179 @@ struct FiltCoef {
     double zi[FF_ORD];
 };
 
-// forward pass input: odd extension of x; backward pass input: the forward output reversed
+// forward pass input: odd extension of x; backward pass input: the forward output reversed.  Branch-free: one
+// unconditional load from a clamped index, the odd reflection applied afterwards (a load inside a divergent branch is
+// waited for before the branch closes).  i outside [0, ne) returns a finite dummy that the caller does not use.
 __device__ __forceinline__ double ff_input(const double *__restrict__ x, int64_t n, const double *__restrict__ yf,
                                            int64_t i, int backward) {
     const int64_t ne = n + 2 * FF_PAD;
-    if (backward) return yf[ne - 1 - i];
-    if (i < FF_PAD) return 2.0 * x[0] - x[FF_PAD - i];
-    if (i >= FF_PAD + n) return 2.0 * x[n - 1] - x[n - 2 - (i - FF_PAD - n)];
-    return x[i - FF_PAD];
+    i = i < 0 ? 0 : (i >= ne ? ne - 1 : i);
+    if (backward) return yf[ne - 1 - i];                     // uniform branch
+    const bool left = i < FF_PAD, right = i >= FF_PAD + n;
+    const int64_t idx = left ? FF_PAD - i : (right ? n - 2 - (i - FF_PAD - n) : i - FF_PAD);
+    const double v = x[idx];
+    const double edge = left ? x[0] : x[n - 1];
+    return (left || right) ? 2.0 * edge - v : v;
 }
 
 __device__ __forceinline__ double ff_step(const FiltCoef &c, double xv, double z[FF_ORD]) {
 #pragma clang fp contract(off)
     // scipy/signal/_lfilter.c.src: y = z0 + b0*x;  z_i = z_{i+1} + x*b_{i+1} - y*a_{i+1};  z_last = x*b_n - y*a_n
-    // plain operators under contract(off): the __dmul_rn/__dadd_rn helpers are ordinary operators that clang fuses
-    const double y = z[0] + c.b[0] * xv;
+    // plain operators under contract(off): the __dmul_rn/__dadd_rn helpers are ordinary operators that clang fuses.
+    // Same operations and operand order as SciPy's, written so that only three of the 21 are on the step-to-step
+    // dependency chain (y, y*a1, z0): a float64 VALU result takes ~25 cycles to come back, and the straightforward
+    // order (mul, dependent add, mul, dependent add, ...) made every one of them wait -- 550 cycles per sample.
+    double xb[FF_ORD + 1], t[FF_ORD], ya[FF_ORD];
 #pragma unroll
-    for (int i = 0; i < FF_ORD - 1; ++i) z[i] = (z[i + 1] + xv * c.b[i + 1]) - y * c.a[i + 1];
-    z[FF_ORD - 1] = xv * c.b[FF_ORD] - y * c.a[FF_ORD];
+    for (int i = 0; i <= FF_ORD; ++i) xb[i] = xv * c.b[i];          // independent of the state
+    const double y = z[0] + xb[0];
+#pragma unroll
+    for (int i = 0; i < FF_ORD - 1; ++i) t[i] = z[i + 1] + xb[i + 1];   // independent of y
+#pragma unroll
+    for (int i = 0; i < FF_ORD; ++i) ya[i] = y * c.a[i + 1];
+#pragma unroll
+    for (int i = 0; i < FF_ORD - 1; ++i) z[i] = t[i] - ya[i];
+    z[FF_ORD - 1] = xb[FF_ORD] - ya[FF_ORD - 1];
     return y;
 }
 
+// One wave = 64 consecutive chunks, one lane per chunk.  A lane walks its chunk sequentially, so a naive load touches
+// 64 different cache lines per step; instead the wave moves data in [64 chunks] x [32 steps] tiles through LDS: tile
+// rows are fetched as contiguous 256-byte pieces (two chunk rows per load instruction), one step-block ahead of the
+// recurrence, and the outputs of a step-block leave the same way.  Per-step cost drops from ~470 cycles (0.9 ms per
+// pass) to the float64 VALU work of the recurrence itself.
 // forward pass -> yf[ne]; backward pass -> out[n] (reversed back and cropped)
+constexpr int FF_SB = 32;              // steps per tile
+constexpr int FF_TS = FF_SB + 1;       // tile row stride in doubles (conflict-free ds_read_b64 down a column)
+
 __global__ void __launch_bounds__(64)
 ff_chunk_kernel(const double *__restrict__ x, int64_t n, const double *yf_in, int backward, FiltCoef c, int chunk,
                 int warm, int64_t n_chunks, double *yf_out, double *__restrict__ out) {
-    const int64_t ch = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= n_chunks) return;
+    __shared__ double tin[64 * FF_TS];
+    __shared__ double tout[64 * FF_TS];
+    const int lane = threadIdx.x, u = lane & 31, hrow = lane >> 5;
+    const int64_t ch0 = (int64_t)blockIdx.x * 64;
+    const int64_t ch = ch0 + lane;
     const int64_t ne = n + 2 * FF_PAD;
-    const int64_t i0 = ch * chunk, i1 = min(ne, i0 + chunk);
-    const int64_t w0 = i0 - warm;
+    const int64_t i0 = ch * chunk;                    // first output index of this lane's chunk
+    const int64_t w0 = i0 - warm;                     // first (virtual) index it runs from; steps with i < 0 are skipped
+    const int n_steps = warm + chunk;                 // multiple of FF_SB
     double z[FF_ORD];
-    int64_t i;
     if (w0 <= 0) {  // exact start: zi * first input sample (scipy.signal.filtfilt)
         const double x0 = ff_input(x, n, yf_in, 0, backward);
 #pragma unroll
         for (int k = 0; k < FF_ORD; ++k) z[k] = c.zi[k] * x0;
-        i = 0;
     } else {
 #pragma unroll
         for (int k = 0; k < FF_ORD; ++k) z[k] = 0.0;
-        i = w0;
     }
-    // the recurrence is serial but its inputs are not: fetch 8 samples ahead so the loads overlap the dependent chain
-    constexpr int PF = 8;
-    while (i < i1) {
-        double xin[PF];
+    // cooperative fetch of step-block sb: instruction k brings rows 2k (lanes 0-31) and 2k+1 (lanes 32-63)
+    double r[32];
+    // index range the whole wave touches in step-block sb (uniform): interior blocks take plain, branch-free loads
+    auto block_lo = [&](int sb) { return ch0 * chunk - warm + (int64_t)sb * FF_SB; };
+    // rows past the last chunk carry clamped dummy data and never store: they do not make a block an edge block
+    const int64_t last_row = min(ch0 + 63, n_chunks - 1);
+    auto block_hi = [&](int sb) { return last_row * chunk - warm + (int64_t)sb * FF_SB + FF_SB - 1; };
+    auto fetch = [&](int sb) __attribute__((always_inline)) {
+        const int64_t hi = block_hi(sb);
+        const int64_t base = (ch0 + hrow) * chunk - warm + (int64_t)sb * FF_SB + u;      // index of (row hrow, column u)
+        // forward: plain loads unless some row of this block holds indices of the left odd extension [0, FF_PAD) -- a row
+        // base is a multiple of 32, so that is the row whose base is exactly 0 -- or reaches the right extension.
+        // Rows still in their idle prefix (negative indices) are clamped to x[0]: their values are never used.
+        const int64_t zero_row = (warm - (int64_t)sb * FF_SB) / chunk;      // row whose base index is 0, if the division is exact
+        const bool has_left = (warm - (int64_t)sb * FF_SB) >= 0 && (warm - (int64_t)sb * FF_SB) % chunk == 0 &&
+                              zero_row >= ch0 && zero_row <= last_row;
+        if (!backward && !has_left && hi < FF_PAD + n) {
 #pragma unroll
-        for (int u = 0; u < PF; ++u) xin[u] = (i + u < i1) ? ff_input(x, n, yf_in, i + u, backward) : 0.0;
+            for (int k = 0; k < 32; ++k) {
+                const int64_t i = base + (min(ch0 + hrow + 2 * k, last_row) - (ch0 + hrow)) * chunk - FF_PAD;
+                r[k] = x[i < 0 ? 0 : i];
+            }
+        } else if (backward && hi < ne) {
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            if (i + u < i1) {
-                const double y = ff_step(c, xin[u], z);
-                if (i + u >= i0) {
+            for (int k = 0; k < 32; ++k) {
+                const int64_t i = base + (min(ch0 + hrow + 2 * k, last_row) - (ch0 + hrow)) * chunk;
+                r[k] = yf_in[ne - 1 - (i < 0 ? 0 : i)];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) r[k] = ff_input(x, n, yf_in, base + (int64_t)2 * k * chunk, backward);
+        }
+    };
+    fetch(0);
+    const int n_sb = n_steps / FF_SB;
+    const int out_sb0 = warm / FF_SB;                 // first step-block that produces outputs
+    for (int sb = 0; sb < n_sb; ++sb) {
+        __syncthreads();                              // previous tile fully consumed (single wave: a cheap fence)
+#pragma unroll
+        for (int k = 0; k < 32; ++k) tin[(2 * k + hrow) * FF_TS + u] = r[k];
+        if (sb + 1 < n_sb) fetch(sb + 1);
+        __syncthreads();
+        const int64_t ib = w0 + (int64_t)sb * FF_SB;
+        const bool emit = sb >= out_sb0;              // uniform
+        if (block_lo(sb) >= 0 && block_hi(sb) < ne) {
+            // interior (uniform): no per-step bounds checks; inputs read 8 ahead, outputs written 8 at a time
+#pragma unroll
+            for (int s8 = 0; s8 < FF_SB; s8 += 8) {
+                double xin[8], yo[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) xin[q] = tin[lane * FF_TS + s8 + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) yo[q] = ff_step(c, xin[q], z);
+                if (emit) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) tout[lane * FF_TS + s8 + q] = yo[q];
+                }
+            }
+        } else {
+            // a step-block that crosses either end of the extended signal for some lane (the first wave's warm-up,
+            // the last chunk).  A lane's first real step (i = 0) sits on a multiple of 8 (warm and chunk are), so inside
+            // a batch of 8 a lane is all-idle or all-active at the front end: one divergent branch per batch, no
+            // per-step selects.  Only the tail (i >= ne inside a batch) needs them.
+#pragma unroll 1
+            for (int s8 = 0; s8 < FF_SB; s8 += 8) {
+                const int64_t ia = ib + s8;
+                if (ia < 0 || ia >= ne) continue;                 // per lane: nothing to do in this batch
+                double xin[8], yo[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) xin[q] = tin[lane * FF_TS + s8 + q];
+                if (ia + 7 < ne) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) yo[q] = ff_step(c, xin[q], z);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        double zn[FF_ORD];
+#pragma unroll
+                        for (int k = 0; k < FF_ORD; ++k) zn[k] = z[k];
+                        yo[q] = ff_step(c, xin[q], zn);
+#pragma unroll
+                        for (int k = 0; k < FF_ORD; ++k) z[k] = ia + q < ne ? zn[k] : z[k];
+                    }
+                }
+                if (emit) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) tout[lane * FF_TS + s8 + q] = yo[q];
+                }
+            }
+        }
+        if (sb >= out_sb0) {                          // uniform: the last chunk / FF_SB step-blocks carry outputs
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const int64_t row_ch = ch0 + 2 * k + hrow;
+                const int64_t i = row_ch * chunk - warm + (int64_t)sb * FF_SB + u;   // index of tile element (row, u)
+                if (row_ch < n_chunks && i >= 0 && i < ne) {
+                    const double y = tout[(2 * k + hrow) * FF_TS + u];
                     if (!backward) {
-                        yf_out[i + u] = y;
+                        yf_out[i] = y;
                     } else {
-                        const int64_t j = ne - 1 - (i + u) - FF_PAD;   // position in the un-reversed, cropped output
-                        if (j >= 0 && j < n) out[j] = y;
+                        const int64_t jj = ne - 1 - i - FF_PAD;   // position in the un-reversed, cropped output
+                        if (jj >= 0 && jj < n) out[jj] = y;
                     }
                 }
             }
         }
-        i += PF;
     }
 }
 
@@ -103,6 +213,7 @@ using namespace rvc;
 
 constexpr int FF_CHUNK = 512;
 constexpr int FF_WARM = 4096;
+static_assert(FF_CHUNK % 32 == 0 && FF_WARM % 32 == 0, "chunk and warm-up are whole step-blocks");
 
 extern "C" int rvc_filtfilt_workspace_bytes(int64_t n, size_t *bytes) {
     if (!bytes || n <= FF_PAD) return fail("rvc_filtfilt_workspace_bytes: bad argument");
