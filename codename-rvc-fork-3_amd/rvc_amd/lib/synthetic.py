@@ -221,7 +221,7 @@ def _dec_refine(g: _Gen, rates, init_ch, inter=192, gin=256, rk=(3, 7, 11), nd=3
 
 def make_synth_checkpoint(sr: int = 48000, vocoder: str = "HiFi-GAN", seed: int = 0, *,
                           upsample_initial_channel: int = 512, spk_embed_dim: int = 109,
-                          half: bool = False) -> dict:
+                          half: bool = False, version: str = "v2") -> dict:
     """An in-memory equivalent of an exported ``.pth`` (extract_model.py:56-107).
 
     ``half=True`` stores the weights as fp16 exactly like real exports do
@@ -230,7 +230,7 @@ def make_synth_checkpoint(sr: int = 48000, vocoder: str = "HiFi-GAN", seed: int 
     cfg = config_list(sr, upsample_initial_channel=upsample_initial_channel, spk_embed_dim=spk_embed_dim)
     rates, ksizes = cfg[12], cfg[14]
     g = _Gen(seed)
-    _text_encoder(g)
+    _text_encoder(g, emb=768 if version == "v2" else 256)   # v1 models take the 256-dim final_proj features (infer.py:472)
     if vocoder == "MRF HiFi-GAN":
         _dec_mrf(g, rates, ksizes, upsample_initial_channel)
     elif vocoder == "RefineGAN":
@@ -244,7 +244,7 @@ def make_synth_checkpoint(sr: int = 48000, vocoder: str = "HiFi-GAN", seed: int 
         "weight": weight,
         "config": cfg,
         "f0": 1,
-        "version": "v2",
+        "version": version,
         "sr": sr,
         "vocoder": vocoder,
         "epoch": 0,

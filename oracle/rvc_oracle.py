@@ -755,6 +755,8 @@ def voice_conversion(hubert_sd, cpt, w, sid: Tensor, audio0: np.ndarray, pitch: 
     with torch.no_grad():
         feats = torch.from_numpy(audio0).float().view(1, -1)
         feats = hubert_forward(hubert_sd, feats)
+        if cpt.get("version", "v1") == "v1":  # pipeline.py:451-453
+            feats = F.linear(feats[0], hubert_sd["final_proj.weight"], hubert_sd["final_proj.bias"]).unsqueeze(0)
         feats0 = feats.clone()
         if big_npy is not None and index_rate > 0:
             feats, score, ix = retrieve_speaker_embeddings(feats, big_npy, index_rate, knn_dtype)

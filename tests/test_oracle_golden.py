@@ -153,3 +153,15 @@ def test_whole_pipeline(tag, sr):
                      protect=float(g["protect"]))
     assert out.shape == g["out"].shape
     assert rms(out - g["out"]) <= 1e-4, rms(out - g["out"])
+
+
+def test_whole_pipeline_v1_model():
+    """v1 checkpoints: 256-dim features through HuBERT's final_proj (pipeline.py:451-453); fixture from
+    tests/golden/make_golden_v1.py (the reference's Pipeline.pipeline, version="v1")."""
+    g = load_golden("pipeline_v1")
+    cpt = S.make_synth_checkpoint(40000, "HiFi-GAN", seed=2, version="v1")
+    torch.manual_seed(int(g["seed"]))
+    out = O.pipeline(S.make_hubert_state_dict(1), S.make_rmvpe_state_dict(0), cpt, g["audio"].copy(), sid=int(g["sid"]),
+                     big_npy=g["index"], index_rate=float(g["index_rate"]))
+    assert out.shape == g["out"].shape
+    assert rms(out - g["out"]) <= 2e-5
