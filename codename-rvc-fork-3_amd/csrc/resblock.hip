@@ -1,10 +1,9 @@
-// Fused ResBlock layer for the narrow vocoder stages (C = 32, 64):
+// Fused ResBlock layer for the narrowest vocoder stage (C = 32; C = 64 is built but off by default):
 //     y = conv2( leaky( conv1_d( leaky(x) ) ) ) + x  [+ running sum] [* 1/3]          (residuals.py:75-86, one dilation)
-// in ONE launch.  At C <= 64 the two convs of a layer are not MFMA-bound but latency-bound on their HBM phases
-// (measured with the unfused kernel: ~380 us of exposed load/store time per launch on 196 MB tensors, whatever the
-// FLOP count).  Fusing removes the intermediate's write + read and the separate residual read: per layer the
-// activation is read once and written once (2 tensor passes instead of 5), and the whole input tile is requested
-// in one burst so its HBM latency is paid once per block instead of once per 4-channel chunk.
+// in ONE launch.  At C = 32 a conv is only 64-230 flop per byte and its HBM phases are not hidden behind the MFMAs, so
+// the two convs of a layer as separate launches (5 tensor passes) lose to one launch that reads the activation once
+// and writes it once (2 passes): 238 / 453 / 676 us per layer at k = 3 / 7 / 11 against 2 x 187 / 272 / 356 us.
+// At C = 64 the wider unfused tiles win (464 vs 2 x 211 us at k = 3), see resblock_layer_supported().
 //
 // Block = 4 waves.  LDS holds the RAW input tile xs[C][N1 + (K-1)*dil] (leaky is applied when fragments are read,
 // 2 VALU ops per MFMA operand, because the residual needs the raw values), the intermediate tile ts[C][N1 + K - 1]
