@@ -1,0 +1,47 @@
+// K8 -- the per-conv epilogue of the RMVPE U-Net as ONE pass: out = relu(x + bias[c]) [+ res]
+// (ConvBlockRes.forward, rvc/lib/predictors/RMVPE.py:25-64 with eval-mode BatchNorm folded into the conv: bias is the
+// folded shift).  PyTorch runs this as a broadcast add, a ReLU and a residual add -- three launches and three trips
+// through HBM per conv, ~170 small launches per utterance.  HBM-bound: one read of x (and res), one write.
+#include "common.h"
+
+namespace rvc {
+
+__global__ void __launch_bounds__(256)
+bias_relu_add_kernel(const float *__restrict__ x, const float *__restrict__ bias, const float *__restrict__ res,
+                     float *__restrict__ out, int channels, int64_t inner4, int relu) {
+    // grid.y = batch * channels; a row of `inner` floats (multiple of 4) per (b, c)
+    const int64_t row = blockIdx.y;
+    const float bv = bias ? bias[row % channels] : 0.f;
+    const f32x4 *xr = reinterpret_cast<const f32x4 *>(x) + row * inner4;
+    const f32x4 *rr = res ? reinterpret_cast<const f32x4 *>(res) + row * inner4 : nullptr;
+    f32x4 *orow = reinterpret_cast<f32x4 *>(out) + row * inner4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < inner4; i += (int64_t)gridDim.x * 256) {
+        f32x4 v = xr[i] + bv;
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (rr) v += rr[i];
+        orow[i] = v;
+    }
+}
+
+}  // namespace rvc
+
+using namespace rvc;
+
+extern "C" int rvc_bias_relu_add_f32(const float *x_dev, const float *bias_dev, const float *res_dev, float *out_dev,
+                                     int batch, int channels, int64_t inner, int relu, void *stream) {
+    if (!x_dev || !out_dev) return fail("rvc_bias_relu_add_f32: null pointer");
+    if (batch <= 0 || channels <= 0 || inner < 0) return fail("rvc_bias_relu_add_f32: bad shape");
+    if (inner % 4) return fail("rvc_bias_relu_add_f32: the inner extent (%lld) must be a multiple of 4", (long long)inner);
+    if (inner == 0) return 0;
+    const int64_t inner4 = inner / 4;
+    int64_t bx = ceil_div(inner4, 256);
+    if (bx > 64) bx = 64;
+    dim3 grid((unsigned)bx, (unsigned)(batch * channels));
+    hipLaunchKernelGGL(bias_relu_add_kernel, grid, dim3(256), 0, (hipStream_t)stream, x_dev, bias_dev, res_dev, out_dev, channels,
+                       inner4, relu);
+    RVC_LAUNCH_CHECK();
+    return 0;
+}

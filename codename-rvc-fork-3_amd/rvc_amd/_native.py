@@ -62,6 +62,7 @@ SYMBOLS = {
     "rvc_attention_workspace_bytes": (c_int, [c_int, c_int64, c_int, c_int, POINTER(c_size_t)]),
     "rvc_attention_qkv_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_float,
                                       c_void_p, c_size_t, c_void_p]),
+    "rvc_bias_relu_add_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p]),
     "rvc_decoder_create": (c_int, [POINTER(DecoderConfig), POINTER(c_void_p)]),
     "rvc_decoder_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]),
     "rvc_decoder_finalize": (c_int, [c_void_p]),
@@ -239,6 +240,20 @@ def attention_qkv(qkv: torch.Tensor, n_heads: int, scale: float, emb_rel_k: torc
                                       emb_rel_v.data_ptr() if rel else None, out.data_ptr(), b, t, n_heads, hd,
                                       float(scale), ws.data_ptr(), ws.numel(), _stream()), "rvc_attention_qkv_f32")
     return out
+
+
+# ---- RMVPE U-Net conv epilogue ------------------------------------------------------------------------
+def bias_relu_add_(x: torch.Tensor, bias: torch.Tensor = None, res: torch.Tensor = None, relu: bool = True) -> torch.Tensor:
+    """In place: x = relu(x + bias[c]) + res for x [B, C, ...] (contiguous, trailing extent a multiple of 4)."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() >= 3
+    b, c = x.shape[0], x.shape[1]
+    inner = x.numel() // (b * c)
+    if res is not None:
+        assert res.is_cuda and res.dtype == torch.float32 and res.is_contiguous() and res.shape == x.shape
+    _check(_lib.rvc_bias_relu_add_f32(x.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                      res.data_ptr() if res is not None else None, x.data_ptr(), b, c, inner, int(relu),
+                                      _stream()), "rvc_bias_relu_add_f32")
+    return x
 
 
 # ---- conv1d (unit-test entry) ----------------------------------------------------------------------

@@ -75,6 +75,12 @@ class RMVPE0Predictor:
 
     def _block(self, x, p):
         w = self.w
+        if x.is_cuda and x.shape[-1] * x.shape[-2] % 4 == 0:
+            # conv by MIOpen; bias + ReLU (+ residual) as ONE pass of librvc_amd K8 instead of three PyTorch launches
+            from rvc_amd import _native
+            y = _native.bias_relu_add_(F.conv2d(x, w[p + ".c1.w"], None, 1, 1), w[p + ".c1.b"])
+            res = F.conv2d(x, w[p + ".sc.w"], w[p + ".sc.b"]) if p + ".sc.w" in w else x
+            return _native.bias_relu_add_(F.conv2d(y, w[p + ".c2.w"], None, 1, 1), w[p + ".c2.b"], res.contiguous())
         y = F.relu(F.conv2d(x, w[p + ".c1.w"], w[p + ".c1.b"], 1, 1))
         y = F.relu(F.conv2d(y, w[p + ".c2.w"], w[p + ".c2.b"], 1, 1))
         if p + ".sc.w" in w:
@@ -103,8 +109,13 @@ class RMVPE0Predictor:
                 x = self._block(x, f"unet.intermediate.layers.{i}.conv.{m}")
         for i in range(5):
             p = f"unet.decoder.layers.{i}"
-            x = F.relu(F.conv_transpose2d(x, w[p + ".up.w"], w[p + ".up.b"], stride=(2, 2), padding=(1, 1),
-                                          output_padding=(1, 1)))
+            if x.is_cuda:
+                from rvc_amd import _native
+                x = _native.bias_relu_add_(F.conv_transpose2d(x, w[p + ".up.w"], None, stride=(2, 2), padding=(1, 1),
+                                                              output_padding=(1, 1)).contiguous(), w[p + ".up.b"])
+            else:
+                x = F.relu(F.conv_transpose2d(x, w[p + ".up.w"], w[p + ".up.b"], stride=(2, 2), padding=(1, 1),
+                                              output_padding=(1, 1)))
             x = torch.cat((x, skips[-1 - i]), dim=1)
             for m in range(4):
                 x = self._block(x, f"{p}.conv2.{m}")

@@ -112,6 +112,14 @@ int rvc_attention_qkv_f32(const float *qkv_dev, const float *emb_rel_k_dev, cons
                           int batch, int64_t n_frames, int n_heads, int head_dim, float scale, void *workspace_dev,
                           size_t workspace_bytes, void *stream);
 
+/* ---- K8: conv epilogue of the RMVPE U-Net ------------------------------------------------------ *
+ * out = relu(x + bias[c]) + res, the tail of `ConvBlockRes.forward` (rvc/lib/predictors/RMVPE.py:25-64: conv ->
+ * BatchNorm (eval, folded by the caller: bias = folded shift) -> ReLU, and after the second conv `+ shortcut(x)` / `+ x`).
+ * x_dev/out_dev/res_dev [batch][channels][inner] (inner = H*W, a multiple of 4); bias_dev [channels] or NULL;
+ * res_dev NULL for no residual; relu 0/1; out_dev may alias x_dev. */
+int rvc_bias_relu_add_f32(const float *x_dev, const float *bias_dev, const float *res_dev, float *out_dev, int batch,
+                          int channels, int64_t inner, int relu, void *stream);
+
 /* ---- K2/K3: vocoder ("dec" of Synthesizer) ---------------------------------------------------- *
  * Replaces `self.dec(z * x_mask, nsff0, g=g)` at rvc/lib/algorithm/synthesizers.py:254-258, i.e.
  *   RVC_DEC_NSF    HiFiGANNSFGenerator.forward  rvc/lib/algorithm/generators/hifigan_nsf.py:173-207

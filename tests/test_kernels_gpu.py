@@ -301,6 +301,19 @@ def test_relative_attention_matches_oracle(native, dev, batch, frames, heads, hd
     assert (got.double() - ref).abs().max().item() <= 3e-5 * max(1.0, ref.abs().max().item())
 
 
+# ---- K8 conv epilogue --------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1, 16, 64, 128), (2, 3, 7, 4), (1, 256, 101, 4), (1, 1, 4)])
+def test_bias_relu_add_bit_exact(native, dev, shape):
+    torch.manual_seed(len(shape))
+    x, res, bias = torch.randn(*shape), torch.randn(*shape), torch.randn(shape[1])
+    bshape = [1, -1] + [1] * (len(shape) - 2)
+    want = torch.relu(x + bias.view(bshape)) + res
+    got = native.bias_relu_add_(x.clone().to(dev), bias.to(dev), res.to(dev)).cpu()
+    assert torch.equal(got, want)                      # same three fp32 operations in the same order
+    assert torch.equal(native.bias_relu_add_(x.clone().to(dev), bias.to(dev)).cpu(), torch.relu(x + bias.view(bshape)))
+    assert torch.equal(native.bias_relu_add_(x.clone().to(dev), None, res.to(dev), relu=False).cpu(), x + res)
+
+
 # ---- K6 filtfilt -------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n", [4000, 480_000, 19, 257])
 def test_filtfilt_matches_scipy(native, dev, n):
