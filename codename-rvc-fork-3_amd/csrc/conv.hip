@@ -381,9 +381,10 @@ int launch_conv(const ConvParams &p_in, hipStream_t stream) {
         case 1: return launch_kw<1>(p, stream);
         case 2: return launch_kw<2>(p, stream);
         case 3: return launch_kw<3>(p, stream);
+        case 5: return launch_kw<5>(p, stream);
         case 7: return launch_kw<7>(p, stream);
         case 11: return launch_kw<11>(p, stream);
-        default: return fail("conv: unsupported kernel size %d (1, 2, 3, 7, 11)", p.kw);
+        default: return fail("conv: unsupported kernel size %d (1, 2, 3, 5, 7, 11)", p.kw);
     }
 }
 

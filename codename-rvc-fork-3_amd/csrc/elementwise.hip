@@ -26,9 +26,35 @@ bias_relu_add_kernel(const float *__restrict__ x, const float *__restrict__ bias
     }
 }
 
+// WaveNet gate (commons.py:142-157 fused_add_tanh_sigmoid_multiply, the conditioning already added by the producing
+// conv's bias): acts[c][t] = tanh(x[c][t]) * sigmoid(x[H + c][t]),  x [B][2H][T] -> acts [B][H][T]
+__global__ void __launch_bounds__(256)
+gate_tanh_sigmoid_kernel(const float *__restrict__ x, float *__restrict__ out, int hidden, int64_t T) {
+    const int64_t b = blockIdx.z;
+    const int c = blockIdx.y;
+    const float *xa = x + (b * 2 * hidden + c) * T;
+    const float *xb = xa + (int64_t)hidden * T;
+    float *o = out + (b * hidden + c) * T;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < T; t += (int64_t)gridDim.x * 256)
+        o[t] = tanhf(xa[t]) * (1.f / (1.f + expf(-xb[t])));
+}
+
 }  // namespace rvc
 
 using namespace rvc;
+
+extern "C" int rvc_gate_tanh_sigmoid_f32(const float *x_dev, float *out_dev, int batch, int hidden, int64_t length,
+                                         void *stream) {
+    if (!x_dev || !out_dev) return fail("rvc_gate_tanh_sigmoid_f32: null pointer");
+    if (batch <= 0 || hidden <= 0 || length < 0) return fail("rvc_gate_tanh_sigmoid_f32: bad shape");
+    if (length == 0) return 0;
+    int64_t bx = ceil_div(length, 256);
+    if (bx > 16) bx = 16;
+    hipLaunchKernelGGL(gate_tanh_sigmoid_kernel, dim3((unsigned)bx, (unsigned)hidden, (unsigned)batch), dim3(256), 0,
+                       (hipStream_t)stream, x_dev, out_dev, hidden, length);
+    RVC_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int rvc_bias_relu_add_f32(const float *x_dev, const float *bias_dev, const float *res_dev, float *out_dev,
                                      int batch, int channels, int64_t inner, int relu, void *stream) {

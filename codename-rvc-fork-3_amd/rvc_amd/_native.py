@@ -63,6 +63,7 @@ SYMBOLS = {
     "rvc_attention_qkv_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_float,
                                       c_void_p, c_size_t, c_void_p]),
     "rvc_bias_relu_add_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p]),
+    "rvc_gate_tanh_sigmoid_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "rvc_decoder_create": (c_int, [POINTER(DecoderConfig), POINTER(c_void_p)]),
     "rvc_decoder_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]),
     "rvc_decoder_finalize": (c_int, [c_void_p]),
@@ -254,6 +255,15 @@ def bias_relu_add_(x: torch.Tensor, bias: torch.Tensor = None, res: torch.Tensor
                                       res.data_ptr() if res is not None else None, x.data_ptr(), b, c, inner, int(relu),
                                       _stream()), "rvc_bias_relu_add_f32")
     return x
+
+
+def gate_tanh_sigmoid(x: torch.Tensor) -> torch.Tensor:
+    """x [B, 2H, T] -> tanh(x[:, :H]) * sigmoid(x[:, H:]) [B, H, T]"""
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3 and x.shape[1] % 2 == 0
+    b, c2, t = x.shape
+    out = torch.empty(b, c2 // 2, t, dtype=torch.float32, device=x.device)
+    _check(_lib.rvc_gate_tanh_sigmoid_f32(x.data_ptr(), out.data_ptr(), b, c2 // 2, t, _stream()), "rvc_gate_tanh_sigmoid_f32")
+    return out
 
 
 # ---- conv1d (unit-test entry) ----------------------------------------------------------------------

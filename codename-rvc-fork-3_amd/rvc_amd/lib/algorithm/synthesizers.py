@@ -147,7 +147,8 @@ class Synthesizer:
             z_p, x_mask = z_p[:, :, head:], x_mask[:, :, head:]
             nsff0 = nsff0[:, head:]
             nz["src_randn"] = nz["src_randn"][:, head * self.upp:]
-        z = flow_reverse(w, z_p, x_mask, g, half=self.inter_channels // 2, hidden=self.hidden_channels)
+        full = phone_lengths_host is not None and rate is None and all(int(n) == t for n in phone_lengths_host)
+        z = flow_reverse(w, z_p, x_mask, g, half=self.inter_channels // 2, hidden=self.hidden_channels, full=full)
         o = self.dec.forward((z * x_mask).contiguous(), nsff0.float().contiguous(), g[:, :, 0].contiguous(),
                              src_randn=nz["src_randn"].contiguous(), src_rand=nz.get("src_rand"),
                              adain_randn=nz.get("adain_randn"))

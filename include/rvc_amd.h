@@ -120,6 +120,11 @@ int rvc_attention_qkv_f32(const float *qkv_dev, const float *emb_rel_k_dev, cons
 int rvc_bias_relu_add_f32(const float *x_dev, const float *bias_dev, const float *res_dev, float *out_dev, int batch,
                           int channels, int64_t inner, int relu, void *stream);
 
+/* WaveNet gate of the flow (rvc/lib/algorithm/commons.py:142-157, modules.py:93-97): acts = tanh(x[:H]) * sigmoid(x[H:]).
+ * x_dev [batch][2*hidden][length] (the conditioning is already inside: the producing conv adds it as its bias),
+ * out_dev [batch][hidden][length]. */
+int rvc_gate_tanh_sigmoid_f32(const float *x_dev, float *out_dev, int batch, int hidden, int64_t length, void *stream);
+
 /* ---- K2/K3: vocoder ("dec" of Synthesizer) ---------------------------------------------------- *
  * Replaces `self.dec(z * x_mask, nsff0, g=g)` at rvc/lib/algorithm/synthesizers.py:254-258, i.e.
  *   RVC_DEC_NSF    HiFiGANNSFGenerator.forward  rvc/lib/algorithm/generators/hifigan_nsf.py:173-207

@@ -30,7 +30,7 @@ for it in range(3):
     with torch.no_grad():
         if which in ("all", "hubert"): hub(wav)
         if which in ("all", "enc"): text_encoder(w, phone, pitch, lens)
-        if which in ("all", "flow"): flow_reverse(w, zp, mask, g)
+        if which in ("all", "flow"): flow_reverse(w, zp, mask, g, full=True)
         if which in ("all", "rmvpe"): rm.mel2hidden(mel, 3201)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -38,7 +38,7 @@ e0.record()
 with torch.no_grad():
     if which in ("all", "hubert"): hub(wav)
     if which in ("all", "enc"): text_encoder(w, phone, pitch, lens)
-    if which in ("all", "flow"): flow_reverse(w, zp, mask, g)
+    if which in ("all", "flow"): flow_reverse(w, zp, mask, g, full=True)
     if which in ("all", "rmvpe"): rm.mel2hidden(mel, 3201)
 e1.record(); torch.cuda.synchronize()
 print(f"{which}: {e0.elapsed_time(e1):.2f} ms (one more pass, HIP events)")
