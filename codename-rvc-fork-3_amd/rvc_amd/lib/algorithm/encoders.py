@@ -86,6 +86,17 @@ def text_encoder(w: Dict[str, torch.Tensor], phone, pitch, lengths, *, hidden=19
     full = all(int(n) == t for n in lengths_host) if lengths_host is not None else bool((lengths == t).all())
     attn_mask = None if full else x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
     pad = (kernel_size - 1) // 2
+    if full:   # every frame valid: the mask is all ones and multiplying by it is the identity (saves ~30 passes)
+        for i in range(n_layers):
+            y = rel_attention(x, w, f"enc_p.encoder.attn_layers.{i}", n_heads, None)
+            x = channel_layer_norm(x + y, w[f"enc_p.encoder.norm_layers_1.{i}.gamma"], w[f"enc_p.encoder.norm_layers_1.{i}.beta"])
+            f = f"enc_p.encoder.ffn_layers.{i}"
+            y = torch.relu_(F.conv1d(x, w[f + ".conv_1.weight"], w[f + ".conv_1.bias"], padding=pad))
+            y = F.conv1d(y, w[f + ".conv_2.weight"], w[f + ".conv_2.bias"], padding=pad)
+            x = channel_layer_norm(x + y, w[f"enc_p.encoder.norm_layers_2.{i}.gamma"], w[f"enc_p.encoder.norm_layers_2.{i}.beta"])
+        stats = F.conv1d(x, w["enc_p.proj.weight"], w["enc_p.proj.bias"])
+        m, logs = torch.split(stats, out_channels, dim=1)
+        return m, logs, x_mask
     x = x * x_mask
     for i in range(n_layers):
         y = rel_attention(x, w, f"enc_p.encoder.attn_layers.{i}", n_heads, attn_mask)
