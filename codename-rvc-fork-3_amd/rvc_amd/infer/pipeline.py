@@ -78,6 +78,17 @@ class AudioProcessor:
         return out.numpy() if as_numpy else out
 
 
+def _reflect_pad(x: torch.Tensor, pad: int) -> torch.Tensor:
+    """np.pad(x, (pad, pad), mode="reflect") for a 1-D device tensor, including pads longer than the signal (NumPy keeps
+    reflecting; torch's F.pad refuses): the even periodic extension with period 2 (n - 1)."""
+    n = x.shape[0]
+    if pad < n:
+        return F.pad(x.view(1, 1, -1), (pad, pad), mode="reflect").view(-1)
+    period = 2 * (n - 1)
+    m = torch.remainder(torch.arange(-pad, n + pad, device=x.device), period)
+    return x[torch.where(m < n, m, period - m)]
+
+
 class FeatureIndex:
     """Device-resident replacement of the faiss index + ``big_npy`` pair (pipeline.py:553-556).
 
@@ -319,7 +330,7 @@ class Pipeline:
         s = 0
         audio_opt = []
         t = None
-        audio_pad = F.pad(audio.view(1, 1, -1), (self.t_pad, self.t_pad), mode="reflect").view(-1)  # pipeline.py:581
+        audio_pad = _reflect_pad(audio, self.t_pad)  # pipeline.py:581
         p_len = audio_pad.shape[0] // self.window
         inp_f0 = None
         if hasattr(f0_file, "name"):  # pipeline.py:584-593

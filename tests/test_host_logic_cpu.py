@@ -120,6 +120,14 @@ def test_split_and_merge_match_reference_golden():
     assert np.asarray(process_audio(np.zeros(16000), 16000)[1]).tolist() == [[0, 16000]]
 
 
+def test_reflect_pad_longer_than_signal_equals_numpy():
+    import torch
+    from rvc_amd.infer.pipeline import _reflect_pad
+    for n, pad in ((11000, 16000), (5, 16), (50, 20), (2, 7)):
+        x = np.arange(n, dtype=np.float64) ** 1.5
+        assert np.array_equal(_reflect_pad(torch.from_numpy(x), pad).numpy(), np.pad(x, (pad, pad), mode="reflect"))
+
+
 def test_f0_file_override():
     p = _pipeline_cpu()
     f0 = np.full(400, 100.0)
