@@ -328,8 +328,7 @@ static int launch_cfg(const ConvParams &p, hipStream_t stream) {
     return 0;
 }
 
-// tuning knobs for experiments (tools/bench_conv.py): RVC_CONV_CIC=4|8 overrides the chunk depth,
-// RVC_CONV_TILE=1 selects the 128x256 block tile where it applies
+// tuning knobs for experiments (tools/bench_conv.py): RVC_CONV_CIC=4|8 overrides the chunk depth
 static int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -337,12 +336,9 @@ static int env_int(const char *name, int dflt) {
 
 template <int KW, int MT, int NT, int WM, int WN>
 static int launch_cic(const ConvParams &p, hipStream_t stream, int cic) {
-    switch (cic) {
-        case 4: return launch_cfg<KW, MT, NT, WM, WN, 4>(p, stream);
-        case 16:
-            if constexpr (KW <= 3) return launch_cfg<KW, MT, NT, WM, WN, 16>(p, stream);
-        default: return launch_cfg<KW, MT, NT, WM, WN, 8>(p, stream);
-    }
+    // 16-channel chunks were measured too (RVC_CONV_CIC=16 in an earlier build): slower everywhere (LDS per block, spills)
+    if (cic == 4) return launch_cfg<KW, MT, NT, WM, WN, 4>(p, stream);
+    return launch_cfg<KW, MT, NT, WM, WN, 8>(p, stream);
 }
 
 template <int KW>
