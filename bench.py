@@ -36,7 +36,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = 
 PEAK_HBM_GBS = 8000.0           # HBM3E spec
 # average HBM bytes per launch of the roofline kernel symbol at the cfg-2 shape, from the PMC passes committed under
 # profiles/ (cannot be collected inside bench.py: it needs rocprofv3)
-PMC_TRAFFIC_BYTES = 641.2e6
+PMC_TRAFFIC_BYTES = 641.0e6
 PMC_TRAFFIC_SOURCE = ("profiles/r01_pmc_conv.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
                       "tools/pmc_conv.py (this same launch mix); FETCH_SIZE calibrated on the same kernel at K=1 with known bytes")
 
