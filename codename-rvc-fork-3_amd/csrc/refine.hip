@@ -191,10 +191,25 @@ rg_down_kernel(const float *__restrict__ har, int64_t L, int stride, int pad, in
     const int64_t b = blockIdx.z;
     if (q >= l_out) return;
     const float *h = har + b * L;
+    const float *wk = w + (int64_t)co * K;
     float acc = 0.f;
-    for (int k = 0; k < K; ++k) {
-        const int64_t p = q * stride + k - pad;
-        acc += w[co * K + k] * ((p >= 0 && p < L) ? h[p] : 0.f);
+    const int64_t p0 = q * stride - pad;
+    if (p0 >= 0 && p0 + K <= L) {
+        // interior: unconditional loads, 8 in flight (a load inside a bounds check is waited for before the next one)
+        int k = 0;
+        for (; k + 8 <= K; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = h[p0 + k + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += wk[k + u] * v[u];
+        }
+        for (; k < K; ++k) acc += wk[k] * h[p0 + k];
+    } else {
+        for (int k = 0; k < K; ++k) {
+            const int64_t p = p0 + k;
+            acc += wk[k] * ((p >= 0 && p < L) ? h[p] : 0.f);
+        }
     }
     out[b * out_bstride + (int64_t)co * l_out + q] = acc + bias[co];
 }
