@@ -150,6 +150,9 @@ def main():
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
     total_samples, t_max = D.reduce_report(samples, elapsed, dev)
+    # outside the timed region: the last waveform must be finite and inside [-1, 1] (the BiGRU poisons its output with NaN if
+    # its workgroups ever fail to rendezvous; a silent NaN utterance must not count as throughput)
+    assert bool(torch.isfinite(out).all()) and float(out.abs().max()) <= 1.0, "bench produced a non-finite or unnormalised waveform"
 
     # PCIe-inclusive variant (host NumPy in, host NumPy out), reported beside `value`, never as `value`
     host_steps = min(args.steps, 4)
