@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--seconds", type=float, default=30.0, help="clip length (BASELINE cfg 2 = 30 s)")
     ap.add_argument("--index-rows", type=int, default=100_000)
+    ap.add_argument("--inflight", type=int, default=2, help="utterances in flight per GPU, each on its own HIP stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="clip length of the bounded CPU-baseline sample")
     args = ap.parse_args()
@@ -103,8 +104,11 @@ def main():
     rank, world, local = D.init_process_group()
     assert world == max(1, args.gpus) or world == 1, (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py measures the HIP path; there is no CPU fallback"
+    local = local % torch.cuda.device_count()   # ranks > devices only in the gloo control-flow test (RVC_DIST_BACKEND)
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
+    if world > 1:   # N host processes share the node's cores: keep each rank's CPU thread pool small
+        torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))
 
     from rvc_amd import _native
     from rvc_amd.infer.infer import VoiceConverter
@@ -135,19 +139,31 @@ def main():
         a = (audios_host if host_io else audios)[j % len(audios)]
         return vc.convert_array(a, index_path="", index_rate=0.75, protect=0.5, sid=0)
 
-    for j in range(args.warmup):
-        out = step(j)
+    # `--inflight` utterances are on the GPU at a time, each on its own HIP stream (VoiceConverter.convert_batch): the K
+    # timed steps are K utterances, interleaved 2 by 2 by default.  --inflight 1 is the strictly sequential schedule.
+    inflight = max(1, args.inflight)
+    kw = dict(index_path="", index_rate=0.75, protect=0.5, sid=0)
+    if inflight == 1:
+        for j in range(args.warmup):
+            out = step(j)
+    else:   # every stream warms up its own workspaces / side stream (W steps per stream)
+        vc.convert_batch([audios[j % len(audios)] for j in range(args.warmup * inflight)], inflight=inflight, **kw)
     if world > 1:
-        torch.distributed.barrier()
+        torch.distributed.barrier(**({} if os.environ.get("RVC_DIST_BACKEND") == "gloo" else {"device_ids": [local]}))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     samples = 0
-    for j in range(args.steps):
-        out = step(args.warmup + j)
-        samples += out.shape[0]
+    if inflight == 1:
+        for j in range(args.steps):
+            out = step(args.warmup + j)
+            samples += out.shape[0]
+    else:
+        outs = vc.convert_batch([audios[(args.warmup + j) % len(audios)] for j in range(args.steps)], inflight=inflight, **kw)
+        samples = sum(int(o.shape[0]) for o in outs)
+        out = outs[-1]
     torch.cuda.synchronize()
     if world > 1:
-        torch.distributed.barrier()
+        torch.distributed.barrier(**({} if os.environ.get("RVC_DIST_BACKEND") == "gloo" else {"device_ids": [local]}))
     elapsed = time.perf_counter() - t0
     total_samples, t_max = D.reduce_report(samples, elapsed, dev)
     # outside the timed region: the last waveform must be finite and inside [-1, 1] (the BiGRU poisons its output with NaN if
@@ -293,7 +309,8 @@ def main():
         "data": "synthetic (seeded random-init weights, FM-tone utterances, clustered index)",
         "rtf": round(value / sr, 2),
         "config": {"workload": f"BASELINE cfg 2: {args.seconds:g} s 16 kHz clip -> 48 kHz, HuBERT-base + NSF-HiFi-GAN 48k, "
-                               f"{args.index_rows}x768 index, index_rate 0.75, rmvpe, protect 0.5; 1 utterance per step per GPU",
+                               f"{args.index_rows}x768 index, index_rate 0.75, rmvpe, protect 0.5; 1 utterance per step per GPU, "
+                               f"{max(1, args.inflight)} utterance(s) in flight per GPU on separate HIP streams",
                    "samples_per_step": int(out.shape[0]), "parallelism": f"utterance-sharded x{world}",
                    "input_residency": "16 kHz float64 utterances resident in HBM before the timed region; waveform left in HBM",
                    "host_io_samples_per_s_rank0": round(host_io_rate, 1),

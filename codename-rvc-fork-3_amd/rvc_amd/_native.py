@@ -8,6 +8,7 @@ library's own message when a call fails.  Tensors are passed as raw device point
 from __future__ import annotations
 
 import ctypes
+import threading
 import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
@@ -105,17 +106,20 @@ def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 class _Workspace:
-    """Grow-only scratch buffer per (device, tag) so steady-state calls allocate nothing."""
+    """Grow-only scratch buffer per (tag, device, stream) so steady-state calls allocate nothing.  Keyed by the current
+    stream as well: utterances that are in flight on different streams must not share scratch memory."""
 
     def __init__(self):
         self._buf = {}
+        self._lock = threading.Lock()
 
     def get(self, tag: str, nbytes: int, device) -> torch.Tensor:
-        key = (tag, str(device))
-        buf = self._buf.get(key)
-        if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
-            self._buf[key] = buf
+        key = (tag, str(device), torch.cuda.current_stream(device).cuda_stream)
+        with self._lock:
+            buf = self._buf.get(key)
+            if buf is None or buf.numel() < nbytes:
+                buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+                self._buf[key] = buf
         return buf
 
 

