@@ -209,7 +209,10 @@ def main():
                 "traffic": PMC_TRAFFIC_BYTES if cfg2 else None,
                 "traffic_source": PMC_TRAFFIC_SOURCE if cfg2 else None,
                 "algorithmic_bytes_per_launch": round(mix_alg_bytes / mix_launches),
-                "flops_per_launch": flops_launch, "avg_launch_ms": round(t_launch * 1e3, 4), "launches_per_utterance": mix_launches}
+                "flops_per_launch": flops_launch, "avg_launch_ms": round(t_launch * 1e3, 4), "launches_per_utterance": mix_launches,
+                "timing": "HIP events around the isolated launch mix on the launch stream (nothing else running); rocprofv3 "
+                          "--stats agrees for a sequential run (profiles/r01_bench_kernel_stats_inflight1.csv); with two "
+                          "utterances in flight a kernel's traced duration also contains the time it shares the chip"}
     del run_mix
 
     # whole vocoder, timed with events around rvc_decoder_forward
