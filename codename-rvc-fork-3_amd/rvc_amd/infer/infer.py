@@ -227,18 +227,38 @@ class VoiceConverter:
             print(traceback.format_exc())
 
     def convert_audio_batch(self, audio_input_paths: str, audio_output_path: str, **kwargs):
-        """infer.py:350-414: sequential loop over a folder, skipping existing outputs."""
+        """infer.py:350-414: every WAV of a folder, skipping existing outputs.  The reference loops sequentially; here the
+        first file loads the models, the rest are converted ``inflight`` (default 2) at a time, each on its own HIP
+        stream (see convert_batch)."""
+        import threading
+        inflight = max(1, int(kwargs.pop("inflight", 2)))
         try:
             start_time = time.time()
             print(f"Converting audio batch '{audio_input_paths}'...")
             audio_files = [f for f in sorted(os.listdir(audio_input_paths)) if f.lower().endswith("wav")]
             print(f"Detected {len(audio_files)} audio files for inference.")
+            jobs = []
             for a in audio_files:
                 new_input = os.path.join(audio_input_paths, a)
                 new_output = os.path.join(audio_output_path, os.path.splitext(a)[0] + "_output.wav")
-                if os.path.exists(new_output):
-                    continue
-                self.convert_audio(audio_input_path=new_input, audio_output_path=new_output, **kwargs)
+                if not os.path.exists(new_output):
+                    jobs.append((new_input, new_output))
+            if jobs:   # the first conversion loads the checkpoint, the embedder and the index cache
+                self.convert_audio(audio_input_path=jobs[0][0], audio_output_path=jobs[0][1], **kwargs)
+            rest = jobs[1:]
+            n_workers = min(inflight, len(rest))
+            dev = self.config.device
+
+            def work(tid):
+                with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                    for src, dst in rest[tid::n_workers]:
+                        self.convert_audio(audio_input_path=src, audio_output_path=dst, **kwargs)   # never raises
+
+            threads = [threading.Thread(target=work, args=(t,)) for t in range(n_workers)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
             print(f"Batch conversion completed in {time.time() - start_time:.2f} seconds.")
         except Exception as error:
             print(f"An error occurred during audio batch conversion: {error}")
