@@ -162,6 +162,8 @@ class VoiceConverter:
         errors = []
         dev = self.config.device
         n_workers = max(1, min(int(inflight), len(audios)))
+        if kwargs.get("noise_seed") is not None:
+            n_workers = 1   # parity mode replays torch's GLOBAL CPU generator stream: one utterance at a time
         if not hasattr(self, "_batch_streams"):
             self._batch_streams = []
         while len(self._batch_streams) < n_workers:
