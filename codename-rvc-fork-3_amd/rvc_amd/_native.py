@@ -65,6 +65,7 @@ SYMBOLS = {
                                       c_void_p, c_size_t, c_void_p]),
     "rvc_bias_relu_add_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p]),
     "rvc_gate_tanh_sigmoid_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "rvc_set_concurrency_hint": (c_int, [c_int]),
     "rvc_decoder_create": (c_int, [POINTER(DecoderConfig), POINTER(c_void_p)]),
     "rvc_decoder_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]),
     "rvc_decoder_finalize": (c_int, [c_void_p]),
@@ -268,6 +269,10 @@ def gate_tanh_sigmoid(x: torch.Tensor) -> torch.Tensor:
     out = torch.empty(b, c2 // 2, t, dtype=torch.float32, device=x.device)
     _check(_lib.rvc_gate_tanh_sigmoid_f32(x.data_ptr(), out.data_ptr(), b, c2 // 2, t, _stream()), "rvc_gate_tanh_sigmoid_f32")
     return out
+
+
+def set_concurrency_hint(utterances_in_flight: int) -> None:
+    _check(_lib.rvc_set_concurrency_hint(int(utterances_in_flight)), "rvc_set_concurrency_hint")
 
 
 # ---- conv1d (unit-test entry) ----------------------------------------------------------------------

@@ -181,11 +181,16 @@ class VoiceConverter:
             except Exception as error:  # surfaced after the join
                 errors.append(error)
 
+        from rvc_amd import _native
+        _native.set_concurrency_hint(n_workers)
         threads = [threading.Thread(target=work, args=(t,)) for t in range(n_workers)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        try:
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        finally:
+            _native.set_concurrency_hint(1)
         for stream in self._batch_streams[:n_workers]:
             torch.cuda.current_stream(dev).wait_stream(stream)
         if errors:

@@ -125,6 +125,11 @@ int rvc_bias_relu_add_f32(const float *x_dev, const float *bias_dev, const float
  * out_dev [batch][hidden][length]. */
 int rvc_gate_tanh_sigmoid_f32(const float *x_dev, float *out_dev, int batch, int hidden, int64_t length, void *stream);
 
+/* Scheduling hint, process-wide: how many utterances the caller keeps in flight on separate streams (default 1).  With
+ * more than one, kernels stop shrinking their tiles to balance a launch across the CUs on its own -- the other streams
+ * fill the idle block slots, and the larger tiles re-read their weights from L2 half as often.  No effect on results. */
+int rvc_set_concurrency_hint(int utterances_in_flight);
+
 /* ---- K2/K3: vocoder ("dec" of Synthesizer) ---------------------------------------------------- *
  * Replaces `self.dec(z * x_mask, nsff0, g=g)` at rvc/lib/algorithm/synthesizers.py:254-258, i.e.
  *   RVC_DEC_NSF    HiFiGANNSFGenerator.forward  rvc/lib/algorithm/generators/hifigan_nsf.py:173-207
