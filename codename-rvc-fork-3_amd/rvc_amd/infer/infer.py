@@ -170,13 +170,19 @@ class VoiceConverter:
             self._batch_streams.append(torch.cuda.Stream(device=dev))
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))   # inputs produced on the caller's stream
+        lock, cursor = threading.Lock(), [0]
 
         def work(tid):
             try:
                 stream = self._batch_streams[tid]
                 stream.wait_event(ready)
                 with torch.cuda.stream(stream):
-                    for i in range(tid, len(audios), n_workers):
+                    while True:
+                        with lock:                 # shared queue: a stream takes the next utterance when it is free
+                            i = cursor[0]
+                            cursor[0] += 1
+                        if i >= len(audios):
+                            break
                         results[i] = self.convert_array(audios[i], **kwargs)
             except Exception as error:  # surfaced after the join
                 errors.append(error)
