@@ -8,7 +8,9 @@ array to the float32 48 kHz waveform, BASELINE cfg 2 (30 s clip, HuBERT-base + N
 feature index, index_rate 0.75, rmvpe, protect 0.5).  Weights are seeded random-init (no network), inputs are
 synthetic.  With N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL) every rank
 converts its own utterances (utterance i -> rank i mod N); the index is built on rank 0 and replicated with one
-broadcast at load; the steady state has no collective ("scaling": "weak").
+broadcast at load; the steady state has no collective ("scaling": "weak").  On each GPU `--inflight` utterances
+(default 2) are in flight at a time, each on its own HIP stream (VoiceConverter.convert_batch): the K timed steps
+are K utterances either way; `--inflight 1` is the strictly one-after-the-other schedule.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      the dominant kernel (the 11-tap 128-channel ResBlock conv of vocoder stage 1, fp32 MFMA implicit
