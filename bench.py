@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- end-to-end voice-conversion throughput of the MI355X path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config {1,2,4,5}] [--inflight M]
 
-One "step" = one pass of the hot path over one synthetic utterance: `Pipeline.pipeline` from the 16 kHz input
-array to the float32 48 kHz waveform, BASELINE cfg 2 (30 s clip, HuBERT-base + NSF-HiFi-GAN 48k, 100k x 768
-feature index, index_rate 0.75, rmvpe, protect 0.5).  Weights are seeded random-init (no network), inputs are
-synthetic.  With N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL) every rank
-converts its own utterances (utterance i -> rank i mod N); the index is built on rank 0 and replicated with one
-broadcast at load; the steady state has no collective ("scaling": "weak").  On each GPU `--inflight` utterances
-(default 2) are in flight at a time, each on its own HIP stream (VoiceConverter.convert_batch): the K timed steps
-are K utterances either way; `--inflight 1` is the strictly one-after-the-other schedule.
+One "step" = one pass of the hot path over one synthetic utterance: `Pipeline.pipeline` from the 16 kHz input array to
+the float32 waveform at the model's rate.  `--config` picks the BASELINE.json configuration (default 2, the one the
+metric is quoted on); config 3 is config 2 at `--gpus 8`:
+  1  10 s clip, HuBERT-base + v2 40k NSF-HiFi-GAN, index_rate 0
+  2  30 s clip, HuBERT-base + NSF-HiFi-GAN 48k, 100 000 x 768 index, index_rate 0.75
+  4  30 s clip, MRF-HiFi-GAN 48k with bf16 weights, 100 000 x 768 index, index_rate 0.75
+  5  30 s clip, RefineGAN 48k, 2 000 000 x 768 index (6.1 GB, brute-force L2 in HBM), noise drawn on the device
+Weights are seeded random-init (no network), inputs synthetic.
+
+N > 1: one rank per GPU.  Started either by `python -m torch.distributed.run ... bench.py --gpus N ...` (RANK / WORLD_SIZE
+already in the environment) or directly as `python bench.py --gpus N ...`, in which case this process -- before it touches
+the GPU -- starts the N ranks itself (rvc_amd.infer.distributed.spawn_ranks; the reference's multi-GPU precedent,
+rvc/train/extract/extract.py:141-152, starts its per-device workers the same way) and relays rank 0's line.  A world size
+that differs from --gpus, or fewer visible GPUs than --gpus, is an error, never a silent 1-GPU run.  Every rank converts
+its own utterances (utterance i -> rank i mod N); the index is built on rank 0 and replicated with ONE RCCL broadcast
+through the C ABI (rvc_index_broadcast) and verified by a device-side checksum; the steady state has no collective
+("scaling": "weak").  On each GPU `--inflight` utterances (default 2) are in flight at a time, each on its own HIP stream.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      the dominant kernel (the 11-tap 128-channel ResBlock conv of vocoder stage 1, fp32 MFMA implicit
-                GEMM), timed live with HIP events on the launch stream
-  roofline_knn  the L2 top-8 kernel against HBM bytes per query-tile pass (SURVEY §8d definition) and fp32 MFMA
-  cpu_baseline  the oracle (CPU restatement of the reference, oracle/rvc_oracle.py) timed on the host cores on
-                a bounded sample of the same workload (rank 0, N = 1 only)
+  roofline      the dominant kernel (the 11-tap 128-channel ResBlock conv of vocoder stage 1, fp32 MFMA implicit GEMM),
+                timed live with HIP events on the launch stream
+  roofline_knn  the L2 top-8 search at this config's (queries x rows), HBM bytes per pass as SURVEY §8d defines them
+  host_io       the same K steps with host NumPy in / host float32 out (PCIe inclusive) at the same `inflight`
+  cpu_baseline  the oracle (CPU restatement of the reference, oracle/rvc_oracle.py) on the host cores: bounded sample,
+                1 warm-up + median of 3 (rank 0, N = 1 only)
 """
 import argparse
 import json
@@ -32,9 +42,8 @@ for p in (ROOT, os.path.join(ROOT, "codename-rvc-fork-3_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = FP32 vector peak
+PEAK_F16_MFMA_TFLOPS = 2500.0   # dense fp16/bf16 MFMA
 PEAK_HBM_GBS = 8000.0           # HBM3E spec
 # average HBM bytes per launch of the roofline kernel symbol at the cfg-2 shape, from the PMC passes committed under
 # profiles/ (cannot be collected inside bench.py: it needs rocprofv3)
@@ -42,41 +51,79 @@ PMC_TRAFFIC_BYTES = 641.0e6
 PMC_TRAFFIC_SOURCE = ("profiles/r01_pmc_conv.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
                       "tools/pmc_conv.py (this same launch mix); FETCH_SIZE calibrated on the same kernel at K=1 with known bytes")
 
+CONFIGS = {
+    1: dict(seconds=10.0, sr=40000, vocoder="HiFi-GAN", index_rows=0, index_rate=0.0, weights="f32",
+            name="BASELINE cfg 1: 10 s 16 kHz clip, HuBERT-base + v2 40k NSF-HiFi-GAN, index_rate 0"),
+    2: dict(seconds=30.0, sr=48000, vocoder="HiFi-GAN", index_rows=100_000, index_rate=0.75, weights="f32",
+            name="BASELINE cfg 2: 30 s 16 kHz clip -> 48 kHz, HuBERT-base + NSF-HiFi-GAN 48k, 100000x768 index, index_rate 0.75"),
+    4: dict(seconds=30.0, sr=48000, vocoder="MRF HiFi-GAN", index_rows=100_000, index_rate=0.75, weights="bf16",
+            name="BASELINE cfg 4: 30 s clip, MRF-HiFi-GAN 48k, vocoder weights stored as bf16 in HBM, 100000x768 index, index_rate 0.75"),
+    5: dict(seconds=30.0, sr=48000, vocoder="RefineGAN", index_rows=2_000_000, index_rate=0.75, weights="f32",
+            name="BASELINE cfg 5 (one GPU's share): 30 s clip, RefineGAN 48k, 2000000x768 index brute-force L2 in HBM, "
+                 "index_rate 0.75, noise drawn on the device"),
+}
 
-def roofline_mix(native, dev, T, rates, k=11):
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--seconds", type=float, default=None, help="override the clip length of the config")
+    ap.add_argument("--index-rows", type=int, default=None, help="override the index size of the config")
+    ap.add_argument("--inflight", type=int, default=2, help="utterances in flight per GPU, each on its own HIP stream")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rooflines", action="store_true", help="skip the per-kernel roofline legs (timed region only)")
+    ap.add_argument("--cpu-seconds", type=float, default=3.0, help="clip length of the bounded CPU-baseline sample")
+    ap.add_argument("--control-flow-only", action="store_true",
+                    help="CPU test hook: run the launcher / process-group / sharding / broadcast / report path over gloo "
+                         "without any kernel (no throughput is measured; the line says so)")
+    return ap.parse_args(argv)
+
+
+def cpu_model_string():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+# ---- roofline legs ----------------------------------------------------------------------------------------------------
+def roofline_mix(torch, native, dev, T, rates, k=11):
     """The launches of conv_mfma_kernel<11,2,2,2,2,4,false> in one utterance's vocoder forward: the 11-tap ResBlock of
     stage 1 (C = 128; the 38k-column stage 0 takes the 128x64-tile symbol), for each dilation d: conv1 (dilation d) then
     conv2 (dilation 1, + residual; the last one also + running sum, x 1/3).
     Returns (callable, flops per call, launches per call, algorithmic HBM bytes per call)."""
-    shapes = [(128, T * rates[0] * rates[1])]
-    state, flops, alg_bytes = [], 0.0, 0.0
+    C, L = 128, T * rates[0] * rates[1]
     gen = torch.Generator().manual_seed(1)
-    for C, L in shapes:
-        x = torch.randn(1, C, L, device=dev)
-        t1 = torch.empty_like(x)
-        y = torch.randn(1, C, L, device=dev)
-        acc = torch.randn(1, C, L, device=dev)
-        w1 = native.conv1d_pack_weight(torch.randn(C, C, k, generator=gen) * 0.02, dev)
-        w2 = native.conv1d_pack_weight(torch.randn(C, C, k, generator=gen) * 0.02, dev)
-        bias = torch.zeros(C, device=dev)
-        state.append((C, x, t1, y, acc, w1, w2, bias))
-        flops += 6 * 2.0 * C * C * k * L
-        tensor = C * L * 4.0
-        alg_bytes += 3 * (2 * tensor) + 2 * (3 * tensor) + 1 * (4 * tensor)   # conv1: r+w; conv2: r+res+w (+acc)
+    x = torch.randn(1, C, L, device=dev)
+    t1 = torch.empty_like(x)
+    y = torch.randn(1, C, L, device=dev)
+    acc = torch.randn(1, C, L, device=dev)
+    w1 = native.conv1d_pack_weight(torch.randn(C, C, k, generator=gen) * 0.02, dev)
+    w2 = native.conv1d_pack_weight(torch.randn(C, C, k, generator=gen) * 0.02, dev)
+    bias = torch.zeros(C, device=dev)
+    flops = 6 * 2.0 * C * C * k * L
+    tensor = C * L * 4.0
+    alg_bytes = 3 * (2 * tensor) + 2 * (3 * tensor) + 1 * (4 * tensor)   # conv1: r+w; conv2: r+res+w (+acc)
 
     def run():
-        for C, x, t1, y, acc, w1, w2, bias in state:
-            for j, d in enumerate((1, 3, 5)):
-                native.conv1d_forward_into(x, w1, bias, C, k, d, 0.1, out=t1)
-                if j < 2:
-                    native.conv1d_forward_into(t1, w2, bias, C, k, 1, 0.1, res=x, out=y)
-                else:
-                    native.conv1d_forward_into(t1, w2, bias, C, k, 1, 0.1, res=x, acc=acc, out_scale=1 / 3, out=y)
+        for j, d in enumerate((1, 3, 5)):
+            native.conv1d_forward_into(x, w1, bias, C, k, d, 0.1, out=t1)
+            if j < 2:
+                native.conv1d_forward_into(t1, w2, bias, C, k, 1, 0.1, res=x, out=y)
+            else:
+                native.conv1d_forward_into(t1, w2, bias, C, k, 1, 0.1, res=x, acc=acc, out_scale=1 / 3, out=y)
     return run, flops, 6, alg_bytes
 
 
 def decoder_flops(T, rates, ksizes, c0=512, cin=192, res_k=(3, 7, 11), n_dil=3):
-    """Closed form of SURVEY §8d (2 x MACs)."""
+    """Closed form of SURVEY §8d (2 x MACs), NSF / MRF topology."""
     macs = cin * c0 * 7 * T
     length, ch = T, c0
     for i, (u, k) in enumerate(zip(rates, ksizes)):
@@ -90,217 +137,146 @@ def decoder_flops(T, rates, ksizes, c0=512, cin=192, res_k=(3, 7, 11), n_dil=3):
     return 2.0 * macs
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--seconds", type=float, default=30.0, help="clip length (BASELINE cfg 2 = 30 s)")
-    ap.add_argument("--index-rows", type=int, default=100_000)
-    ap.add_argument("--inflight", type=int, default=2, help="utterances in flight per GPU, each on its own HIP stream")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=3.0, help="clip length of the bounded CPU-baseline sample")
-    args = ap.parse_args()
+def synth_index_device(torch, n_rows, dev, seed=0, n_centres=512, jitter=0.05, dim=768):
+    """rvc_amd.lib.synthetic.synth_index's recipe (cluster centres + jitter) drawn on the device: a 2 M-row index is
+    6.1 GB, too slow to draw with NumPy inside a bench run."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    centres = torch.randn(n_centres, dim, device=dev, generator=g) * 0.35
+    out = torch.empty(n_rows, dim, device=dev)
+    for s in range(0, n_rows, 1 << 18):
+        e = min(n_rows, s + (1 << 18))
+        which = torch.randint(0, n_centres, (e - s,), device=dev, generator=g)
+        out[s:e] = centres[which] + jitter * torch.randn(e - s, dim, device=dev, generator=g)
+    return out
 
+
+def main():
+    args = parse_args()
+    cfg = dict(CONFIGS[args.config])
+    if args.seconds is not None:
+        cfg["seconds"] = args.seconds
+    if args.index_rows is not None:
+        cfg["index_rows"] = args.index_rows
+    want = max(1, args.gpus)
+
+    # ---- who am I: a rank started by a launcher, or the process that has to start the ranks ----
+    if "WORLD_SIZE" not in os.environ and want > 1:
+        import torch  # device_count() does not initialise HIP on this image; nothing else here touches the GPU
+        from rvc_amd.infer import distributed as D
+        if not args.control_flow_only:
+            n_dev = torch.cuda.device_count()
+            if n_dev < want:
+                print(f"bench.py: --gpus {want} but only {n_dev} GPU(s) are visible; refusing to report a {want}-GPU "
+                      "number from fewer devices", file=sys.stderr)
+                sys.exit(2)
+        extra = {"RVC_DIST_BACKEND": "gloo"} if args.control_flow_only else {}
+        sys.exit(D.spawn_ranks([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], want, env_extra=extra))
+
+    import torch
     from rvc_amd.infer import distributed as D
     rank, world, local = D.init_process_group()
-    assert world == max(1, args.gpus) or world == 1, (world, args.gpus)
+    if world != want:
+        print(f"bench.py: --gpus {want} but WORLD_SIZE is {world}; start one rank per GPU (or drop the launcher and let "
+              "bench.py start them)", file=sys.stderr)
+        sys.exit(2)
+    if args.control_flow_only:
+        return control_flow_only(torch, D, args, cfg, rank, world)
+
     assert torch.cuda.is_available(), "bench.py measures the HIP path; there is no CPU fallback"
-    local = local % torch.cuda.device_count()   # ranks > devices only in the gloo control-flow test (RVC_DIST_BACKEND)
+    n_dev = torch.cuda.device_count()
+    if world > n_dev and os.environ.get("RVC_DIST_BACKEND") != "gloo":
+        print(f"bench.py: {world} ranks but {n_dev} GPU(s) visible", file=sys.stderr)
+        sys.exit(2)
+    local = local % n_dev   # ranks > devices only with RVC_DIST_BACKEND=gloo (several ranks share a GPU: control-flow runs)
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
+    gloo_only = os.environ.get("RVC_DIST_BACKEND") == "gloo"
     if world > 1:   # N host processes share the node's cores: keep each rank's CPU thread pool small
         torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier(**({} if gloo_only else {"device_ids": [local]}))
 
     from rvc_amd import _native
     from rvc_amd.infer.infer import VoiceConverter
     from rvc_amd.lib import synthetic as S
 
     # ---- load (untimed): weights, index broadcast ----
-    sr = 48000
-    cpt = S.make_synth_checkpoint(sr, "HiFi-GAN", seed=0)
+    sr = cfg["sr"]
+    cpt = S.make_synth_checkpoint(sr, cfg["vocoder"], seed=0)
     vc = VoiceConverter(device=dev)
+    if cfg["weights"] == "bf16":
+        vc.dec_weight_dtype = "bf16"
     vc.load_checkpoint_dict(cpt)
     vc.load_hubert_state_dict(S.make_hubert_state_dict(1))
     vc.vc.load_rmvpe_state_dict(S.make_rmvpe_state_dict(0))
-    big = S.synth_index(args.index_rows, seed=0) if rank == 0 else None
-    t0 = time.perf_counter()
-    index_dev = D.broadcast_index(big, dev)
-    torch.cuda.synchronize()
-    t_bcast = time.perf_counter() - t0
-    assert D.checksums_agree(index_dev), "feature index differs across ranks after the broadcast"
-    vc.vc.set_index(index_dev)
+    index_dev, bcast = None, {}
+    if cfg["index_rows"] > 0:
+        big = None
+        if rank == 0:
+            big = S.synth_index(cfg["index_rows"], seed=0) if cfg["index_rows"] <= 200_000 else \
+                synth_index_device(torch, cfg["index_rows"], dev, seed=0)
+        index_dev = D.broadcast_index(big, dev, force_rccl=not gloo_only)
+        bcast = D.last_broadcast_info()
+        assert D.checksums_agree(index_dev), "feature index differs across ranks after the broadcast"
+        vc.vc.set_index(index_dev)
+        del big
 
-    n_in = int(round(args.seconds * 16000))
+    n_in = int(round(cfg["seconds"] * 16000))
     n_total = args.steps + args.warmup
     # utterance i (global) uses rng seed i; this rank converts i = rank, rank + world, ...
     audios_host = [S.synth_audio(n_in, seed=rank + world * j) for j in range(min(n_total, 4))]
     audios = [torch.from_numpy(a).to(dev) for a in audios_host]   # inputs resident in HBM before the timed region
 
-    def step(j, host_io=False):
-        a = (audios_host if host_io else audios)[j % len(audios)]
-        return vc.convert_array(a, index_path="", index_rate=0.75, protect=0.5, sid=0)
-
-    # `--inflight` utterances are on the GPU at a time, each on its own HIP stream (VoiceConverter.convert_batch): the K
-    # timed steps are K utterances, interleaved 2 by 2 by default.  --inflight 1 is the strictly sequential schedule.
     inflight = max(1, args.inflight)
-    kw = dict(index_path="", index_rate=0.75, protect=0.5, sid=0)
-    if inflight == 1:
-        for j in range(args.warmup):
-            out = step(j)
-    else:   # every stream warms up its own workspaces / side stream (W steps per stream)
-        vc.convert_batch([audios[j % len(audios)] for j in range(args.warmup * inflight)], inflight=inflight, **kw)
-    if world > 1:
-        torch.distributed.barrier(**({} if os.environ.get("RVC_DIST_BACKEND") == "gloo" else {"device_ids": [local]}))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    samples = 0
-    if inflight == 1:
-        for j in range(args.steps):
-            out = step(args.warmup + j)
-            samples += out.shape[0]
-    else:
-        outs = vc.convert_batch([audios[(args.warmup + j) % len(audios)] for j in range(args.steps)], inflight=inflight, **kw)
-        samples = sum(int(o.shape[0]) for o in outs)
-        out = outs[-1]
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier(**({} if os.environ.get("RVC_DIST_BACKEND") == "gloo" else {"device_ids": [local]}))
-    elapsed = time.perf_counter() - t0
-    total_samples, t_max = D.reduce_report(samples, elapsed, dev)
-    # outside the timed region: the last waveform must be finite and inside [-1, 1] (the BiGRU poisons its output with NaN if
-    # its workgroups ever fail to rendezvous; a silent NaN utterance must not count as throughput)
-    assert bool(torch.isfinite(out).all()) and float(out.abs().max()) <= 1.0, "bench produced a non-finite or unnormalised waveform"
+    kw = dict(index_path="", index_rate=cfg["index_rate"], protect=0.5, sid=0)
 
-    # PCIe-inclusive variant (host NumPy in, host NumPy out), reported beside `value`, never as `value`
-    host_steps = min(args.steps, 4)
+    def run_steps(pool, first, count):
+        """`count` utterances, `inflight` at a time (VoiceConverter.convert_batch; 1 = strictly one after the other)."""
+        return vc.convert_batch([pool[(first + j) % len(pool)] for j in range(count)], inflight=inflight, **kw)
+
+    run_steps(audios, 0, args.warmup * inflight)   # every stream warms up its own workspaces / side stream
+    barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for j in range(host_steps):
-        step(j, host_io=True)
+    outs = run_steps(audios, args.warmup, args.steps)
     torch.cuda.synchronize()
-    host_io_rate = host_steps * int(out.shape[0]) / (time.perf_counter() - t0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    samples = sum(int(o.shape[0]) for o in outs)
+    total_samples, t_max = D.reduce_report(samples, elapsed, dev)
+    # outside the timed region: EVERY timed waveform must be finite and inside [-1, 1] (a silent NaN utterance must not
+    # count as throughput)
+    for o in outs:
+        assert bool(torch.isfinite(o).all()) and float(o.abs().max()) <= 1.0, "bench produced a non-finite or unnormalised waveform"
+    out_len = int(outs[-1].shape[0])
+    del outs
+
+    # the boundary as the reference has it: host NumPy in, host float32 NumPy out (PCIe inclusive), same schedule
+    run_steps(audios_host, 0, inflight)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    houts = run_steps(audios_host, args.warmup, args.steps)
+    torch.cuda.synchronize()
+    t_host = time.perf_counter() - t0
+    assert all(isinstance(o, np.ndarray) and o.dtype == np.float32 and np.isfinite(o).all() for o in houts)
+    host_io = {"samples_per_s_rank0": round(sum(o.shape[0] for o in houts) / t_host, 1),
+               "ms_per_step": round(t_host / args.steps * 1e3, 2), "inflight": inflight,
+               "what": "same K steps, 16 kHz float64 NumPy array in host memory -> float32 NumPy waveform in host memory "
+                       "(the reference's Pipeline.pipeline boundary, pipeline.py:509-528)"}
+    del houts
 
     if rank != 0:
+        barrier()
+        D.destroy_native_comm()
         if world > 1:
-            torch.distributed.barrier()
             torch.distributed.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel symbol: conv_mfma_kernel<11,2,2,2,2,4,false> (stage-1 11-tap ResBlock convs) ----
-    rates, ksizes = cpt["config"][12], cpt["config"][14]
-    n_pad = n_in + 32000                              # 1 s reflect pad each side (pipeline.py:581)
-    T = min(n_pad // 160, 2 * ((n_pad - 400) // 320 + 1))   # synth frames (pipeline.py:467)
-    run_mix, mix_flops, mix_launches, mix_alg_bytes = roofline_mix(_native, dev, T, rates)
-    for _ in range(2):
-        run_mix()
-    reps = 5
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        run_mix()
-    e1.record()
-    torch.cuda.synchronize()
-    t_launch = e0.elapsed_time(e1) / (reps * mix_launches) * 1e-3
-    flops_launch = mix_flops / mix_launches
-    cfg2 = T == 3198 and list(rates[:2]) == [12, 10]
-    roofline = {"kernel": "rvc::conv_mfma_kernel<11,2,2,2,2,4,false>: the 6 launches per utterance of the 11-tap ResBlock convs of vocoder "
-                          "stage 1 (C=128, 383 760 columns), in the decoder's own mix (dilations 1/3/5, residual on every second one)",
-                "bound": "mfma", "achieved": round(flops_launch / t_launch / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(flops_launch / t_launch / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": PMC_TRAFFIC_BYTES if cfg2 else None,
-                "traffic_source": PMC_TRAFFIC_SOURCE if cfg2 else None,
-                "algorithmic_bytes_per_launch": round(mix_alg_bytes / mix_launches),
-                "flops_per_launch": flops_launch, "avg_launch_ms": round(t_launch * 1e3, 4), "launches_per_utterance": mix_launches,
-                "timing": "HIP events around the isolated launch mix on the launch stream (nothing else running); rocprofv3 "
-                          "--stats agrees for a sequential run (profiles/r01_bench_kernel_stats_inflight1.csv); with two "
-                          "utterances in flight a kernel's traced duration also contains the time it shares the chip"}
-    del run_mix
-
-    # whole vocoder, timed with events around rvc_decoder_forward
-    z = torch.randn(1, 192, T, device=dev)
-    f0 = torch.full((1, T), 220.0, device=dev)
-    gv = torch.randn(1, 256, device=dev)
-    nz = torch.randn(1, T * 480, 1, device=dev)
-    vc.net_g.dec.forward(z, f0, gv, src_randn=nz)
-    e0.record()
-    for _ in range(3):
-        vc.net_g.dec.forward(z, f0, gv, src_randn=nz)
-    e1.record()
-    torch.cuda.synchronize()
-    t_dec = e0.elapsed_time(e1) / 3 * 1e-3
-    dflops = decoder_flops(T, rates, ksizes)
-
-    # kNN kernel
-    F_ = (n_in + 32000 - 400) // 320 + 1
-    q = index_dev[torch.randint(0, index_dev.shape[0], (F_,), device=dev)] + 0.03 * torch.randn(F_, 768, device=dev)
-    idx = vc.vc._preset_index
-    idx.search_device(q)
-    e0.record()
-    for _ in range(5):
-        idx.search_device(q)
-    e1.record()
-    torch.cuda.synchronize()
-    t_knn = e0.elapsed_time(e1) / 5 * 1e-3
-    passes = -(-F_ // 128)
-    knn_bytes = passes * index_dev.shape[0] * 768 * 4.0
-    knn_flops = 2.0 * F_ * index_dev.shape[0] * 768
-    roofline_knn = {"kernel": "knn_partial_kernel + knn_merge_kernel", "bound": "hbm", "query_tile": 128, "passes": passes,
-                    "achieved": round(knn_bytes / t_knn / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(knn_bytes / t_knn / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
-                    "mfma_tflops": round(knn_flops / t_knn / 1e12, 2),
-                    "mfma_frac": round(knn_flops / t_knn / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "avg_launch_ms": round(t_knn * 1e3, 4)}
-
-    # the kernel's HBM-bound regime: <= 32 queries (one MFMA column tile) against a cfg-5-sized index that cannot sit in
-    # the 256 MB Infinity Cache; algorithmic bytes = one pass over the index
-    roofline_knn_stream = None
-    try:
-        n_big = 2_000_000
-        big_idx = torch.empty(n_big, 768, device=dev)
-        for s0 in range(0, n_big, 250_000):
-            big_idx[s0:s0 + 250_000].normal_(0, 0.35)
-        big_norms = _native.knn_index_norms(big_idx)
-        q32 = big_idx[torch.randint(0, n_big, (32,), device=dev)] + 0.03 * torch.randn(32, 768, device=dev)
-        for _ in range(2):
-            _native.knn_search(big_idx, big_norms, q32)
-        e0.record()
-        for _ in range(5):
-            _native.knn_search(big_idx, big_norms, q32)
-        e1.record()
-        torch.cuda.synchronize()
-        t_s = e0.elapsed_time(e1) / 5 * 1e-3
-        sbytes = n_big * 768 * 4.0
-        roofline_knn_stream = {"kernel": "knn_direct_kernel<8,3> + knn_merge_kernel, 32 queries x 2 000 000 rows (6.1 GB index), one pass",
-                               "bound": "hbm", "achieved": round(sbytes / t_s / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                               "frac": round(sbytes / t_s / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
-                               "avg_search_ms": round(t_s * 1e3, 4)}
-        del big_idx, big_norms
-    except torch.OutOfMemoryError:
-        pass
-
-    # ---- CPU baseline: the oracle on the host cores, bounded sample ----
-    cpu_baseline = None
-    if world == 1 and not args.no_cpu_baseline:
-        from oracle import rvc_oracle as O
-        cores = min(os.cpu_count() or 1, 32)   # the restatement's torch ops stop scaling (and thrash) far below 256 threads
-        torch.set_num_threads(cores)
-        a = S.synth_audio(int(args.cpu_seconds * 16000), seed=0)
-        hub_sd, rm_sd = S.make_hubert_state_dict(1), S.make_rmvpe_state_dict(0)
-        big_host = index_dev.cpu().numpy()
-        torch.manual_seed(0)
-        t0 = time.perf_counter()
-        ref = O.pipeline(hub_sd, rm_sd, cpt, a, sid=0, pitch=0, big_npy=big_host, index_rate=0.75, protect=0.5,
-                         knn_dtype=np.float32)
-        t_cpu = time.perf_counter() - t0
-        cpu_baseline = {"value": round(ref.shape[0] / t_cpu, 1), "unit": "samples/s", "cores": cores, "kind": "port",
-                        "sample": f"{args.cpu_seconds:g} s clip, same cfg-2 settings (48k NSF, {args.index_rows}x768 index, "
-                                  f"index_rate 0.75), 1 run of oracle.pipeline, torch threads = {cores}",
-                        "seconds": round(t_cpu, 2)}
-
     value = total_samples / t_max
     line = {
-        "metric": "48 kHz audio samples/sec end-to-end VC",
+        "metric": "48 kHz audio samples/sec end-to-end VC" if sr == 48000 else f"{sr // 1000} kHz audio samples/sec end-to-end VC",
         "value": round(value, 1),
         "unit": "samples/s",
         "n_gpus": world,
@@ -313,22 +289,157 @@ def main():
         "dtype": "f32",
         "data": "synthetic (seeded random-init weights, FM-tone utterances, clustered index)",
         "rtf": round(value / sr, 2),
-        "config": {"workload": f"BASELINE cfg 2: {args.seconds:g} s 16 kHz clip -> 48 kHz, HuBERT-base + NSF-HiFi-GAN 48k, "
-                               f"{args.index_rows}x768 index, index_rate 0.75, rmvpe, protect 0.5; 1 utterance per step per GPU, "
-                               f"{max(1, args.inflight)} utterance(s) in flight per GPU on separate HIP streams",
-                   "samples_per_step": int(out.shape[0]), "parallelism": f"utterance-sharded x{world}",
-                   "input_residency": "16 kHz float64 utterances resident in HBM before the timed region; waveform left in HBM",
-                   "host_io_samples_per_s_rank0": round(host_io_rate, 1),
-                   "index_broadcast_s": round(t_bcast, 4)},
-        "roofline": roofline,
-        "roofline_knn": roofline_knn,
-        "roofline_knn_stream": roofline_knn_stream,
-        "decoder": {"tflops_per_utterance": round(dflops / 1e12, 4), "ms": round(t_dec * 1e3, 2),
-                    "achieved_tflops": round(dflops / t_dec / 1e12, 2),
-                    "frac_of_fp32_peak": round(dflops / t_dec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
-        "cpu_baseline": cpu_baseline,
+        "config": {"workload": f"{cfg['name']}; rmvpe, protect 0.5; 1 utterance per step per GPU, {inflight} utterance(s) in "
+                               f"flight per GPU on separate HIP streams" + (f"; clip {cfg['seconds']:g} s" if args.seconds else ""),
+                   "baseline_config": args.config,
+                   "samples_per_step": out_len, "parallelism": f"utterance-sharded x{world}", "inflight": inflight,
+                   "input_residency": "16 kHz float64 utterances resident in HBM before the timed region; waveform left in HBM "
+                                      "(host_io carries the PCIe-inclusive figure at the same inflight)",
+                   "noise": "drawn on the device (torch Philox)",
+                   "vocoder_weights": cfg["weights"]},
+        "rccl_ranks": bcast.get("n_ranks"),
+        "index_broadcast": None if not bcast else {
+            "transport": bcast.get("transport"), "bytes": bcast.get("bytes"), "seconds": round(bcast.get("seconds", 0.0), 4),
+            "gbps": round(bcast.get("bytes", 0) / max(bcast.get("seconds", 0.0), 1e-9) / 1e9, 2) if world > 1 else None,
+            "rccl_version": bcast.get("rccl_version"), "library": bcast.get("library"),
+            "verified": "device checksum (rvc_checksum64) equal on every rank"},
+        "host_io": host_io,
     }
+
+    if not args.no_rooflines:
+        line.update(rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev))
+
+    # ---- CPU baseline: the oracle on the host cores, bounded sample, 1 warm-up + median of 3 ----
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import rvc_oracle as O
+        cores = min(os.cpu_count() or 1, 32)   # the restatement's torch ops stop scaling (and thrash) far below 256 threads
+        torch.set_num_threads(cores)
+        a = S.synth_audio(int(args.cpu_seconds * 16000), seed=0)
+        hub_sd, rm_sd = S.make_hubert_state_dict(1), S.make_rmvpe_state_dict(0)
+        cpu_rows = min(cfg["index_rows"], 100_000)
+        big_host = index_dev[:cpu_rows].cpu().numpy() if cpu_rows else None
+        times, n_out = [], 0
+        for rep in range(4):
+            torch.manual_seed(0)
+            t0 = time.perf_counter()
+            ref = O.pipeline(hub_sd, rm_sd, cpt, a, sid=0, pitch=0, big_npy=big_host, index_rate=cfg["index_rate"], protect=0.5,
+                             knn_dtype=np.float32)
+            times.append(time.perf_counter() - t0)
+            n_out = ref.shape[0]
+        t_cpu = float(np.median(times[1:]))
+        line["cpu_baseline"] = {
+            "value": round(n_out / t_cpu, 1), "unit": "samples/s", "cores": cores, "cpu_model": cpu_model_string(),
+            "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": f"{args.cpu_seconds:g} s clip at this config's settings ({cfg['vocoder']} {sr // 1000}k, "
+                      f"{cpu_rows}x768 index, index_rate {cfg['index_rate']}), oracle.pipeline, torch threads = {cores}; "
+                      "1 warm-up run + median of 3",
+            "seconds_median": round(t_cpu, 2), "seconds_all": [round(t, 2) for t in times]}
+    else:
+        line["cpu_baseline"] = None
+
     print(json.dumps(line), flush=True)
+    barrier()
+    D.destroy_native_comm()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev):
+    """Per-kernel legs (rank 0, after the timed region): dominant conv symbol, whole vocoder, kNN."""
+    res = {}
+    sr = cfg["sr"]
+    rates, ksizes = cpt["config"][12], cpt["config"][14]
+    n_pad = n_in + 32000                              # 1 s reflect pad each side (pipeline.py:581)
+    F_ = (n_pad - 400) // 320 + 1                     # HuBERT frames
+    T = min(n_pad // 160, 2 * F_)                     # synth frames (pipeline.py:467)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    # ---- dominant kernel symbol: conv_mfma_kernel<11,2,2,2,2,4,false> (stage-1 11-tap ResBlock convs) ----
+    run_mix, mix_flops, mix_launches, mix_alg_bytes = roofline_mix(torch, _native, dev, T, rates)
+    for _ in range(2):
+        run_mix()
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        run_mix()
+    e1.record()
+    torch.cuda.synchronize()
+    t_launch = e0.elapsed_time(e1) / (reps * mix_launches) * 1e-3
+    flops_launch = mix_flops / mix_launches
+    cfg2 = T == 3198 and list(rates[:2]) == [12, 10]
+    res["roofline"] = {
+        "kernel": f"rvc::conv_mfma_kernel<11,2,2,2,2,4,false>: the 6 launches per utterance of the 11-tap ResBlock convs of "
+                  f"vocoder stage 1 (C=128, {T * rates[0] * rates[1]} columns), in the decoder's own mix (dilations 1/3/5, "
+                  "residual on every second one)",
+        "bound": "mfma", "achieved": round(flops_launch / t_launch / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+        "unit": "TFLOP/s", "frac": round(flops_launch / t_launch / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+        "traffic": PMC_TRAFFIC_BYTES if cfg2 else None,
+        "traffic_source": PMC_TRAFFIC_SOURCE if cfg2 else None,
+        "algorithmic_bytes_per_launch": round(mix_alg_bytes / mix_launches),
+        "flops_per_launch": flops_launch, "avg_launch_ms": round(t_launch * 1e3, 4), "launches_per_utterance": mix_launches,
+        "timing": "HIP events around the isolated launch mix on the launch stream (nothing else running); rocprofv3 "
+                  "--stats agrees for a sequential run (profiles/); with two utterances in flight a kernel's traced "
+                  "duration also contains the time it shares the chip"}
+    del run_mix
+
+    # ---- whole vocoder, timed with events around rvc_decoder_forward ----
+    z = torch.randn(1, 192, T, device=dev)
+    f0 = torch.full((1, T), 220.0, device=dev)
+    gv = torch.randn(1, 256, device=dev)
+    nz = vc.net_g._draw(None, 1, T)
+
+    def dec():
+        return vc.net_g.dec.forward(z, f0, gv, src_randn=nz["src_randn"].contiguous(), src_rand=nz.get("src_rand"),
+                                    adain_randn=nz.get("adain_randn"))
+    dec()
+    e0.record()
+    for _ in range(3):
+        dec()
+    e1.record()
+    torch.cuda.synchronize()
+    t_dec = e0.elapsed_time(e1) / 3 * 1e-3
+    if cfg["vocoder"] == "RefineGAN":
+        dflops = 3889.5e9 / 3198 * T   # SURVEY §8d: measured with FlopCounterMode on the reference module
+    else:
+        dflops = decoder_flops(T, rates, ksizes)
+    res["decoder"] = {"vocoder": cfg["vocoder"], "tflops_per_utterance": round(dflops / 1e12, 4), "ms": round(t_dec * 1e3, 2),
+                      "achieved_tflops": round(dflops / t_dec / 1e12, 2),
+                      "frac_of_fp32_peak": round(dflops / t_dec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+    del z, nz
+
+    # ---- kNN at this config's shape (F_ queries of one utterance x the resident index) ----
+    if index_dev is not None:
+        idx = vc.vc._preset_index
+        n_rows = int(index_dev.shape[0])
+        q = index_dev[torch.randint(0, n_rows, (F_,), device=dev)] + 0.03 * torch.randn(F_, 768, device=dev)
+        idx.search_device(q)
+        reps = 5 if n_rows <= 200_000 else 2
+        e0.record()
+        for _ in range(reps):
+            idx.search_device(q)
+        e1.record()
+        torch.cuda.synchronize()
+        t_knn = e0.elapsed_time(e1) / reps * 1e-3
+        res["roofline_knn"] = _native.knn_roofline_report(n_rows, F_, 768, t_knn, PEAK_HBM_GBS, PEAK_FP32_MFMA_TFLOPS,
+                                                          PEAK_F16_MFMA_TFLOPS)
+    return res
+
+
+def control_flow_only(torch, D, args, cfg, rank, world):
+    """CPU test hook (--control-flow-only): everything around the kernels -- process group, striding, index broadcast,
+    checksum, report reduction, the one-line report -- over gloo on host tensors.  No throughput is measured."""
+    from rvc_amd.lib import synthetic as S
+    big = S.synth_index(256, seed=0) if rank == 0 else None
+    idx = D.broadcast_index(big, "cpu")
+    assert D.checksums_agree(idx)
+    mine = D.shard_indices(args.steps * world, rank, world)
+    total, t_max = D.reduce_report(len(mine) * 1000, 1.0 + 0.001 * rank, "cpu")
+    info = D.last_broadcast_info()
+    if rank == 0:
+        print(json.dumps({"metric": "control-flow-only (no kernels, no throughput)", "value": None, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ranks": torch.distributed.get_world_size() if world > 1 else 1,
+                          "rccl_ranks": None, "index_broadcast": {"transport": info.get("transport"), "n_ranks": info.get("n_ranks", 1)},
+                          "total_samples": total, "t_max": t_max, "baseline_config": args.config}), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

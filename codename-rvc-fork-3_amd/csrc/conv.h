@@ -35,6 +35,14 @@ struct ConvParams {
     int debug = 0;   // experiments only (RVC_CONV_DEBUG): 1 = skip x loads, 2 = skip y stores, 4 = skip res loads
 };
 
+// While alive, launch_conv calls made by THIS thread use `hint` utterances-in-flight instead of the process default
+// (a decoder handle's own setting, rvc_decoder_set_concurrency_hint); hint <= 0 changes nothing.
+struct ConcurrencyScope {
+    explicit ConcurrencyScope(int hint);
+    ~ConcurrencyScope();
+    int saved;
+};
+
 // picks the tile configuration from m_total; returns non-zero and sets the error on unsupported shapes
 int launch_conv(const ConvParams &p, hipStream_t stream);
 

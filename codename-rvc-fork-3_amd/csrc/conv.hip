@@ -312,8 +312,11 @@ conv_mfma_kernel(const ConvParams p) {
     }
 }
 
-static std::atomic<int> g_concurrency{1};   // rvc_set_concurrency_hint
-static int concurrency_hint() { return g_concurrency.load(std::memory_order_relaxed); }
+static std::atomic<int> g_concurrency{1};   // rvc_set_concurrency_hint: process-wide default
+static thread_local int t_concurrency = 0;  // > 0 while the calling thread is inside a forward of a handle that has its own hint
+static int concurrency_hint() { return t_concurrency > 0 ? t_concurrency : g_concurrency.load(std::memory_order_relaxed); }
+ConcurrencyScope::ConcurrencyScope(int hint) : saved(t_concurrency) { if (hint > 0) t_concurrency = hint; }
+ConcurrencyScope::~ConcurrencyScope() { t_concurrency = saved; }
 
 template <int KW, int MT, int NT, int WM, int WN, int CIC>
 static int launch_cfg(const ConvParams &p, hipStream_t stream) {

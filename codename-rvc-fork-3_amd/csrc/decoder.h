@@ -1,5 +1,6 @@
 // Shared host-side structures of the vocoder handle (decoder.hip: NSF / MRF schedule; refine.hip: RefineGAN).
 #pragma once
+#include <atomic>
 #include <map>
 #include <string>
 #include <vector>
@@ -72,6 +73,7 @@ struct rvc_decoder {
     rvc::DevBuf pre_w, pre_b;      // pre_conv [256][7], [256]
     rvc::ConvW mel;                // mel_conv k7 192 -> 256
     std::vector<rvc::RefineStage> rstages;
+    std::atomic<int> concurrency{0};   // rvc_decoder_set_concurrency_hint (0 = process default)
     // debug tap
     int tap_stage = -2;
     float *tap_dev = nullptr;

@@ -592,10 +592,18 @@ extern "C" int rvc_decoder_set_tap(rvc_decoder *dec, int stage, float *tap_dev) 
     return 0;
 }
 
+extern "C" int rvc_decoder_set_concurrency_hint(rvc_decoder *dec, int utterances_in_flight) {
+    if (!dec) return fail("rvc_decoder_set_concurrency_hint: null decoder");
+    if (utterances_in_flight < 0) return fail("rvc_decoder_set_concurrency_hint: negative hint %d", utterances_in_flight);
+    dec->concurrency.store(utterances_in_flight, std::memory_order_relaxed);
+    return 0;
+}
+
 extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const float *f0_dev, const float *g_dev,
                                    const rvc_decoder_noise *noise, int batch, int64_t T, float *out_dev,
                                    void *workspace_dev, size_t workspace_bytes, void *stream_) {
     if (!d || !z_dev || !f0_dev || !g_dev || !noise || !out_dev || !workspace_dev) return fail("rvc_decoder_forward: null pointer");
+    ConcurrencyScope scope(d->concurrency.load(std::memory_order_relaxed));
     if (!d->finalized) return fail("rvc_decoder_forward: decoder not finalized");
     if (batch <= 0 || T <= 0) return fail("rvc_decoder_forward: empty batch");
     if (!noise->src_randn_dev) return fail("rvc_decoder_forward: src_randn_dev is required");

@@ -7,6 +7,8 @@
 // recurrent weights stream from L2 (786 KB, resident) as 16-byte loads, two barriers per step.
 //
 // thread (jq, kq), jq in [0,192), kq in [0,4): partial dot products of gate rows 4jq..4jq+3 over k in [64kq, 64kq+64)
+#include <atomic>
+
 #include "common.h"
 
 namespace rvc {
@@ -22,12 +24,14 @@ bigru_kernel(const float *__restrict__ gi,      // [B][T][2][768]  W_ih x + b_ih
              const float *__restrict__ whhT,    // [2][256][768]   W_hh transposed
              const float *__restrict__ bhh,     // [2][768]
              float *__restrict__ out,           // [B][T][512]
-             int T) {
+             int T,
+             const int *__restrict__ redo) {    // NULL: always run; else run (b, dir) only if redo[2 b + dir] != 0
     __shared__ __attribute__((aligned(16))) float part_s[4 * GRU_G];
     __shared__ float h_s[GRU_H];
     const int tid = threadIdx.x;
     const int dir = blockIdx.x;
     const int b = blockIdx.y;
+    if (redo && redo[2 * b + dir] == 0) return;   // block-uniform: the multi-workgroup pass of this sequence was clean
     const int jq = tid % 192;
     const int kq = tid / 192;
     const float4 *W4 = reinterpret_cast<const float4 *>(whhT + (size_t)dir * GRU_H * GRU_G);
@@ -90,18 +94,23 @@ bigru_kernel(const float *__restrict__ gi,      // [B][T][2][768]  W_ih x + b_ih
 // write-through store each: tag = step + 1, no separate flag, no fence -- cdna_hip_programming.md §6 G16 form R2);
 // one wave polls the 192 foreign granules with relaxed agent-scope loads.  Two parities of the exchange buffer are
 // enough: a workgroup cannot get two steps ahead of a peer whose step-s value it still needs.
-// Every spin is bounded; on a timeout the workgroup stops polling and poisons its output with NaN.
+// Every spin is bounded.  The 8 workgroups of a launch are normally co-resident within microseconds; when other streams
+// hold every block slot they start one by one as slots free up and the early ones wait.  If a wait ever exceeds the
+// bound, the workgroup stops polling, raises status[2 b + dir] and the launch is followed by bigru_kernel restricted
+// to the raised (batch item, direction) pairs -- the single-workgroup recurrence, slower but free of any rendezvous --
+// which overwrites that sequence's output.  No host round trip is involved; the status words stay readable afterwards
+// (rvc_bigru_status).
 constexpr int GRU_CUS = 4;
 constexpr int GRU_UNITS = GRU_H / GRU_CUS;      // 64 hidden units per workgroup
 constexpr int GRU_ROWS = 3 * GRU_UNITS;         // 192 gate rows per workgroup
 constexpr int GRU_HS = 68;                      // LDS stride between k-quarters of h (bank spread for the b128 reads)
-constexpr unsigned GRU_SPIN_LIMIT = 1u << 22;
+constexpr unsigned GRU_SPIN_LIMIT = 1u << 22;   // default bound of one rendezvous wait (~0.3 s of polling)
 
 typedef unsigned long long u64;
 
 __global__ void __launch_bounds__(GRU_THREADS)
 bigru_mc_kernel(const float *__restrict__ gi, const float *__restrict__ whhT, const float *__restrict__ bhh,
-                float *__restrict__ out, u64 *__restrict__ xchg, int T) {
+                float *__restrict__ out, u64 *__restrict__ xchg, int *__restrict__ status, int T, unsigned spin_limit) {
     __shared__ __attribute__((aligned(16))) float h_s[4 * GRU_HS];
     __shared__ float g_s[GRU_ROWS];
     __shared__ int dead_s;
@@ -189,23 +198,44 @@ bigru_mc_kernel(const float *__restrict__ gi, const float *__restrict__ whhT, co
                         for (int m = 0; m < GRU_CUS - 1; ++m) h_s[GRU_HS * (idx[m] >> 6) + (idx[m] & 63)] = v[m];
                         break;
                     }
-                    if (++spins > GRU_SPIN_LIMIT) { if (lane == 0) dead_s = 1; break; }
+                    if (++spins > spin_limit) { if (lane == 0) dead_s = 1; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
         }
         __syncthreads();
     }
-    if (dead_s && tid < GRU_UNITS) outb[(size_t)(dir == 0 ? T - 1 : 0) * 2 * GRU_H + tid] = __int_as_float(0x7fc00000);
+    if (dead_s && tid == 0) atomicAdd(&status[2 * b + dir], 1);   // device-scope; read by the launch that follows
 }
 
 }  // namespace rvc
 
 using namespace rvc;
 
+static std::atomic<unsigned> g_spin_limit{GRU_SPIN_LIMIT};
+
+static size_t bigru_xchg_bytes(int batch) { return (size_t)batch * 2 * 2 * GRU_H * sizeof(u64); }
+
 extern "C" int rvc_bigru_workspace_bytes(int batch, size_t *bytes) {
     if (!bytes || batch <= 0) return fail("rvc_bigru_workspace_bytes: bad argument");
-    *bytes = (size_t)batch * 2 * 2 * GRU_H * sizeof(u64);
+    *bytes = bigru_xchg_bytes(batch) + align_up((size_t)batch * 2 * sizeof(int), 256);   // granules, then status words
+    return 0;
+}
+
+extern "C" int rvc_bigru_set_spin_limit(unsigned polls) {
+    g_spin_limit.store(polls ? polls : GRU_SPIN_LIMIT, std::memory_order_relaxed);
+    return 0;
+}
+
+extern "C" int rvc_bigru_status(const void *workspace_dev, int batch, int *n_redone_host, void *stream) {
+    if (!workspace_dev || !n_redone_host || batch <= 0 || batch > 64) return fail("rvc_bigru_status: bad argument");
+    int st[128];
+    RVC_HIP(hipMemcpyAsync(st, (const char *)workspace_dev + bigru_xchg_bytes(batch), (size_t)batch * 2 * sizeof(int),
+                           hipMemcpyDeviceToHost, (hipStream_t)stream));
+    RVC_HIP(hipStreamSynchronize((hipStream_t)stream));
+    int n = 0;
+    for (int i = 0; i < batch * 2; ++i) n += st[i] != 0;
+    *n_redone_host = n;
     return 0;
 }
 
@@ -217,7 +247,7 @@ extern "C" int rvc_bigru_forward(const float *gi_dev, const float *whhT_dev, con
     if (batch <= 0 || n_steps <= 0 || n_steps > (1 << 30)) return fail("rvc_bigru_forward: bad shape");
     if (!workspace_dev) {  // single-workgroup-per-direction variant (weights streamed from L2)
         hipLaunchKernelGGL(bigru_kernel, dim3(2, batch), dim3(GRU_THREADS), 0, (hipStream_t)stream, gi_dev, whhT_dev,
-                           bhh_dev, out_dev, (int)n_steps);
+                           bhh_dev, out_dev, (int)n_steps, (const int *)nullptr);
         RVC_LAUNCH_CHECK();
         return 0;
     }
@@ -225,9 +255,14 @@ extern "C" int rvc_bigru_forward(const float *gi_dev, const float *whhT_dev, con
     if (rvc_bigru_workspace_bytes(batch, &need)) return 1;
     if (workspace_bytes < need) return fail("rvc_bigru_forward: workspace too small (%zu < %zu)", workspace_bytes, need);
     if (batch * 2 * GRU_CUS > 128) return fail("rvc_bigru_forward: batch %d needs %d co-resident workgroups (max 128)", batch, batch * 2 * GRU_CUS);
-    RVC_HIP(hipMemsetAsync(workspace_dev, 0, need, (hipStream_t)stream));  // tags must start below epoch 1 on every call
+    RVC_HIP(hipMemsetAsync(workspace_dev, 0, need, (hipStream_t)stream));  // tags must start below epoch 1 on every call; status = 0
+    int *status = (int *)((char *)workspace_dev + bigru_xchg_bytes(batch));
     hipLaunchKernelGGL(bigru_mc_kernel, dim3(2 * GRU_CUS, batch), dim3(GRU_THREADS), 0, (hipStream_t)stream, gi_dev, whhT_dev,
-                       bhh_dev, out_dev, (u64 *)workspace_dev, (int)n_steps);
+                       bhh_dev, out_dev, (u64 *)workspace_dev, status, (int)n_steps, g_spin_limit.load(std::memory_order_relaxed));
+    RVC_LAUNCH_CHECK();
+    // 2 x batch workgroups that return at once unless their sequence's rendezvous timed out (see bigru_mc_kernel)
+    hipLaunchKernelGGL(bigru_kernel, dim3(2, batch), dim3(GRU_THREADS), 0, (hipStream_t)stream, gi_dev, whhT_dev, bhh_dev,
+                       out_dev, (int)n_steps, (const int *)status);
     RVC_LAUNCH_CHECK();
     return 0;
 }

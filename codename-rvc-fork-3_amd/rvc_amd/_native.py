@@ -60,6 +60,8 @@ SYMBOLS = {
     "rvc_bigru_workspace_bytes": (c_int, [c_int, POINTER(c_size_t)]),
     "rvc_bigru_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_size_t,
                                   c_void_p]),
+    "rvc_bigru_status": (c_int, [c_void_p, c_int, POINTER(c_int), c_void_p]),
+    "rvc_bigru_set_spin_limit": (c_int, [ctypes.c_uint]),
     "rvc_attention_workspace_bytes": (c_int, [c_int, c_int64, c_int, c_int, POINTER(c_size_t)]),
     "rvc_attention_qkv_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_float,
                                       c_void_p, c_size_t, c_void_p]),
@@ -75,9 +77,16 @@ SYMBOLS = {
     "rvc_decoder_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(DecoderNoise), c_int, c_int64,
                                     c_void_p, c_void_p, c_size_t, c_void_p]),
     "rvc_decoder_set_tap": (c_int, [c_void_p, c_int, c_void_p]),
+    "rvc_decoder_set_concurrency_hint": (c_int, [c_void_p, c_int]),
     "rvc_conv1d_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rvc_conv1d_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_int64, c_int, c_int, c_float, c_float, c_void_p]),
+    "rvc_comm_unique_id": (c_int, [c_void_p]),
+    "rvc_comm_create": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    "rvc_comm_destroy": (c_int, [c_void_p]),
+    "rvc_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), c_char_p, c_size_t]),
+    "rvc_index_broadcast": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "rvc_checksum64": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
 }
 
 for _name, (_res, _args) in SYMBOLS.items():
@@ -162,6 +171,23 @@ def knn_blend(index: torch.Tensor, feats: torch.Tensor, d2: torch.Tensor, ids: t
     return out
 
 
+def knn_roofline_report(n_rows: int, n_queries: int, dim: int, seconds: float, peak_hbm_gbs: float,
+                        peak_f32_tflops: float, peak_f16_tflops: float) -> dict:
+    """SURVEY §8d's kNN roofline for one rvc_knn_search of (n_queries x n_rows) that took `seconds`: HBM bytes per
+    query-tile pass x passes, and the MFMA rate the same time corresponds to."""
+    stream = n_queries <= 64
+    q_tile = 32 if stream else 128
+    passes = -(-n_queries // q_tile)
+    bytes_total = passes * n_rows * dim * 4.0
+    flops = 2.0 * n_queries * n_rows * dim
+    return {"kernel": ("knn_direct_kernel" if stream else "knn_partial_kernel") + " + knn_merge_kernel",
+            "shape": f"{n_queries} queries x {n_rows} rows x {dim}", "bound": "hbm", "query_tile": q_tile, "passes": passes,
+            "bytes_per_pass": n_rows * dim * 4, "achieved": round(bytes_total / seconds / 1e9, 1), "peak": peak_hbm_gbs,
+            "unit": "GB/s", "frac": round(bytes_total / seconds / 1e9 / peak_hbm_gbs, 4), "traffic": None,
+            "mfma_tflops": round(flops / seconds / 1e12, 2), "mfma_frac_fp32": round(flops / seconds / 1e12 / peak_f32_tflops, 4),
+            "avg_search_ms": round(seconds * 1e3, 4)}
+
+
 # ---- K4 ------------------------------------------------------------------------------------------
 def logmel_rmvpe(audio: torch.Tensor, pad_to: int = 32) -> tuple[torch.Tensor, int]:
     """audio [B, n] -> (log-mel [B, 128, T_padded], T) with the frame axis reflect-padded to a multiple of pad_to."""
@@ -226,6 +252,22 @@ def bigru_forward(gi: torch.Tensor, whh_t: torch.Tensor, bhh: torch.Tensor, mult
     return out
 
 
+def bigru_redone(batch: int = 1, device=None) -> int:
+    """How many (batch item, direction) sequences of the last multi-workgroup forward on the current stream's workspace
+    had to be recomputed by the single-workgroup kernel (synchronises the stream)."""
+    device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    need = c_size_t()
+    _check(_lib.rvc_bigru_workspace_bytes(batch, ctypes.byref(need)), "rvc_bigru_workspace_bytes")
+    ws = _ws.get("bigru", need.value, device)
+    n = c_int()
+    _check(_lib.rvc_bigru_status(ws.data_ptr(), batch, ctypes.byref(n), _stream()), "rvc_bigru_status")
+    return n.value
+
+
+def bigru_set_spin_limit(polls: int) -> None:
+    _check(_lib.rvc_bigru_set_spin_limit(int(polls)), "rvc_bigru_set_spin_limit")
+
+
 # ---- HuBERT attention -------------------------------------------------------------------------------
 def attention_qkv(qkv: torch.Tensor, n_heads: int, scale: float, emb_rel_k: torch.Tensor = None,
                   emb_rel_v: torch.Tensor = None) -> torch.Tensor:
@@ -273,6 +315,59 @@ def gate_tanh_sigmoid(x: torch.Tensor) -> torch.Tensor:
 
 def set_concurrency_hint(utterances_in_flight: int) -> None:
     _check(_lib.rvc_set_concurrency_hint(int(utterances_in_flight)), "rvc_set_concurrency_hint")
+
+
+# ---- multi-GPU: RCCL index broadcast + device checksum ----------------------------------------------
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    _check(_lib.rvc_comm_unique_id(buf), "rvc_comm_unique_id")
+    return buf.raw
+
+
+class Comm:
+    """RCCL communicator of the job (one rank per GPU), created collectively from rank 0's 128-byte id."""
+
+    def __init__(self, unique_id: bytes, n_ranks: int, rank: int):
+        assert len(unique_id) == COMM_ID_BYTES
+        self._h = c_void_p()
+        _check(_lib.rvc_comm_create(ctypes.create_string_buffer(unique_id, COMM_ID_BYTES), int(n_ranks), int(rank),
+                                    ctypes.byref(self._h)), "rvc_comm_create")
+
+    def info(self) -> dict:
+        n, r, v = c_int(), c_int(), c_int()
+        path = ctypes.create_string_buffer(512)
+        _check(_lib.rvc_comm_info(self._h, ctypes.byref(n), ctypes.byref(r), ctypes.byref(v), path, 512), "rvc_comm_info")
+        return {"n_ranks": n.value, "rank": r.value, "rccl_version": v.value, "library": path.value.decode()}
+
+    def broadcast_(self, t: torch.Tensor, root: int = 0) -> torch.Tensor:
+        """In-place broadcast of a contiguous HBM tensor's bytes from ``root`` on torch's current stream."""
+        if not t.is_cuda or not t.is_contiguous():
+            raise NativeError("Comm.broadcast_ wants a contiguous HBM tensor")
+        _check(_lib.rvc_index_broadcast(self._h, t.data_ptr(), t.numel() * t.element_size(), int(root), _stream()),
+               "rvc_index_broadcast")
+        return t
+
+    def destroy(self):
+        h, self._h = self._h, None
+        if h:
+            _check(_lib.rvc_comm_destroy(h), "rvc_comm_destroy")
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.rvc_comm_destroy(self._h)
+            self._h = None
+
+
+def checksum64(t: torch.Tensor) -> torch.Tensor:
+    """[2] int64 device tensor: (sum of 32-bit words, sum of (i+1)*word_i) mod 2^64 of the tensor's bytes, computed in HBM."""
+    if not t.is_cuda or not t.is_contiguous():
+        raise NativeError("checksum64 wants a contiguous HBM tensor")
+    out = torch.empty(2, dtype=torch.int64, device=t.device)
+    _check(_lib.rvc_checksum64(t.data_ptr(), t.numel() * t.element_size(), out.data_ptr(), _stream()), "rvc_checksum64")
+    return out
 
 
 # ---- conv1d (unit-test entry) ----------------------------------------------------------------------
@@ -343,6 +438,9 @@ class Decoder:
         if h and _lib is not None:  # _lib is None during interpreter shutdown
             _lib.rvc_decoder_destroy(h)
             self._h = None
+
+    def set_concurrency_hint(self, utterances_in_flight: int):
+        _check(_lib.rvc_decoder_set_concurrency_hint(self._h, int(utterances_in_flight)), "rvc_decoder_set_concurrency_hint")
 
     def set_tap(self, stage: int, tap: torch.Tensor | None):
         _check(_lib.rvc_decoder_set_tap(self._h, stage, tap.data_ptr() if tap is not None else None),

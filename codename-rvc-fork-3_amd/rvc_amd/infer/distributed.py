@@ -1,20 +1,31 @@
 """Multi-GPU batch conversion: one process per GPU, utterances sharded by striding, the feature index
-replicated with ONE broadcast at load time (RCCL over xGMI on a GPU node, gloo in CPU tests).
+replicated with ONE RCCL broadcast over xGMI at load time.
 
 The reference converts batches with a sequential loop on one device (rvc/infer/infer.py:396-406); its only
-multi-GPU precedent is the file striding of feature extraction, ``files[i::len(devices)]``
-(rvc/train/extract/extract.py:145,198), which is the partitioning used here.  Utterances share no state, so
-the steady state has no collective at all; a final reduce of (samples, seconds) produces the report.
+multi-GPU precedent is feature extraction, which starts one worker per device itself and strides the file list,
+``files[i::len(devices)]`` (rvc/train/extract/extract.py:141-152, 198).  Both are mirrored here: ``spawn_ranks``
+starts the per-GPU processes, ``shard_indices`` is the striding.  Utterances share no state, so the steady state
+has no collective at all; a final reduce of (samples, seconds) produces the report.
+
+Transport: on GPUs the index travels through librvc_amd's own RCCL communicator (``rvc_index_broadcast``,
+include/rvc_amd.h) -- torch.distributed only carries the 128-byte communicator id and the few report scalars.
+Tensors that live on the host (the world_size-2 gloo tests on CPU) take torch.distributed's gloo broadcast instead;
+that branch is chosen by where the caller's tensor lives, never as a fallback for a failed RCCL call.
 """
 from __future__ import annotations
 
 import os
-import zlib
+import socket
+import subprocess
+import sys
+import time
 from typing import Callable, List, Sequence
 
 import numpy as np
 import torch
 import torch.distributed as dist
+
+_MASK64 = (1 << 64) - 1
 
 
 def env_rank_world():
@@ -22,55 +33,142 @@ def env_rank_world():
 
 
 def init_process_group(backend: str | None = None):
-    """Idempotent init from the torchrun environment; returns (rank, world, local_rank)."""
+    """Idempotent init from the torchrun-style environment; returns (rank, world, local_rank).
+
+    On GPUs the group is "cpu:gloo,cuda:nccl" ("nccl" is RCCL on ROCm): device tensors (barrier, report reduce) go over
+    RCCL, the 128-byte communicator id over gloo.  RVC_DIST_BACKEND=gloo lets several ranks share one GPU or none
+    (control-flow tests)."""
     rank, world, local = env_rank_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            # "nccl" is RCCL on ROCm; RVC_DIST_BACKEND=gloo lets several ranks share one GPU (control-flow tests)
-            backend = os.environ.get("RVC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        if backend == "nccl":
+            backend = os.environ.get("RVC_DIST_BACKEND") or ("cpu:gloo,cuda:nccl" if torch.cuda.is_available() else "gloo")
+        if "nccl" in backend:
             torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 
 def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
-    """utterance i -> rank i mod world"""
+    """utterance i -> rank i mod world (extract.py:145: ``files[i::len(devices)]``)"""
     return list(range(rank, n_items, world))
 
 
-def broadcast_index(big_npy, device, src: int = 0) -> torch.Tensor:
-    """Replicate the N x 768 fp32 feature index from rank ``src``: one broadcast of its shape, one of its bytes.
+def _has_gloo() -> bool:
+    """Can the default group move host tensors?"""
+    try:
+        cfg = str(dist.get_backend_config())
+    except Exception:
+        cfg = str(dist.get_backend())
+    return "gloo" in cfg.lower()
 
-    Returns the device tensor on every rank.  Ranks other than ``src`` pass ``big_npy=None``."""
+
+# ---- the one collective: index replication -----------------------------------------------------------------------
+_comm = None          # librvc_amd RCCL communicator of this process (one per job)
+_last_broadcast = {}  # facts of the last broadcast_index call, for the bench report
+
+
+def native_comm():
+    """The job-wide RCCL communicator behind the C ABI, created on first use: rank 0 draws the id, torch.distributed
+    hands its 128 bytes round, every rank joins on its own GPU."""
+    global _comm
+    if _comm is not None:
+        return _comm
+    from rvc_amd import _native
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    if world == 1:
+    ident = torch.zeros(_native.COMM_ID_BYTES, dtype=torch.uint8)
+    if rank == 0:
+        ident = torch.frombuffer(bytearray(_native.comm_unique_id()), dtype=torch.uint8).clone()
+    if world > 1:
+        if _has_gloo():
+            dist.broadcast(ident, 0)
+        else:   # an nccl-only group set up by somebody else: the id rides a device tensor
+            ident_dev = ident.cuda()
+            dist.broadcast(ident_dev, 0)
+            ident = ident_dev.cpu()
+    _comm = _native.Comm(bytes(ident.numpy().tobytes()), world, rank)
+    return _comm
+
+
+def destroy_native_comm():
+    global _comm
+    if _comm is not None:
+        _comm.destroy()
+        _comm = None
+
+
+def broadcast_index(big_npy, device, src: int = 0, force_rccl: bool = False) -> torch.Tensor:
+    """Replicate the N x dim fp32 feature index from rank ``src``: its shape, then ONE broadcast of its bytes.
+
+    Returns the resident tensor on every rank; ranks other than ``src`` pass ``big_npy=None``.  ``force_rccl`` runs the
+    RCCL broadcast even in a single-rank job (bench.py does, so that a 1-GPU run still proves the library path)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    on_gpu = torch.device(device).type == "cuda"
+    _last_broadcast.clear()
+    if world == 1 and not (force_rccl and on_gpu):
         return torch.as_tensor(big_npy, dtype=torch.float32).to(device).contiguous()
-    shape = torch.zeros(2, dtype=torch.int64, device=device)
+    shape = torch.zeros(2, dtype=torch.int64)
     if rank == src:
         t = torch.as_tensor(big_npy, dtype=torch.float32).to(device).contiguous()
         shape[0], shape[1] = t.shape
-    dist.broadcast(shape, src)
+    if world > 1:
+        if _has_gloo():
+            dist.broadcast(shape, src)
+        else:
+            shape_dev = shape.to(device)
+            dist.broadcast(shape_dev, src)
+            shape = shape_dev.cpu()
     if rank != src:
         t = torch.empty((int(shape[0]), int(shape[1])), dtype=torch.float32, device=device)
-    dist.broadcast(t, src)
+    if on_gpu:
+        comm = native_comm()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        comm.broadcast_(t, src)
+        torch.cuda.synchronize()
+        seconds = time.perf_counter() - t0
+        _last_broadcast.update(comm.info(), seconds=seconds, bytes=t.numel() * 4, transport="rccl (rvc_index_broadcast)")
+    else:
+        t0 = time.perf_counter()
+        dist.broadcast(t, src)
+        _last_broadcast.update(n_ranks=world, rank=rank, seconds=time.perf_counter() - t0, bytes=t.numel() * 4,
+                               transport="gloo (host tensors)")
     return t
 
 
-def tensor_checksum(t: torch.Tensor) -> int:
-    """crc32 of the raw bytes (verification that every rank holds the root's index)."""
-    return zlib.crc32(t.detach().cpu().contiguous().numpy().tobytes())
+def last_broadcast_info() -> dict:
+    return dict(_last_broadcast)
+
+
+def tensor_checksum(t: torch.Tensor):
+    """(sum of the 32-bit words, sum of (i+1)*word_i) mod 2^64 of the tensor's bytes.  HBM tensors are reduced on the
+    device (rvc_checksum64: the index never crosses PCIe again); host tensors (CPU tests) with the same formula in NumPy."""
+    t = t.detach().contiguous()
+    if t.is_cuda:
+        from rvc_amd import _native
+        s = _native.checksum64(t).cpu().numpy().view(np.uint64)
+        return int(s[0]), int(s[1])
+    raw = t.numpy().tobytes()
+    raw += b"\0" * (-len(raw) % 4)
+    w = np.frombuffer(raw, dtype="<u4").astype(np.uint64)
+    with np.errstate(over="ignore"):
+        s1 = int(w.sum(dtype=np.uint64))
+        s2 = int((w * np.arange(1, w.size + 1, dtype=np.uint64)).sum(dtype=np.uint64))
+    return s1 & _MASK64, s2 & _MASK64
 
 
 def checksums_agree(t: torch.Tensor) -> bool:
-    c = torch.tensor([tensor_checksum(t)], dtype=torch.int64, device=t.device)
+    """True when every rank holds the same bytes (MIN == MAX of both checksum words over the ranks)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return True
+    s1, s2 = tensor_checksum(t)
+    # int64 views of the two words, split in 32-bit halves so MIN/MAX compare exactly whatever the sign
+    c = torch.tensor([s1 >> 32, s1 & 0xFFFFFFFF, s2 >> 32, s2 & 0xFFFFFFFF], dtype=torch.int64, device=t.device)
     lo, hi = c.clone(), c.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-    return bool(lo.item() == hi.item())
+    return bool(torch.equal(lo, hi))
 
 
 def convert_sharded(utterances: Sequence, convert: Callable, rank: int, world: int):
@@ -87,3 +185,53 @@ def reduce_report(samples: int, seconds: float, device):
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return int(s.item()), float(t.item())
+
+
+# ---- starting the ranks (extract.py:141-152 starts its per-device workers itself; so does this) ------------------
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(argv: Sequence[str], n_ranks: int, env_extra: dict | None = None, timeout: float | None = None) -> int:
+    """Start ``n_ranks`` copies of ``argv`` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, one per
+    GPU, and wait for them; returns the first non-zero exit code (0 if all succeeded).  Rank 0 inherits stdout, so its
+    report line is the parent's.  When a rank fails the others are terminated (by PID) instead of being left at a barrier.
+
+    The caller must not have touched the GPU: children are plain new processes (never an exec of a process that has
+    initialised HIP)."""
+    port = free_port()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    deadline = None if timeout is None else time.time() + timeout
+    rc = 0
+    alive = set(range(n_ranks))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is not None:
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"[spawn_ranks] rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+        if rc != 0 or (deadline is not None and time.time() > deadline):
+            if rc == 0:
+                rc = 124
+                print(f"[spawn_ranks] timeout after {timeout} s; stopping all ranks", file=sys.stderr)
+            for r in alive:
+                procs[r].terminate()
+            for r in alive:
+                try:
+                    procs[r].wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            break
+        time.sleep(0.05)
+    return rc

@@ -57,6 +57,7 @@ class VoiceConverter:
         self.n_spk = None
         self.use_f0 = None
         self.loaded_model = None
+        self.dec_weight_dtype = "f32"   # "bf16": the vocoder's conv weights are stored as bf16 in HBM (BASELINE cfg 4)
 
     # ---- embedder (infer.py:64-74; file layout rvc/lib/utils.py:96-146) ----
     def load_hubert(self, embedder_model: str, embedder_model_custom: str = None):
@@ -101,6 +102,7 @@ class VoiceConverter:
             self.net_g = Synthesizer(*self.cpt["config"], use_f0=self.use_f0,
                                      text_enc_hidden_dim=self.text_enc_hidden_dim, vocoder=self.vocoder)
             del self.net_g.enc_q
+            self.net_g.dec_weight_dtype = self.dec_weight_dtype
             self.net_g.load_state_dict(self.cpt["weight"], strict=False)
             self.net_g = self.net_g.to(self.config.device).float()
             self.net_g.eval()
@@ -187,8 +189,7 @@ class VoiceConverter:
             except Exception as error:  # surfaced after the join
                 errors.append(error)
 
-        from rvc_amd import _native
-        _native.set_concurrency_hint(n_workers)
+        self.net_g.dec.set_concurrency_hint(n_workers)   # per decoder handle: other converters in the process are unaffected
         threads = [threading.Thread(target=work, args=(t,)) for t in range(n_workers)]
         try:
             for t in threads:
@@ -196,7 +197,7 @@ class VoiceConverter:
             for t in threads:
                 t.join()
         finally:
-            _native.set_concurrency_hint(1)
+            self.net_g.dec.set_concurrency_hint(0)
         for stream in self._batch_streams[:n_workers]:
             torch.cuda.current_stream(dev).wait_stream(stream)
         if errors:

@@ -13,6 +13,7 @@ Signatures and defaults follow the reference; additions are keyword-only and opt
 from __future__ import annotations
 
 import os
+import threading
 
 import numpy as np
 import torch
@@ -101,6 +102,8 @@ class FeatureIndex:
         self.vectors = big_npy.to(device=device, dtype=torch.float32).contiguous()
         self.norms = _native.knn_index_norms(self.vectors)
         self.ntotal = int(self.vectors.shape[0])
+        # built on the loading thread's stream; utterances on other streams (convert_batch) read it afterwards
+        torch.cuda.current_stream(self.vectors.device).synchronize()
 
     def __bool__(self):
         return True
@@ -144,10 +147,12 @@ class Pipeline:
         self.device = config.device
         rmvpe_path = os.path.join("rvc", "models", "predictors", "rmvpe.pt")  # pipeline.py:207-210
         self.model_rmvpe = RMVPE0Predictor(rmvpe_path if os.path.isfile(rmvpe_path) else None, device=self.device)
+        # shared by the host threads of VoiceConverter.convert_batch: filled under the lock, read-only afterwards
+        self._lock = threading.Lock()
         self._index_cache = {}
         self._preset_index = None
         self._f0_streams = {}      # side stream per caller stream (several utterances may be in flight)
-        self._coarse_thr = None
+        self._coarse_thr = torch.from_numpy(self._coarse_thresholds()).to(self.device)
         self.ref_freqs = REF_FREQS
         self.autotune = Autotune(self.ref_freqs)
         self.note_dict = self.autotune.note_dict
@@ -165,13 +170,16 @@ class Pipeline:
             return None
         if file_index != "" and os.path.exists(file_index):
             key = (file_index, os.path.getmtime(file_index))
-            if key not in self._index_cache:
-                try:
-                    self._index_cache = {key: FeatureIndex(_load_index_file(file_index), self.device)}
-                except Exception as error:  # pipeline.py:557-559: warn and continue without retrieval
-                    print(f"An error occurred reading the FAISS index: {error}")
-                    return None
-            return self._index_cache[key]
+            with self._lock:   # one thread loads and uploads; the others wait and share the resident copy
+                index = self._index_cache.get(key)
+                if index is None:
+                    try:
+                        index = FeatureIndex(_load_index_file(file_index), self.device)
+                    except Exception as error:  # pipeline.py:557-559: warn and continue without retrieval
+                        print(f"An error occurred reading the FAISS index: {error}")
+                        return None
+                    self._index_cache = {key: index}
+            return index
         return self._preset_index
 
     # ---- F0 ------------------------------------------------------------------------------------------------
@@ -229,8 +237,6 @@ class Pipeline:
     def _postprocess_f0_device(self, f0, pitch):
         """`_postprocess_f0` without leaving HBM (no f0 file, no autotune): same key shift (one float64 multiply) and
         the same coarse integers, read off the threshold table instead of re-evaluating log on the device."""
-        if self._coarse_thr is None:
-            self._coarse_thr = torch.from_numpy(self._coarse_thresholds()).to(self.device)
         f0 = f0 * pow(2, pitch / 12)
         coarse = torch.searchsorted(self._coarse_thr, f0, right=True) + 1
         return coarse, f0
@@ -362,9 +368,10 @@ class Pipeline:
             # main stream, then the recurrence + decode + pitch quantisation run on a side stream underneath HuBERT
             # and the retrieval, so f0 is ready before the synthesizer needs it and no CU idles waiting for the GRU.
             main = torch.cuda.current_stream()
-            side = self._f0_streams.get(main.cuda_stream)
-            if side is None:
-                side = self._f0_streams[main.cuda_stream] = torch.cuda.Stream(device=self.device)
+            with self._lock:
+                side = self._f0_streams.get(main.cuda_stream)
+                if side is None:
+                    side = self._f0_streams[main.cuda_stream] = torch.cuda.Stream(device=self.device)
             if f0_method != "rmvpe":
                 raise NotImplementedError(f"f0_method={f0_method!r}: only 'rmvpe' is implemented")
             gi, n_f0 = self.model_rmvpe.front_half_device(audio_dev)

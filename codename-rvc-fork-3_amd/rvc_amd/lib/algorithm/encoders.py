@@ -22,16 +22,24 @@ def channel_layer_norm(x, gamma, beta, eps=1e-5):
     return F.layer_norm(x.transpose(1, -1), (x.shape[1],), gamma, beta, eps).transpose(1, -1)
 
 
-def _rel_attention_hip(x, w: Dict[str, torch.Tensor], p: str, n_heads: int):
-    """Unmasked layer on the GPU: one fused q/k/v GEMM, librvc_amd K7 (scores, relative terms, softmax, PV in one
-    launch + a split combine), output projection.  Time-major in between, so no [T, T] tensor is ever materialised."""
-    from rvc_amd import _native
-    if p + ".qkv.weight" not in w:   # fused once per state dict
+def prepare_attention_weights(w: Dict[str, torch.Tensor], n_layers: int) -> None:
+    """Fused q/k/v projection and friends, built once when the state dict reaches the device (Synthesizer._to_device):
+    forwards on several host threads share `w` and must find it complete."""
+    for i in range(n_layers):
+        p = f"enc_p.encoder.attn_layers.{i}"
+        if p + ".conv_q.weight" not in w:
+            continue
         w[p + ".qkv.weight"] = torch.cat([w[p + f".conv_{n}.weight"][:, :, 0] for n in "qkv"], 0).contiguous()
         w[p + ".qkv.bias"] = torch.cat([w[p + f".conv_{n}.bias"] for n in "qkv"], 0).contiguous()
         w[p + ".o.weight"] = w[p + ".conv_o.weight"][:, :, 0].contiguous()
         w[p + ".ek"] = w[p + ".emb_rel_k"][0].contiguous()
         w[p + ".ev"] = w[p + ".emb_rel_v"][0].contiguous()
+
+
+def _rel_attention_hip(x, w: Dict[str, torch.Tensor], p: str, n_heads: int):
+    """Unmasked layer on the GPU: one fused q/k/v GEMM, librvc_amd K7 (scores, relative terms, softmax, PV in one
+    launch + a split combine), output projection.  Time-major in between, so no [T, T] tensor is ever materialised."""
+    from rvc_amd import _native
     d = x.shape[1]
     qkv = F.linear(x.transpose(1, 2), w[p + ".qkv.weight"], w[p + ".qkv.bias"]).contiguous()
     a = _native.attention_qkv(qkv, n_heads, 1.0 / math.sqrt(d // n_heads), w[p + ".ek"], w[p + ".ev"])

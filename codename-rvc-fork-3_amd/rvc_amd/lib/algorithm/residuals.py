@@ -26,6 +26,14 @@ def wavenet(x, x_mask, g_cond, w: Dict[str, torch.Tensor], p: str, hidden=192, n
     return output * x_mask
 
 
+def prepare_flow_weights(w: Dict[str, torch.Tensor], n_layers: int = 3) -> None:
+    """The WaveNet in_layer biases of each coupling layer as one vector (the conditioning is added to it per call); built
+    once at load, like encoders.prepare_attention_weights."""
+    for key in [k for k in w if k.endswith(".enc.cond_layer.weight")]:
+        q = key[:-len(".cond_layer.weight")]
+        w[q + ".in_bias"] = torch.cat([w[f"{q}.in_layers.{i}.bias"] for i in range(n_layers)])
+
+
 def _flow_reverse_full(w: Dict[str, torch.Tensor], z_p, g, half, hidden, n_flows, n_layers=3, k=5):
     """B == 1, every frame valid: no mask multiplies, the conditioning folded into the in_layer biases, the gate as
     one librvc_amd kernel (tanh * sigmoid of the two halves) instead of add + tanh + sigmoid + mul.  The convs stay
@@ -39,8 +47,6 @@ def _flow_reverse_full(w: Dict[str, torch.Tensor], z_p, g, half, hidden, n_flows
         q = p + ".enc"
         x0, x1 = x[:, :half], x[:, half:]
         h = F.conv1d(x0, w[p + ".pre.weight"], w[p + ".pre.bias"])
-        if q + ".in_bias" not in w:
-            w[q + ".in_bias"] = torch.cat([w[f"{q}.in_layers.{i}.bias"] for i in range(n_layers)])
         bias_all = F.conv1d(g, w[q + ".cond_layer.weight"], w[q + ".cond_layer.bias"]).view(-1) + w[q + ".in_bias"]
         skip = None
         for i in range(n_layers):

@@ -24,8 +24,8 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from rvc_amd.lib.algorithm.encoders import text_encoder
-from rvc_amd.lib.algorithm.residuals import flow_reverse
+from rvc_amd.lib.algorithm.encoders import prepare_attention_weights, text_encoder
+from rvc_amd.lib.algorithm.residuals import flow_reverse, prepare_flow_weights
 from rvc_amd.lib.algorithm.weights import fold_weight_norm
 
 
@@ -51,11 +51,14 @@ class Synthesizer:
         self.w: Dict[str, torch.Tensor] = {}
         self._dec_weights: Optional[Dict[str, torch.Tensor]] = None
         self.dec = None
+        self.dec_weight_dtype = "f32"   # "bf16": BASELINE cfg 4, the vocoder's weights are bf16 values
 
     # ---- nn.Module-like surface used by the reference's loader ----
     def load_state_dict(self, state_dict, strict: bool = False):
         w = fold_weight_norm({k: v for k, v in state_dict.items() if not k.startswith("enc_q.")})
         self._dec_weights = {k[4:]: v for k, v in w.items() if k.startswith("dec.")}
+        if self.dec_weight_dtype == "bf16":   # after weight-norm folding: what a bf16 copy of the folded tensor holds
+            self._dec_weights = {k: v.float().bfloat16().float() for k, v in self._dec_weights.items()}
         self.w = {k: v for k, v in w.items() if not k.startswith("dec.")}
         self.dec = None
         if self.device.type == "cuda":
@@ -65,6 +68,11 @@ class Synthesizer:
     def _to_device(self):
         from rvc_amd import _native
         self.w = {k: v.to(self.device) for k, v in self.w.items()}
+        # derived tensors are built HERE, once, on the loading thread: forwards run concurrently on several host threads
+        # and streams (VoiceConverter.convert_batch) and only ever read self.w
+        prepare_attention_weights(self.w, self.n_layers)
+        prepare_flow_weights(self.w)
+        torch.cuda.synchronize(self.device)   # visible to every stream that will use them
         if self._dec_weights is not None and self.dec is None:
             with torch.cuda.device(self.device):
                 self.dec = _native.Decoder(self.vocoder, self.sr, self._dec_weights, in_channels=self.inter_channels,

@@ -13,8 +13,10 @@
  *     asynchronous on it; 0 / NULL = the default stream;
  *   - every function returns 0 on success, non-zero on error; rvc_last_error() describes the last failure
  *     of the calling thread;
- *   - a handle is bound to the device that was current when it was created and is not thread-safe;
- *     distinct handles are independent;
+ *   - a handle is bound to the device that was current when it was created; distinct handles are independent.
+ *     rvc_decoder_forward only READS the handle (weights, tables) and works in the caller's workspace, so several threads
+ *     may run forwards of one handle concurrently, each with its own stream and workspace (VoiceConverter.convert_batch
+ *     does); create / set_tensor / finalize / set_tap / destroy must not overlap any other call on the same handle;
  *   - tensors are dense, row-major, fp32 unless said otherwise.
  */
 #ifndef RVC_AMD_H
@@ -90,8 +92,16 @@ int rvc_filtfilt_order5(const double *x_dev, int64_t n, const double *coef_host,
  * whhT_dev [2][256][768] = W_hh transposed per direction, bhh_dev [2][768]; out_dev [batch][n_steps][512]
  * (forward hidden in [0,256), reverse in [256,512), as torch lays it out).
  * workspace_dev: rvc_bigru_workspace_bytes() bytes of scratch for the multi-workgroup variant (4 workgroups per
- * direction exchange h through it); NULL selects the single-workgroup-per-direction variant. */
+ * direction exchange h through it); NULL selects the single-workgroup-per-direction variant.
+ * The multi-workgroup variant needs its 8 workgroups running at the same time.  A launch that shares the GPU with other
+ * streams may see them start late; every wait is bounded, and a (batch item, direction) whose wait ran out is
+ * recomputed by the single-workgroup recurrence inside the same call (device-side decision, no host round trip).
+ * rvc_bigru_status reports, after synchronising `stream`, how many (batch item, direction) pairs of the LAST forward on
+ * that workspace were recomputed; rvc_bigru_set_spin_limit changes the bound (polls per wait; 0 restores the default
+ * 2^22) -- a test hook to force the recompute path. */
 int rvc_bigru_workspace_bytes(int batch, size_t *bytes);
+int rvc_bigru_status(const void *workspace_dev, int batch, int *n_redone_host, void *stream);
+int rvc_bigru_set_spin_limit(unsigned polls);
 int rvc_bigru_forward(const float *gi_dev, const float *whhT_dev, const float *bhh_dev, float *out_dev,
                       int batch, int64_t n_steps, int hidden, void *workspace_dev, size_t workspace_bytes, void *stream);
 
@@ -125,9 +135,11 @@ int rvc_bias_relu_add_f32(const float *x_dev, const float *bias_dev, const float
  * out_dev [batch][hidden][length]. */
 int rvc_gate_tanh_sigmoid_f32(const float *x_dev, float *out_dev, int batch, int hidden, int64_t length, void *stream);
 
-/* Scheduling hint, process-wide: how many utterances the caller keeps in flight on separate streams (default 1).  With
- * more than one, kernels stop shrinking their tiles to balance a launch across the CUs on its own -- the other streams
- * fill the idle block slots, and the larger tiles re-read their weights from L2 half as often.  No effect on results. */
+/* Scheduling hint: how many utterances the caller keeps in flight on separate streams (default 1).  With more than one,
+ * kernels stop shrinking their tiles to balance a launch across the CUs on its own -- the other streams fill the idle
+ * block slots, and the larger tiles re-read their weights from L2 half as often.  No effect on results.
+ * This one is the process-wide default (used by rvc_conv1d_forward and by decoder handles without a hint of their own);
+ * rvc_decoder_set_concurrency_hint below sets it per handle, so that two converters in one process do not share it. */
 int rvc_set_concurrency_hint(int utterances_in_flight);
 
 /* ---- K2/K3: vocoder ("dec" of Synthesizer) ---------------------------------------------------- *
@@ -187,6 +199,10 @@ int rvc_decoder_forward(rvc_decoder *dec, const float *z_dev, const float *f0_de
                         const rvc_decoder_noise *noise, int batch, int64_t n_frames, float *out_dev,
                         void *workspace_dev, size_t workspace_bytes, void *stream);
 
+/* Per-handle scheduling hint (see rvc_set_concurrency_hint); 0 = follow the process-wide default.  May be called while
+ * forwards of this handle are running on other threads: it only affects forwards that start afterwards. */
+int rvc_decoder_set_concurrency_hint(rvc_decoder *dec, int utterances_in_flight);
+
 /* Debug hook for the parity tests: after stage `stage` of the next forward calls, copy that stage's output
  * ([batch][C_stage][L_stage], the mean of the three ResBlocks) to tap_dev; stage -1 = har_source [batch][T*upp].
  * tap_dev = NULL switches it off. */
@@ -202,6 +218,31 @@ int rvc_conv1d_forward(const float *x_dev, const float *w_packed_dev, const floa
                        const float *res_dev, const float *acc_dev, float *y_dev,
                        int batch, int c_in, int c_out, int64_t length, int k, int dilation,
                        float slope_in, float out_scale, void *stream);
+
+/* ---- multi-GPU: index replication ---------------------------------------------------------------- *
+ * The path shards by utterance, one process per GPU (the reference's own multi-GPU precedent is the file striding of
+ * rvc/train/extract/extract.py:141-152, 198); its only exchange is making `big_npy` (pipeline.py:556) resident on
+ * every GPU, which replaces the per-call `faiss.read_index` of pipeline.py:555 on each worker.  These entries wrap RCCL
+ * (bound at run time, so a single-GPU process never loads it):
+ *   rank 0:      rvc_comm_unique_id(id)  ->  the host side hands the 128 bytes to every rank (TCP store, file, ...)
+ *   every rank:  rvc_comm_create(id, n_ranks, rank, &comm)      collective, on the rank's own current device
+ *                rvc_index_broadcast(comm, buf, bytes, root, stream)   ONE ncclBroadcast of raw bytes, in place
+ *                rvc_checksum64(buf, bytes, out2, stream)       replica == root's?  (compare the two words across ranks)
+ *                rvc_comm_destroy(comm)
+ * A communicator is bound to the device current at creation; calls on one communicator must not be concurrent. */
+typedef struct rvc_comm rvc_comm;
+#define RVC_COMM_ID_BYTES 128
+int rvc_comm_unique_id(unsigned char *id_host /* [RVC_COMM_ID_BYTES] */);
+int rvc_comm_create(const unsigned char *id_host, int n_ranks, int rank, rvc_comm **out);
+int rvc_comm_destroy(rvc_comm *comm);
+/* n_ranks as RCCL reports it (ncclCommCount), this rank, RCCL's version code, and which librccl was bound; comm may be
+ * NULL (library facts only) and any output pointer may be NULL. */
+int rvc_comm_info(const rvc_comm *comm, int *n_ranks, int *rank, int *rccl_version, char *library_path,
+                  size_t library_path_bytes);
+int rvc_index_broadcast(rvc_comm *comm, void *buf_dev, size_t bytes, int root, void *stream);
+/* out2_dev[0] = sum of the buffer's little-endian 32-bit words, out2_dev[1] = sum of (i + 1) * word_i, both mod 2^64
+ * (a trailing 1-3 bytes are zero-extended into a last word).  Computed in HBM: the index never crosses PCIe. */
+int rvc_checksum64(const void *buf_dev, size_t bytes, uint64_t *out2_dev, void *stream);
 
 #ifdef __cplusplus
 }

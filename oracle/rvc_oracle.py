@@ -780,13 +780,14 @@ def voice_conversion(hubert_sd, cpt, w, sid: Tensor, audio0: np.ndarray, pitch: 
 
 def pipeline(hubert_sd, rmvpe_sd, cpt, audio: np.ndarray, *, sid=0, pitch=0, big_npy=None, index_rate=0.0,
              protect=0.5, noise=None, knn_dtype=np.float64, taps=None, volume_envelope=1, f0_autotune=False,
-             f0_autotune_strength=1) -> np.ndarray:
-    """Pipeline.pipeline, pipeline.py:509-694, rmvpe branch."""
+             f0_autotune_strength=1, x_query=X_QUERY, x_center=X_CENTER, x_max=X_MAX) -> np.ndarray:
+    """Pipeline.pipeline, pipeline.py:509-694, rmvpe branch.  x_query / x_center / x_max: the memory-tier constants of
+    rvc/configs/config.py:116-121 that Pipeline.__init__ reads from its config object (pipeline.py:124-127)."""
     tgt_sr = cpt["config"][-1]
     w = fold_weight_norm(cpt["weight"])
     t_pad, t_pad_tgt = 16000 * X_PAD, tgt_sr * X_PAD
     audio = highpass(audio)
-    opt_ts = split_points(audio)
+    opt_ts = split_points(audio, x_query, x_center, x_max)
     audio_pad = np.pad(audio, (t_pad, t_pad), mode="reflect")
     p_len = audio_pad.shape[0] // WINDOW
     sid_t = torch.tensor(sid).unsqueeze(0).long()

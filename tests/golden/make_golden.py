@@ -209,8 +209,51 @@ def main():
         save(f"pipeline_{tag}", audio=audio, out=out.astype(np.float32), seed=np.int64(4321), sid=np.int64(2),
              pitch=np.int64(2), index_rate=np.float64(idx_rate), protect=np.float64(protect))
         print(f"    pipeline {tag}: {out.shape[0]} samples rms {np.sqrt((out ** 2).mean()):.4f}")
+    multiseg(hub, big)
+
+
+class CfgSmall:
+    """A smaller memory tier (config.py:116-121 chooses these constants by GPU memory): the segmentation branch of
+    pipeline.py:563-577, 614-680 triggers on a few seconds of audio instead of > 41 s, so the fixture stays small."""
+    x_pad, x_query, x_center, x_max, device = 1, 1, 3, 4, "cpu"
+
+
+def multiseg(hub=None, big=None):
+    """10. multi-segment Pipeline.pipeline: 3 segments cut at quiet points, per-segment HuBERT + Synthesizer noise draws
+    from ONE seeded CPU generator stream, crops, concatenation (pipeline.py:563-577, 614-681)."""
+    if hub is None:
+        hub = HubertModel(HubertConfig()).eval()
+        hsd = S.make_hubert_state_dict(1)
+        hub.load_state_dict({k: v for k, v in hsd.items() if not k.startswith("final_proj")}, strict=False)
+    if big is None:
+        big = S.synth_index(4096, seed=0)
+    ref_pipeline.faiss.read_index = lambda path: BruteIndex(big)
+    open(os.path.join(scratch, "fake.index"), "w").close()
+    audio = S.synth_audio(16000 * 8 + 1234, seed=45)
+    cpt = S.make_synth_checkpoint(48000, "HiFi-GAN", seed=0)
+    net = build_net(cpt)
+    vcp = Pipeline(48000, CfgSmall())
+    calls = []
+    real_vc = vcp.voice_conversion
+
+    def recording_vc(model, net_g, sid, audio0, pitch, pitchf, *a, **k):
+        calls.append((audio0.shape[0], pitch.shape[1]))
+        return real_vc(model, net_g, sid, audio0, pitch, pitchf, *a, **k)
+
+    vcp.voice_conversion = recording_vc
+    torch.manual_seed(777)
+    out = vcp.pipeline(hub, net, 1, audio.copy(), 0, "rmvpe", os.path.join(scratch, "fake.index"), 0.75, True, 3, 1, "v2",
+                       0.5, 128, False, 1, None)
+    assert len(calls) == 3, calls
+    save("pipeline_multiseg", audio=audio, out=out.astype(np.float32), seed=np.int64(777), sid=np.int64(1),
+         index_rate=np.float64(0.75), protect=np.float64(0.5), x_query=np.int64(1), x_center=np.int64(3),
+         x_max=np.int64(4), segs=np.array(calls, dtype=np.int64))
+    print(f"    pipeline multiseg: segments {calls} -> {out.shape[0]} samples rms {np.sqrt((out ** 2).mean()):.4f}")
 
 
 if __name__ == "__main__":
-    main()
+    if "--only-multiseg" in sys.argv:
+        multiseg()
+    else:
+        main()
     shutil.rmtree(scratch, ignore_errors=True)

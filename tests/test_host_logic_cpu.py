@@ -66,8 +66,8 @@ def test_f0_postprocess_device_table_equals_host_formula():
     import torch
     g = load_golden("f0_coarse")
     p = _pipeline_cpu()
-    p.device, p._coarse_thr = "cpu", None
     thr = p._coarse_thresholds()
+    p.device, p._coarse_thr = "cpu", torch.from_numpy(thr)   # Pipeline.__init__ builds the table once, at construction
     assert thr.shape == (254,) and np.all(np.diff(thr) > 0)
     rng = np.random.default_rng(0)
     edge = np.concatenate([thr, np.nextafter(thr, -np.inf), np.nextafter(thr, np.inf)])

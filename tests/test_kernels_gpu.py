@@ -263,6 +263,62 @@ def test_bigru_matches_torch_gru(native, dev, batch, steps, multi_cu):
     assert (out - ref).abs().max().item() <= 2e-5
 
 
+def _gru_case(batch, steps, seed=5):
+    torch.manual_seed(seed)
+    gru = torch.nn.GRU(384, 256, num_layers=1, batch_first=True, bidirectional=True).eval()
+    x = torch.randn(batch, steps, 384)
+    with torch.no_grad():
+        ref = gru(x)[0]
+    sd = gru.state_dict()
+    wih = torch.cat([sd["weight_ih_l0"], sd["weight_ih_l0_reverse"]], 0)
+    bih = torch.cat([sd["bias_ih_l0"], sd["bias_ih_l0_reverse"]], 0)
+    gi = F.linear(x, wih, bih).view(batch, steps, 2, 768)
+    whh_t = torch.stack([sd["weight_hh_l0"].t(), sd["weight_hh_l0_reverse"].t()], 0).contiguous()
+    bhh = torch.stack([sd["bias_hh_l0"], sd["bias_hh_l0_reverse"]], 0).contiguous()
+    return gi, whh_t, bhh, ref
+
+
+def test_bigru_while_another_stream_saturates_the_cus(native, dev):
+    """The 8-workgroup exchange kernel launched while a second stream keeps every CU busy with conv tiles (what two
+    utterances in flight do, RMVPE.py:515-536 under VoiceConverter.convert_batch): late-starting workgroups must
+    either rendezvous in time or be recomputed by the single-workgroup kernel -- the result is the GRU's either way."""
+    gi, whh_t, bhh, ref = _gru_case(1, 3232)
+    gi, whh_t, bhh = gi.to(dev), whh_t.to(dev), bhh.to(dev)
+    C, L = 128, 383_760
+    x = torch.randn(1, C, L, device=dev)
+    y = torch.empty_like(x)
+    w = native.conv1d_pack_weight(torch.randn(C, C, 11) * 0.02, dev)
+    bias = torch.zeros(C, device=dev)
+    hog = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        with torch.cuda.stream(hog):
+            for _ in range(12):                       # ~13 ms of back-to-back 3000-tile launches
+                native.conv1d_forward_into(x, w, bias, C, 11, 1, 0.1, out=y)
+        out = native.bigru_forward(gi, whh_t, bhh, multi_cu=True)
+        redone = native.bigru_redone(1, dev)
+        torch.cuda.synchronize()
+        err = (out.cpu() - ref).abs().max().item()
+        print(f"bigru under load, rep {rep}: max err {err:.2e}, sequences recomputed: {redone}")
+        assert torch.isfinite(out).all() and err <= 2e-5
+
+
+def test_bigru_timeout_is_recomputed_not_poisoned(native, dev):
+    """Force every rendezvous wait to give up after one poll (rvc_bigru_set_spin_limit): the in-call single-workgroup
+    recompute must restore the exact result, for every batch item and direction, and report itself."""
+    gi, whh_t, bhh, ref = _gru_case(2, 333)
+    native.bigru_set_spin_limit(1)
+    try:
+        out = native.bigru_forward(gi.to(dev), whh_t.to(dev), bhh.to(dev), multi_cu=True)
+        redone = native.bigru_redone(2, dev)
+    finally:
+        native.bigru_set_spin_limit(0)
+    assert redone >= 1, "a 1-poll bound should have timed out somewhere"
+    assert (out.cpu() - ref).abs().max().item() <= 2e-5
+    out = native.bigru_forward(gi.to(dev), whh_t.to(dev), bhh.to(dev), multi_cu=True)
+    assert native.bigru_redone(2, dev) == 0 and (out.cpu() - ref).abs().max().item() <= 2e-5
+
+
 # ---- K7 attention ------------------------------------------------------------------------------------
 @pytest.mark.parametrize("batch,frames,heads,hd", [(1, 1, 12, 64), (1, 31, 2, 64), (2, 97, 12, 64), (1, 1599, 12, 64),
                                                    (1, 64, 3, 64), (1, 200, 2, 96), (2, 333, 2, 96)])

@@ -165,3 +165,18 @@ def test_whole_pipeline_v1_model():
                      big_npy=g["index"], index_rate=float(g["index_rate"]))
     assert out.shape == g["out"].shape
     assert rms(out - g["out"]) <= 2e-5
+
+
+def test_whole_pipeline_multi_segment():
+    """Three segments (pipeline.py:563-577 split points, :614-681 per-segment conversion + crop + concat) at the smaller
+    memory tier x_query/x_center/x_max = 1/3/4: fixture from make_golden.py::multiseg (the reference's own Pipeline)."""
+    g = load_golden("pipeline_multiseg")
+    cpt = S.make_synth_checkpoint(48000, "HiFi-GAN", seed=0)
+    taps = {}
+    torch.manual_seed(int(g["seed"]))
+    out = O.pipeline(S.make_hubert_state_dict(1), S.make_rmvpe_state_dict(0), cpt, g["audio"].copy(), sid=int(g["sid"]),
+                     big_npy=S.synth_index(4096, seed=0), index_rate=float(g["index_rate"]), protect=float(g["protect"]),
+                     x_query=int(g["x_query"]), x_center=int(g["x_center"]), x_max=int(g["x_max"]), taps=taps)
+    assert len(taps["opt_ts"]) == 2 and g["segs"].shape == (3, 2)
+    assert out.shape == g["out"].shape                       # segment lengths, crops: integer bookkeeping
+    assert rms(out - g["out"]) <= 2e-5, rms(out - g["out"])
