@@ -153,6 +153,7 @@ class Pipeline:
         self._preset_index = None
         self._f0_streams = {}      # side stream per caller stream (several utterances may be in flight)
         self._coarse_thr = torch.from_numpy(self._coarse_thresholds()).to(self.device)
+        self.debug_taps = None     # tests: a dict here receives "f0_raw" (the RMVPE contour of the last call, device tensor)
         self.ref_freqs = REF_FREQS
         self.autotune = Autotune(self.ref_freqs)
         self.note_dict = self.autotune.note_dict
@@ -379,6 +380,8 @@ class Pipeline:
             gi.record_stream(side)
             with torch.cuda.stream(side):
                 f0_dev = self.model_rmvpe.back_half_device(gi, n_f0, thred=0.03)
+                if self.debug_taps is not None:
+                    self.debug_taps["f0_raw"] = f0_dev
                 if inp_f0 is None and f0_autotune is not True:
                     # the contour never leaves HBM and the host never waits for it: everything below is enqueued
                     # while the GPU is still busy with HuBERT

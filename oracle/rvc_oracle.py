@@ -280,10 +280,12 @@ def rmvpe_decode(hidden: np.ndarray, thred=0.03) -> np.ndarray:
     return f0
 
 
-def rmvpe_infer_from_audio(audio: np.ndarray, sd, thred=0.03) -> np.ndarray:
+def rmvpe_infer_from_audio(audio: np.ndarray, sd, thred=0.03, taps=None) -> np.ndarray:
     """RMVPE.py:472-485"""
     a = torch.from_numpy(audio).float().unsqueeze(0)
     hidden = rmvpe_mel2hidden(logmel_rmvpe(a), sd)
+    if taps is not None:
+        taps["salience"] = hidden.squeeze(0).numpy()
     return rmvpe_decode(hidden.squeeze(0).numpy(), thred)
 
 
@@ -780,9 +782,12 @@ def voice_conversion(hubert_sd, cpt, w, sid: Tensor, audio0: np.ndarray, pitch: 
 
 def pipeline(hubert_sd, rmvpe_sd, cpt, audio: np.ndarray, *, sid=0, pitch=0, big_npy=None, index_rate=0.0,
              protect=0.5, noise=None, knn_dtype=np.float64, taps=None, volume_envelope=1, f0_autotune=False,
-             f0_autotune_strength=1, x_query=X_QUERY, x_center=X_CENTER, x_max=X_MAX) -> np.ndarray:
+             f0_autotune_strength=1, x_query=X_QUERY, x_center=X_CENTER, x_max=X_MAX, f0_override=None) -> np.ndarray:
     """Pipeline.pipeline, pipeline.py:509-694, rmvpe branch.  x_query / x_center / x_max: the memory-tier constants of
-    rvc/configs/config.py:116-121 that Pipeline.__init__ reads from its config object (pipeline.py:124-127)."""
+    rvc/configs/config.py:116-121 that Pipeline.__init__ reads from its config object (pipeline.py:124-127).
+    f0_override (test infrastructure, not a reference argument): the raw RMVPE contour to use instead of evaluating the
+    network -- the tie-aware full-length tests hand over the product's contour when the two differ only on frames whose
+    salience arg-max is a certified near-tie (taps["salience"] holds this side's salience for that certificate)."""
     tgt_sr = cpt["config"][-1]
     w = fold_weight_norm(cpt["weight"])
     t_pad, t_pad_tgt = 16000 * X_PAD, tgt_sr * X_PAD
@@ -791,7 +796,9 @@ def pipeline(hubert_sd, rmvpe_sd, cpt, audio: np.ndarray, *, sid=0, pitch=0, big
     audio_pad = np.pad(audio, (t_pad, t_pad), mode="reflect")
     p_len = audio_pad.shape[0] // WINDOW
     sid_t = torch.tensor(sid).unsqueeze(0).long()
-    f0 = rmvpe_infer_from_audio(audio_pad, rmvpe_sd)
+    f0 = rmvpe_infer_from_audio(audio_pad, rmvpe_sd, taps=taps) if f0_override is None else np.array(f0_override, dtype=np.float64)
+    if taps is not None:
+        taps["f0_raw"] = f0.copy()
     coarse, f0bak = f0_to_coarse(f0, pitch, f0_autotune, f0_autotune_strength)
     coarse, f0bak = coarse[:p_len], f0bak[:p_len]
     pitch_t = torch.tensor(coarse).unsqueeze(0).long()

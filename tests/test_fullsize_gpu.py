@@ -45,21 +45,67 @@ def _converter(S, sr, voc, hubert, config=None):
     return vc
 
 
-def _coarse_mismatch(vc, audio, oracle_coarse):
-    """End-to-end coarse-pitch integers of the product (GPU U-Net -> BiGRU -> decode -> threshold table) vs the oracle's."""
+SAL_TIE = 2.5e-4   # salience near-tie bound: ~4x the largest GPU-vs-CPU salience difference measured (6e-5, tools/diag_rmvpe.py)
+
+
+def _f0_tie_report(f0_p, f0_o, sal_o):
+    """Frames where the product's RMVPE contour differs from the oracle's by more than fp noise, each CERTIFIED as a
+    near-tie of the oracle's own salience arg-max (RMVPE.py:459-512 picks the arg-max bin, then averages +-4 bins): the
+    bin the product chose must be within SAL_TIE of the oracle's maximum.  The synthetic (random-weight) RMVPE has a flat,
+    noise-like salience -- median top-2 gap 2e-3, minimum ~1e-6 over 3200 frames -- so two fp32 evaluations of the same
+    network can legitimately pick different peaks on a frame.  Returns the differing frame indices (certified)."""
+    n = min(len(f0_p), len(f0_o))
+    f0_p, f0_o = f0_p[:n], f0_o[:n]
+    differ = np.nonzero(np.abs(f0_p - f0_o) > 1e-3 * np.maximum(f0_o, 1.0))[0]
+    for t in differ:
+        if f0_p[t] <= 0:      # voicing decision differs: max salience within SAL_TIE of the 0.03 threshold
+            assert abs(sal_o[t].max() - 0.03) <= SAL_TIE, (t, sal_o[t].max())
+            continue
+        cents = 1200 * np.log2(f0_p[t] / 10)
+        b = int(np.clip(round((cents - 1997.3794084376191) / 20), 0, 359))
+        near = sal_o[t, max(0, b - 4): b + 5].max()          # the product's peak, wherever inside its averaging window
+        assert sal_o[t].max() - near <= SAL_TIE, f"frame {t}: product f0 {f0_p[t]:.2f} vs oracle {f0_o[t]:.2f} is not a salience near-tie ({sal_o[t].max() - near:.2e})"
+    return differ
+
+
+def _run_pair(S, sds, vc, hubert, cpt, audio, big, rate, seed, **okw):
+    """Product and oracle on one input under one seed.  If their f0 contours differ (only on certified near-tie frames),
+    the oracle is re-run on the product's contour so that the waveform comparison tests everything downstream of that
+    decision at full length; the number of such frames is reported and bounded by the caller."""
     from oracle import rvc_oracle as O
-    a = np.pad(O.highpass(audio), (16000, 16000), mode="reflect")
-    f0 = vc.vc.model_rmvpe.infer_from_audio_device(torch.from_numpy(a).float().to(DEV), thred=0.03)
-    coarse, _ = vc.vc._postprocess_f0_device(f0, 0)
-    got = coarse[:len(oracle_coarse)].cpu().numpy()
-    return float((got != oracle_coarse).mean()), int(np.abs(got - oracle_coarse).max())
+    taps = {}
+    t0 = time.time()
+    torch.manual_seed(seed)
+    want = O.pipeline(sds[0], sds[1], cpt, audio.copy(), sid=0, pitch=0, big_npy=big, index_rate=rate, protect=0.5, taps=taps, **okw)
+    t_oracle = time.time() - t0
+    vc.vc.debug_taps = {}
+    got = vc.vc.pipeline(hubert, vc.net_g, 0, audio.copy(), 0, "rmvpe", "", rate, True, 3, 1, "v2", 0.5, 128, False, 1, None,
+                         noise_seed=seed)
+    f0_p = vc.vc.debug_taps["f0_raw"].cpu().numpy()
+    vc.vc.debug_taps = None
+    differ = _f0_tie_report(f0_p, taps["f0_raw"], taps["salience"])
+    plain_err = rms(got - want) if got.shape == want.shape else float("nan")
+    if len(differ):
+        torch.manual_seed(seed)
+        want = O.pipeline(sds[0], sds[1], cpt, audio.copy(), sid=0, pitch=0, big_npy=big, index_rate=rate, protect=0.5,
+                          f0_override=f0_p, **okw)
+    rel = np.abs(f0_p[:len(taps["f0_raw"])] - taps["f0_raw"]) / np.maximum(taps["f0_raw"], 1.0)
+    rel[differ] = 0
+    return got, want, dict(tie_frames=len(differ), n_frames=len(f0_p), plain_err=plain_err, t_oracle=t_oracle,
+                           f0_rel_max=float(rel.max()), opt_ts=taps.get("opt_ts"))
 
 
 @pytest.mark.parametrize("cfg", [2, 1])
 def test_baseline_config_full_length_vs_oracle(S, hubert, sds, cfg):
     """cfg 2 exactly as bench.py runs it (30 s, 48 k NSF, 100 000-row index, index_rate 0.75) and cfg 1 (10 s, 40 k,
-    index_rate 0): whole Pipeline.pipeline vs oracle.pipeline under one seed.  Reference: pipeline.py:509-694."""
-    from oracle import rvc_oracle as O
+    index_rate 0): whole Pipeline.pipeline vs oracle.pipeline under one seed.  Reference: pipeline.py:509-694.
+
+    The NSF source integrates f0 into phase (hifigan.py:172-177), so ONE frame whose salience arg-max falls on another
+    peak shifts the phase of everything after it (measured: a single flipped frame at second 23 of 30 -> 3e-2 RMS on the
+    last 7 s; identical contours -> 4e-7 over the whole clip, tools/diag_fullsize.py).  The comparison is therefore
+    tie-aware exactly like the neighbour ids: contours must be equal to 1e-3 relative except on frames certified as
+    salience near-ties (_f0_tie_report), and the waveform gate is applied with the oracle following the product on
+    those frames."""
     secs, sr, rows, rate = (30, 48000, 100_000, 0.75) if cfg == 2 else (10, 40000, 0, 0.0)
     cpt = S.make_synth_checkpoint(sr, "HiFi-GAN", seed=0)
     vc = _converter(S, sr, "HiFi-GAN", hubert)
@@ -67,23 +113,15 @@ def test_baseline_config_full_length_vs_oracle(S, hubert, sds, cfg):
     if rows:
         vc.vc.set_index(big)
     audio = S.synth_audio(16000 * secs, seed=0)
-    taps = {}
-    t0 = time.time()
-    torch.manual_seed(1234)
-    want = O.pipeline(sds[0], sds[1], cpt, audio.copy(), sid=0, pitch=0, big_npy=big, index_rate=rate, protect=0.5, taps=taps,
-                      knn_dtype=np.float32)
-    t_oracle = time.time() - t0
-    got = vc.vc.pipeline(hubert, vc.net_g, 0, audio.copy(), 0, "rmvpe", "", rate, True, 3, 1, "v2", 0.5, 128, False, 1, None,
-                         noise_seed=1234)
+    got, want, info = _run_pair(S, sds, vc, hubert, cpt, audio, big, rate, 1234, knn_dtype=np.float32)
     assert got.dtype == np.float32 and got.shape == want.shape == ((1_439_040,) if cfg == 2 else (399_200,))
     err = rms(got - want)
-    mism, worst = _coarse_mismatch(vc, audio, taps["coarse"])
-    print(f"cfg {cfg} full length: rms err {err:.3e} (oracle rms {rms(want):.3f}, oracle {t_oracle:.0f} s); coarse f0 bins: "
-          f"{100 * mism:.3f} % of {len(taps['coarse'])} frames differ (max |delta| {worst})")
+    print(f"cfg {cfg} full length: rms err {err:.3e} (oracle rms {rms(want):.3f}, oracle {info['t_oracle']:.0f} s); "
+          f"f0: {info['tie_frames']} of {info['n_frames']} frames are certified salience near-ties, the rest agree to "
+          f"{info['f0_rel_max']:.1e} relative; waveform error before following the product on those frames: {info['plain_err']:.3e}")
     assert err <= 1e-3, err
-    # coarse bins are bit-exact on identical salience (test_rmvpe_matches_reference_golden); end to end they inherit the
-    # U-Net's ~1e-3 salience difference through an argmax -> a frame can land in the neighbouring 20-cent peak
-    assert mism <= 0.01, mism
+    assert info["tie_frames"] <= 0.002 * info["n_frames"], info   # a handful per 30 s at most
+    assert info["f0_rel_max"] <= 1e-3
 
 
 def test_multi_segment_matches_reference_golden(S, hubert):
@@ -105,20 +143,18 @@ def test_multi_segment_matches_reference_golden(S, hubert):
 
 
 def test_45s_two_segments_vs_oracle(S, hubert, sds):
-    """> 41 s at the default tier: the host-filtfilt branch, two segments, waveform (not only lengths) vs the oracle."""
-    from oracle import rvc_oracle as O
+    """> 41 s at the default tier: the host-filtfilt branch, two segments, waveform (not only lengths) vs the oracle
+    (tie-aware in f0 like the full-length test above)."""
     cpt = S.make_synth_checkpoint(48000, "HiFi-GAN", seed=0)
     vc = _converter(S, 48000, "HiFi-GAN", hubert)
     audio = S.synth_audio(16000 * 45, seed=45)
-    taps = {}
-    torch.manual_seed(99)
-    want = O.pipeline(sds[0], sds[1], cpt, audio.copy(), sid=0, pitch=0, taps=taps)
-    got = vc.vc.pipeline(hubert, vc.net_g, 0, audio.copy(), 0, "rmvpe", "", 0.0, True, 3, 1, "v2", 0.5, 128, False, 1, None,
-                         noise_seed=99)
-    assert len(taps["opt_ts"]) == 1 and got.shape == want.shape == (int(load_golden("segmentation")["outlen_45"]),)
+    got, want, info = _run_pair(S, sds, vc, hubert, cpt, audio, None, 0.0, 99)
+    assert len(info["opt_ts"]) == 1 and got.shape == want.shape == (int(load_golden("segmentation")["outlen_45"]),)
     err = rms(got - want)
-    print(f"45 s, 2 segments: rms err {err:.3e} (oracle rms {rms(want):.3f})")
+    print(f"45 s, 2 segments: rms err {err:.3e} (oracle rms {rms(want):.3f}); f0 near-tie frames {info['tie_frames']} of "
+          f"{info['n_frames']}; before following the product on them: {info['plain_err']:.3e}")
     assert err <= 1e-3, err
+    assert info["tie_frames"] <= 0.002 * info["n_frames"], info
 
 
 @pytest.mark.parametrize("hint", [1, 2])
