@@ -20,40 +20,11 @@
 // d2 = ||x||^2 - 2 q.x + ||q||^2 is faiss' own BLAS formulation (IndexFlat, > 20 queries), clamped at 0.
 #include <stdlib.h>
 
-#include "common.h"
+#include <mutex>
+
+#include "knn_common.h"
 
 namespace rvc {
-
-constexpr int KNN_K = 8;
-constexpr int KNN_BQ = 128;    // queries per block
-constexpr int KNN_BN = 128;    // index rows per inner tile
-constexpr int KNN_KC = 32;     // floats of D per staged chunk
-constexpr int KNN_LDS_STRIDE = KNN_KC + 1;
-constexpr int KNN_SLOTS_PER_STRIPE = 4;  // 2 wave-rows x 2 lane-halves
-
-struct TopK {
-    float d[KNN_K];
-    int id[KNN_K];
-    __device__ __forceinline__ void init() {
-#pragma unroll
-        for (int i = 0; i < KNN_K; ++i) { d[i] = INFINITY; id[i] = -1; }
-    }
-    // keep ascending order; equal distances keep the earlier (lower id) entry first
-    __device__ __forceinline__ void insert(float v, int n) {
-        if (v < d[KNN_K - 1]) {
-#pragma unroll
-            for (int p = KNN_K - 1; p >= 1; --p) {
-                const bool shift = v < d[p - 1];
-                const bool here = v < d[p];
-                const float nd = shift ? d[p - 1] : (here ? v : d[p]);
-                const int ni = shift ? id[p - 1] : (here ? n : id[p]);
-                d[p] = nd;
-                id[p] = ni;
-            }
-            if (v < d[0]) { d[0] = v; id[0] = n; }
-        }
-    }
-};
 
 __global__ void __launch_bounds__(256)
 knn_norms_kernel(const float *__restrict__ x, int64_t n_rows, int dim, float *__restrict__ norms) {
@@ -482,49 +453,6 @@ knn_direct_kernel(const float *__restrict__ index, const float *__restrict__ nor
     }
 }
 
-__device__ __forceinline__ bool cand_less(float da, int ia, float db, int ib) {
-    return (da < db) || (da == db && (unsigned)ia < (unsigned)ib);
-}
-
-// one block (4 waves) per query: merge n_slots sorted lists of 8 into the final ascending top-8
-__device__ __forceinline__ void wave_top8(float (&d)[KNN_K], int (&id)[KNN_K], int lane, float *out_d, int *out_i) {
-    // 8 rounds of wave-wide arg-min over the lane heads (lists sorted ascending by (d, id))
-    for (int round = 0; round < KNN_K; ++round) {
-        float bd = d[0];
-        int bi = id[0];
-        int bl = lane;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float od = __shfl_xor(bd, o);
-            const int oi = __shfl_xor(bi, o);
-            const int ol = __shfl_xor(bl, o);
-            if (cand_less(od, oi, bd, bi) || (od == bd && oi == bi && ol < bl)) { bd = od; bi = oi; bl = ol; }
-        }
-        if (lane == 0) { out_d[round] = bd; out_i[round] = bi; }
-        if (lane == bl) {  // pop
-#pragma unroll
-            for (int p = 0; p < KNN_K - 1; ++p) { d[p] = d[p + 1]; id[p] = id[p + 1]; }
-            d[KNN_K - 1] = INFINITY;
-            id[KNN_K - 1] = 0x7fffffff;
-        }
-    }
-}
-
-__device__ __forceinline__ void list_insert(float (&d)[KNN_K], int (&id)[KNN_K], float v, int n) {
-    if (cand_less(v, n, d[KNN_K - 1], id[KNN_K - 1])) {
-#pragma unroll
-        for (int p = KNN_K - 1; p >= 1; --p) {
-            const bool shift = cand_less(v, n, d[p - 1], id[p - 1]);
-            const bool here = cand_less(v, n, d[p], id[p]);
-            const float nd = shift ? d[p - 1] : (here ? v : d[p]);
-            const int ni = shift ? id[p - 1] : (here ? n : id[p]);
-            d[p] = nd;
-            id[p] = ni;
-        }
-        if (cand_less(v, n, d[0], id[0])) { d[0] = v; id[0] = n; }
-    }
-}
-
 __global__ void __launch_bounds__(256)
 knn_merge_kernel(const float *__restrict__ part_d, const int *__restrict__ part_id, int n_slots,
                  const float *__restrict__ queries, int dim, float *__restrict__ out_d2,
@@ -585,11 +513,13 @@ knn_blend_kernel(const float *__restrict__ index, int dim, const float *__restri
         float w[KNN_K];
         float sum = 0.f;
         for (int i = 0; i < k; ++i) {
+            const int64_t id = ids[q * k + i];
             const float inv = 1.f / d2[q * k + i];  // no guard for d2 == 0, as in the reference
-            w[i] = inv * inv;
+            w[i] = id >= 0 ? inv * inv : 0.f;       // an index with fewer than k rows: the missing neighbours carry no weight
             sum += w[i];
+            id_s[i] = id >= 0 ? id : 0;
         }
-        for (int i = 0; i < k; ++i) { w_s[i] = w[i] / sum; id_s[i] = ids[q * k + i]; }
+        for (int i = 0; i < k; ++i) w_s[i] = w[i] / sum;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < dim; c += blockDim.x) {
@@ -638,33 +568,36 @@ static KnnPlan knn_plan(int64_t n_rows, int64_t n_queries, int dim = 768) {
     return p;
 }
 
+// knn_screen.hip
+bool knn_screen_applicable(int64_t n_rows, int64_t n_queries, int dim);
+size_t knn_screen_workspace_bytes(int64_t n_rows, int64_t n_queries, int dim);
+int knn_finalize_launch(const float *index, int64_t n_rows, int dim, const float *queries, int64_t n_queries, const int *cand_id,
+                        const int *cand_cnt, const float *cand_s, const void *aux_dev, int cap, float *out_d2, int64_t *out_ids,
+                        int *n_exact_scans, hipStream_t stream);
+int knn_screened_search(const float *index, const void *aux_dev, int64_t n_rows, int dim, const float *queries, int64_t n_queries,
+                        float *out_d2, int64_t *out_ids, void *workspace, hipStream_t stream);
+
 }  // namespace rvc
 
 using namespace rvc;
 
-extern "C" int rvc_knn_index_norms(const float *index_dev, int64_t n_rows, int dim, float *norms_dev,
-                                   void *stream) {
-    if (!index_dev || !norms_dev || n_rows <= 0 || dim <= 0 || dim % 4) return fail("rvc_knn_index_norms: bad argument");
-    hipLaunchKernelGGL(knn_norms_kernel, dim3((unsigned)ceil_div(n_rows, 4)), dim3(256), 0, (hipStream_t)stream,
-                       index_dev, n_rows, dim, norms_dev);
-    RVC_LAUNCH_CHECK();
+extern "C" int rvc_knn_workspace_bytes(int64_t n_rows, int64_t n_queries, int dim, int k, size_t *bytes) {
+    if (!bytes || k != KNN_K || n_rows <= 0 || n_queries <= 0 || dim <= 0) return fail("rvc_knn_workspace_bytes: bad argument (k must be 8)");
+    const size_t slots = (size_t)knn_plan(n_rows, n_queries, dim).n_slots();
+    size_t need = align_up((size_t)n_queries * slots * KNN_K * sizeof(float), 256) +
+                  align_up((size_t)n_queries * slots * KNN_K * sizeof(int), 256);
+    if (dim % 256 == 0 && dim <= 1024) {   // the fp16-screened regime may be chosen at search time (rvc_knn_set_mode)
+        const size_t screened = knn_screen_workspace_bytes(n_rows, n_queries, dim);
+        if (screened > need) need = screened;
+    }
+    *bytes = need;
     return 0;
 }
 
-extern "C" int rvc_knn_workspace_bytes(int64_t n_rows, int64_t n_queries, int k, size_t *bytes) {
-    if (!bytes || k != KNN_K || n_rows <= 0 || n_queries <= 0) return fail("rvc_knn_workspace_bytes: bad argument (k must be 8)");
-    // the ABI carries no dim here: size for the larger of the two plans (dim 256 packs more blocks per CU)
-    size_t slots = (size_t)knn_plan(n_rows, n_queries, 768).n_slots();
-    const size_t slots_v1 = (size_t)knn_plan(n_rows, n_queries, 256).n_slots();
-    if (slots_v1 > slots) slots = slots_v1;
-    *bytes = align_up((size_t)n_queries * slots * KNN_K * sizeof(float), 256) +
-             align_up((size_t)n_queries * slots * KNN_K * sizeof(int), 256);
-    return 0;
-}
-
-extern "C" int rvc_knn_search(const float *index_dev, const float *norms_dev, int64_t n_rows, int dim,
+extern "C" int rvc_knn_search(const float *index_dev, const void *aux_dev, int64_t n_rows, int dim,
                               const float *queries_dev, int64_t n_queries, int k, float *out_d2_dev,
                               int64_t *out_ids_dev, void *workspace_dev, size_t workspace_bytes, void *stream) {
+    const float *norms_dev = (const float *)aux_dev;   // the aux blob starts with ||x||^2 per row (rvc_knn_index_build)
     if (k != KNN_K) return fail("rvc_knn_search: k must be 8 (pipeline.py:499), got %d", k);
     if (dim <= 0 || dim % KNN_KC) return fail("rvc_knn_search: dim must be a multiple of %d, got %d", KNN_KC, dim);
     if (n_rows >= (int64_t)1 << 31) return fail("rvc_knn_search: more than 2^31 rows");
@@ -672,8 +605,11 @@ extern "C" int rvc_knn_search(const float *index_dev, const float *norms_dev, in
         return fail("rvc_knn_search: null pointer");
     if (n_queries == 0) return 0;
     size_t need = 0;
-    if (rvc_knn_workspace_bytes(n_rows, n_queries, k, &need)) return 1;
+    if (rvc_knn_workspace_bytes(n_rows, n_queries, dim, k, &need)) return 1;
     if (workspace_bytes < need) return fail("rvc_knn_search: workspace too small (%zu < %zu)", workspace_bytes, need);
+    if (knn_screen_applicable(n_rows, n_queries, dim))
+        return knn_screened_search(index_dev, aux_dev, n_rows, dim, queries_dev, n_queries, out_d2_dev, out_ids_dev, workspace_dev,
+                                   (hipStream_t)stream);
     const KnnPlan plan = knn_plan(n_rows, n_queries, dim);
     const int n_slots = plan.n_slots();
     float *part_d = (float *)workspace_dev;
@@ -682,11 +618,15 @@ extern "C" int rvc_knn_search(const float *index_dev, const float *norms_dev, in
     static const int pf = getenv("RVC_KNN_STREAM_PF") ? atoi(getenv("RVC_KNN_STREAM_PF")) : 3;
     if (plan.direct) {
         const size_t lds = knd_lds_bytes(dim);
+        static std::mutex lds_mutex;               // several host threads search concurrently (convert_batch)
         static size_t lds_set = 0;
-        if (lds > lds_set) {
-            hipError_t e = hipFuncSetAttribute((const void *)knn_direct_kernel<KND_WAVES, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return fail("rvc_knn_search: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-            lds_set = lds;
+        {
+            std::lock_guard<std::mutex> guard(lds_mutex);
+            if (lds > lds_set) {
+                hipError_t e = hipFuncSetAttribute((const void *)knn_direct_kernel<KND_WAVES, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return fail("rvc_knn_search: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+                lds_set = lds;
+            }
         }
         static const int waves_env = getenv("RVC_KNN_DIRECT_WAVES") ? atoi(getenv("RVC_KNN_DIRECT_WAVES")) : 0;
         if (waves_env == 84) {   // RVC_KNN_DIRECT_WAVES=84: 4 line groups in flight (+1.5 % on a 2 M-row index)
@@ -713,6 +653,11 @@ extern "C" int rvc_knn_search(const float *index_dev, const float *norms_dev, in
         hipLaunchKernelGGL(knn_partial_kernel, grid, dim3(256), 0, (hipStream_t)stream, index_dev, norms_dev, n_rows, dim,
                            queries_dev, n_queries, plan.stripe_rows, part_d, part_id, n_slots);
     RVC_LAUNCH_CHECK();
+    // the per-slot lists (best 8 of disjoint row subsets by the GEMM-form score) are candidates; the result is ranked by
+    // the exact direct-difference distance, the same final step as the screened regime (knn_screen.hip)
+    if (dim % 256 == 0 && dim <= 1024)
+        return knn_finalize_launch(index_dev, n_rows, dim, queries_dev, n_queries, part_id, nullptr, part_d, aux_dev, n_slots * KNN_K,
+                                   out_d2_dev, out_ids_dev, nullptr, (hipStream_t)stream);
     hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)n_queries), dim3(256), 0, (hipStream_t)stream, part_d, part_id,
                        n_slots, queries_dev, dim, out_d2_dev, out_ids_dev);
     RVC_LAUNCH_CHECK();

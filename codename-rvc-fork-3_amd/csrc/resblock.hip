@@ -12,6 +12,8 @@
 // columns, i.e. both GEMMs run N1 wide and the K - 1 overlapping columns are recomputed by the neighbour.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "conv.h"
 
 namespace rvc {
@@ -236,13 +238,13 @@ static int launch_fused(const float *x, const float *w1, const float *b1, const 
     using F = FusedCfg<KW, C, N1, WM>;
     constexpr int BN = N1 - (KW - 1);
     const size_t lds = (size_t)(2 * F::WSLAB + C * F::XW + C * F::TW) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)resblock_layer_kernel<KW, C, N1, WM>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail("resblock_layer: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-        attr_set = true;
-    }
+    static std::once_flag attr_once;      // per template instance; forwards run on several host threads
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [lds] {
+        attr_err = hipFuncSetAttribute((const void *)resblock_layer_kernel<KW, C, N1, WM>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    if (attr_err != hipSuccess) return fail("resblock_layer: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(attr_err));
     hipLaunchKernelGGL((resblock_layer_kernel<KW, C, N1, WM>), dim3((unsigned)ceil_div(L, BN), batch), dim3(256), lds, stream, x, w1,
                        b1, w2, b2, accin, y, L, dil, slope, out_scale);
     RVC_LAUNCH_CHECK();

@@ -47,8 +47,10 @@ class DecoderNoise(ctypes.Structure):
 SYMBOLS = {
     "rvc_abi_version": (c_int, []),
     "rvc_last_error": (c_char_p, []),
-    "rvc_knn_index_norms": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
-    "rvc_knn_workspace_bytes": (c_int, [c_int64, c_int64, c_int, POINTER(c_size_t)]),
+    "rvc_knn_index_aux_bytes": (c_int, [c_int64, c_int, POINTER(c_size_t)]),
+    "rvc_knn_index_build": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
+    "rvc_knn_set_mode": (c_int, [c_int]),
+    "rvc_knn_workspace_bytes": (c_int, [c_int64, c_int64, c_int, c_int, POINTER(c_size_t)]),
     "rvc_knn_search": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p,
                                c_void_p, c_size_t, c_void_p]),
     "rvc_knn_blend": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p,
@@ -94,8 +96,9 @@ for _name, (_res, _args) in SYMBOLS.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-if _lib.rvc_abi_version() != 1:
-    raise ImportError(f"librvc_amd.so ABI {_lib.rvc_abi_version()} != 1: rebuild it")
+ABI_VERSION = 2
+if _lib.rvc_abi_version() != ABI_VERSION:
+    raise ImportError(f"librvc_amd.so ABI {_lib.rvc_abi_version()} != {ABI_VERSION}: rebuild it")
 
 
 def _check(rc: int, what: str):
@@ -137,25 +140,38 @@ _ws = _Workspace()
 
 
 # ---- K1 ------------------------------------------------------------------------------------------
-def knn_index_norms(index: torch.Tensor) -> torch.Tensor:
+def knn_index_build(index: torch.Tensor) -> torch.Tensor:
+    """The per-index aux blob of rvc_knn_index_build (||x||^2, fp16 copy, screening statistics) as an opaque uint8 tensor."""
     index = _dev_f32(index, "index")
-    norms = torch.empty(index.shape[0], dtype=torch.float32, device=index.device)
-    _check(_lib.rvc_knn_index_norms(index.data_ptr(), index.shape[0], index.shape[1], norms.data_ptr(), _stream()),
-           "rvc_knn_index_norms")
-    return norms
+    need = c_size_t()
+    _check(_lib.rvc_knn_index_aux_bytes(index.shape[0], index.shape[1], ctypes.byref(need)), "rvc_knn_index_aux_bytes")
+    aux = torch.empty(need.value, dtype=torch.uint8, device=index.device)
+    _check(_lib.rvc_knn_index_build(index.data_ptr(), index.shape[0], index.shape[1], aux.data_ptr(), aux.numel(), _stream()),
+           "rvc_knn_index_build")
+    return aux
 
 
-def knn_search(index: torch.Tensor, norms: torch.Tensor, queries: torch.Tensor, k: int = 8):
-    index, norms, queries = _dev_f32(index, "index"), _dev_f32(norms, "norms"), _dev_f32(queries, "queries")
+knn_index_norms = knn_index_build   # round-1 name: the blob starts with the row norms
+
+
+def knn_set_mode(mode: int) -> None:
+    """0 auto, 1 exact fp32 regimes only, 2 fp16-screened whenever the shape allows (test hook; results do not change)."""
+    _check(_lib.rvc_knn_set_mode(int(mode)), "rvc_knn_set_mode")
+
+
+def knn_search(index: torch.Tensor, aux: torch.Tensor, queries: torch.Tensor, k: int = 8):
+    index, queries = _dev_f32(index, "index"), _dev_f32(queries, "queries")
+    if not aux.is_cuda or aux.dtype != torch.uint8:
+        raise NativeError("aux must be the uint8 HBM blob returned by knn_index_build")
     nq = queries.shape[0]
     d2 = torch.empty((nq, k), dtype=torch.float32, device=index.device)
     ids = torch.empty((nq, k), dtype=torch.int64, device=index.device)
     if nq == 0:
         return d2, ids
     need = c_size_t()
-    _check(_lib.rvc_knn_workspace_bytes(index.shape[0], nq, k, ctypes.byref(need)), "rvc_knn_workspace_bytes")
+    _check(_lib.rvc_knn_workspace_bytes(index.shape[0], nq, index.shape[1], k, ctypes.byref(need)), "rvc_knn_workspace_bytes")
     ws = _ws.get("knn", need.value, index.device)
-    _check(_lib.rvc_knn_search(index.data_ptr(), norms.data_ptr(), index.shape[0], index.shape[1], queries.data_ptr(),
+    _check(_lib.rvc_knn_search(index.data_ptr(), aux.data_ptr(), index.shape[0], index.shape[1], queries.data_ptr(),
                                nq, k, d2.data_ptr(), ids.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
            "rvc_knn_search")
     return d2, ids
@@ -173,18 +189,30 @@ def knn_blend(index: torch.Tensor, feats: torch.Tensor, d2: torch.Tensor, ids: t
 
 def knn_roofline_report(n_rows: int, n_queries: int, dim: int, seconds: float, peak_hbm_gbs: float,
                         peak_f32_tflops: float, peak_f16_tflops: float) -> dict:
-    """SURVEY §8d's kNN roofline for one rvc_knn_search of (n_queries x n_rows) that took `seconds`: HBM bytes per
-    query-tile pass x passes, and the MFMA rate the same time corresponds to."""
+    """SURVEY §8d's kNN roofline for one rvc_knn_search of (n_queries x n_rows) that took `seconds` (all launches of the
+    search: query conversion, sample pass, bound, main pass, exact re-scoring).  §8d prices a pass over the index at
+    n_rows * dim * 4 B (the fp32 rows the reference's algorithm reads) times ceil(Q / Qt) passes; the screened regime
+    (Qt = 256) streams an fp16 copy, so the bytes it really moves per pass are half of that -- both are stated."""
+    screened = n_queries > 64 and n_rows >= 16384 and dim % 256 == 0
     stream = n_queries <= 64
-    q_tile = 32 if stream else 128
+    q_tile = 256 if screened else (32 if stream else 128)
     passes = -(-n_queries // q_tile)
-    bytes_total = passes * n_rows * dim * 4.0
+    bytes_8d = passes * n_rows * dim * 4.0
+    bytes_moved = passes * n_rows * dim * (2.0 if screened else 4.0) + (8.0 * n_queries * dim * 4 if screened else 0.0)
     flops = 2.0 * n_queries * n_rows * dim
-    return {"kernel": ("knn_direct_kernel" if stream else "knn_partial_kernel") + " + knn_merge_kernel",
+    return {"kernel": ("knn_screen_kernel<false> (sample) + knn_select_kernel + knn_screen_kernel<true> (main, fp16 MFMA) + "
+                       "knn_finalize_kernel (exact fp32 re-scoring)" if screened else
+                       ("knn_direct_kernel" if stream else "knn_partial_kernel") + " + knn_finalize_kernel"),
+            "regime": "fp16-screened, exact re-scoring" if screened else ("fp32 streaming" if stream else "fp32 GEMM"),
             "shape": f"{n_queries} queries x {n_rows} rows x {dim}", "bound": "hbm", "query_tile": q_tile, "passes": passes,
-            "bytes_per_pass": n_rows * dim * 4, "achieved": round(bytes_total / seconds / 1e9, 1), "peak": peak_hbm_gbs,
-            "unit": "GB/s", "frac": round(bytes_total / seconds / 1e9 / peak_hbm_gbs, 4), "traffic": None,
-            "mfma_tflops": round(flops / seconds / 1e12, 2), "mfma_frac_fp32": round(flops / seconds / 1e12 / peak_f32_tflops, 4),
+            "bytes_per_pass_8d": n_rows * dim * 4, "achieved": round(bytes_8d / seconds / 1e9, 1), "peak": peak_hbm_gbs,
+            "unit": "GB/s", "frac": round(bytes_8d / seconds / 1e9 / peak_hbm_gbs, 4),
+            "bytes_moved_per_search": bytes_moved, "moved_gbs": round(bytes_moved / seconds / 1e9, 1),
+            "moved_frac": round(bytes_moved / seconds / 1e9 / peak_hbm_gbs, 4),
+            "traffic": None,
+            "mfma_tflops": round(flops / seconds / 1e12, 2),
+            "mfma_frac": round(flops / seconds / 1e12 / (peak_f16_tflops if screened else peak_f32_tflops), 4),
+            "mfma_peak_used": "fp16 dense 2500 TF" if screened else "fp32 157.3 TF",
             "avg_search_ms": round(seconds * 1e3, 4)}
 
 

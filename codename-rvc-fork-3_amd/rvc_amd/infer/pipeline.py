@@ -100,7 +100,7 @@ class FeatureIndex:
         if isinstance(big_npy, np.ndarray):
             big_npy = torch.from_numpy(np.ascontiguousarray(big_npy, dtype=np.float32))
         self.vectors = big_npy.to(device=device, dtype=torch.float32).contiguous()
-        self.norms = _native.knn_index_norms(self.vectors)
+        self.aux = _native.knn_index_build(self.vectors)   # ||x||^2, fp16 copy, screening statistics
         self.ntotal = int(self.vectors.shape[0])
         # built on the loading thread's stream; utterances on other streams (convert_batch) read it afterwards
         torch.cuda.current_stream(self.vectors.device).synchronize()
@@ -109,7 +109,7 @@ class FeatureIndex:
         return True
 
     def search_device(self, queries: torch.Tensor, k: int = 8):
-        return _native.knn_search(self.vectors, self.norms, queries, k)
+        return _native.knn_search(self.vectors, self.aux, queries, k)
 
     def search(self, npy: np.ndarray, k: int = 8):
         """faiss-style host API: (D2 [Q,k] float32 ascending, I [Q,k] int64)."""
@@ -153,7 +153,7 @@ class Pipeline:
         self._preset_index = None
         self._f0_streams = {}      # side stream per caller stream (several utterances may be in flight)
         self._coarse_thr = torch.from_numpy(self._coarse_thresholds()).to(self.device)
-        self.debug_taps = None     # tests: a dict here receives "f0_raw" (the RMVPE contour of the last call, device tensor)
+        self.debug_taps = None     # tests: a dict here receives "f0_raw" and "salience" of the last call (device tensors)
         self.ref_freqs = REF_FREQS
         self.autotune = Autotune(self.ref_freqs)
         self.note_dict = self.autotune.note_dict
@@ -379,7 +379,7 @@ class Pipeline:
             side.wait_stream(main)
             gi.record_stream(side)
             with torch.cuda.stream(side):
-                f0_dev = self.model_rmvpe.back_half_device(gi, n_f0, thred=0.03)
+                f0_dev = self.model_rmvpe.back_half_device(gi, n_f0, thred=0.03, taps=self.debug_taps)
                 if self.debug_taps is not None:
                     self.debug_taps["f0_raw"] = f0_dev
                 if inp_f0 is None and f0_autotune is not True:

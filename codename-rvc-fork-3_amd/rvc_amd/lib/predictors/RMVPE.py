@@ -168,8 +168,11 @@ class RMVPE0Predictor:
         return self.unet_features(mel), n_frames
 
     @torch.no_grad()
-    def back_half_device(self, gi: torch.Tensor, n_frames: int, thred=0.03) -> torch.Tensor:
-        return self.decode(self.gru_head(gi, n_frames)[0], thred)
+    def back_half_device(self, gi: torch.Tensor, n_frames: int, thred=0.03, taps=None) -> torch.Tensor:
+        hidden = self.gru_head(gi, n_frames)[0]
+        if taps is not None:      # tests: the salience behind the contour (device tensor [n_frames, 360])
+            taps["salience"] = hidden
+        return self.decode(hidden, thred)
 
     def infer_from_audio(self, audio, thred=0.03) -> np.ndarray:
         """Reference signature (RMVPE.py:472-485): NumPy audio in, NumPy float64 f0 out."""

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RVC_AMD_ABI_VERSION 1
+#define RVC_AMD_ABI_VERSION 2
 
 /* ---- library ------------------------------------------------------------------------------------ */
 
@@ -42,23 +42,37 @@ const char *rvc_last_error(void);
  * rvc/infer/pipeline.py:497-507 (`Pipeline._retrieve_speaker_embeddings`), where `index` is the faiss
  * index read at pipeline.py:555 and `big_npy = index.reconstruct_n(0, ntotal)` (pipeline.py:556).
  * Search is exact brute-force squared L2 over big_npy (faiss IndexFlat semantics: ascending distance,
- * ties -> lower id).
+ * ties -> lower id).  The returned distances are sum_k (q_k - x_k)^2 evaluated in fp32 in a fixed order (faiss' flat
+ * scanner form), identical whichever internal regime finds the candidates:
+ *   <= 64 queries            one streaming pass over the fp32 index (HBM-bound)
+ *   more, >= 16384 rows      fp16 matrix-core screening pass with a proven error bound -> candidate superset -> exact
+ *                            re-scoring (csrc/knn_screen.hip); a query whose candidate list overflows is answered by an
+ *                            exact scan inside the same call
+ *   otherwise                fp32 matrix-core GEMM with per-lane top-8 lists
  */
 
-/* ||x_n||^2 for every index row; run once when the index is loaded. norms_dev: [n_rows] */
-int rvc_knn_index_norms(const float *index_dev, int64_t n_rows, int dim, float *norms_dev, void *stream);
+/* Per-index derived data, built once when the index is loaded ("aux" blob, opaque, caller-owned device memory):
+ * ||x_n||^2, an fp16 copy of the rows, and the index-wide maxima the screening bound needs. */
+int rvc_knn_index_aux_bytes(int64_t n_rows, int dim, size_t *bytes);
+int rvc_knn_index_build(const float *index_dev, int64_t n_rows, int dim, void *aux_dev, size_t aux_bytes, void *stream);
 
-/* bytes of scratch rvc_knn_search needs for (n_rows, n_queries) */
-int rvc_knn_workspace_bytes(int64_t n_rows, int64_t n_queries, int k, size_t *bytes);
+/* bytes of scratch rvc_knn_search needs for (n_rows, n_queries, dim) */
+int rvc_knn_workspace_bytes(int64_t n_rows, int64_t n_queries, int dim, int k, size_t *bytes);
 
-/* out_d2_dev [n_queries,k] squared distances ascending; out_ids_dev [n_queries,k] int64 row ids. k must be 8, dim % 32 == 0. */
-int rvc_knn_search(const float *index_dev, const float *norms_dev, int64_t n_rows, int dim,
+/* out_d2_dev [n_queries,k] squared distances ascending; out_ids_dev [n_queries,k] int64 row ids (-1 where the index has
+ * fewer than k rows). k must be 8, dim % 32 == 0.  aux_dev: what rvc_knn_index_build filled for this index. */
+int rvc_knn_search(const float *index_dev, const void *aux_dev, int64_t n_rows, int dim,
                    const float *queries_dev, int64_t n_queries, int k,
                    float *out_d2_dev, int64_t *out_ids_dev,
                    void *workspace_dev, size_t workspace_bytes, void *stream);
 
+/* Test hook, process-wide: 0 = choose the regime by shape (default), 1 = never screen (fp32 GEMM / streaming only),
+ * 2 = screen whenever the shape allows it (>= 4096 rows, dim a multiple of 256).  Results do not depend on it. */
+int rvc_knn_set_mode(int mode);
+
 /* pipeline.py:500-506: w = (1/d2)^2, w /= sum(w); out = index_rate * sum_k w_k * index[id_k] + (1-index_rate) * feats.
- * feats_dev/out_dev: [n_queries, dim] (may alias). */
+ * feats_dev/out_dev: [n_queries, dim] (may alias).  Neighbours with id < 0 (index smaller than k) are left out of the
+ * sums; d2 == 0 is not guarded, as in the reference (an exact duplicate of a query gives inf/inf there too). */
 int rvc_knn_blend(const float *index_dev, int dim, const float *feats_dev, const float *d2_dev,
                   const int64_t *ids_dev, int64_t n_queries, int k, float index_rate,
                   float *out_dev, void *stream);

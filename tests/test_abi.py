@@ -26,14 +26,14 @@ def test_header_and_library_agree():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/rvc_amd.h but not exported"
     assert sorted(_native.SYMBOLS) == declared, "ctypes table and header drifted apart"
-    assert lib.rvc_abi_version() == 1
+    assert lib.rvc_abi_version() == _native.ABI_VERSION == 2
 
 
 def test_errors_are_reported_not_swallowed():
     from rvc_amd import _native
     lib = _native._lib
     need = ctypes.c_size_t()
-    assert lib.rvc_knn_workspace_bytes(100, 10, 5, ctypes.byref(need)) != 0  # k != 8
+    assert lib.rvc_knn_workspace_bytes(100, 10, 768, 5, ctypes.byref(need)) != 0  # k != 8
     assert b"k must be 8" in lib.rvc_last_error()
     cfg = _native.DecoderConfig()
     cfg.kind = 7
@@ -49,4 +49,4 @@ def test_no_cpu_fallback():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
     with pytest.raises(_native.NativeError):
-        _native.knn_index_norms(torch.zeros(4, 768))
+        _native.knn_index_build(torch.zeros(4, 768))

@@ -46,25 +46,28 @@ def _converter(S, sr, voc, hubert, config=None):
 
 
 SAL_TIE = 2.5e-4   # salience near-tie bound: ~4x the largest GPU-vs-CPU salience difference measured (6e-5, tools/diag_rmvpe.py)
+F0_NOISE = 2e-5    # relative f0 difference that identical arg-max bins produce (measured ~1e-6: the 9-bin weighted mean
+                   # moves with the salience's 1e-5-level differences)
 
 
-def _f0_tie_report(f0_p, f0_o, sal_o):
+def _f0_tie_report(f0_p, sal_p, f0_o, sal_o):
     """Frames where the product's RMVPE contour differs from the oracle's by more than fp noise, each CERTIFIED as a
-    near-tie of the oracle's own salience arg-max (RMVPE.py:459-512 picks the arg-max bin, then averages +-4 bins): the
-    bin the product chose must be within SAL_TIE of the oracle's maximum.  The synthetic (random-weight) RMVPE has a flat,
-    noise-like salience -- median top-2 gap 2e-3, minimum ~1e-6 over 3200 frames -- so two fp32 evaluations of the same
-    network can legitimately pick different peaks on a frame.  Returns the differing frame indices (certified)."""
+    near-tie of the salience arg-max (RMVPE.py:459-512 picks the arg-max bin, then averages +-4 bins around it): the bin
+    the product chose must be within SAL_TIE of the oracle's maximum IN THE ORACLE'S OWN salience, and the two saliences
+    must agree to SAL_TIE everywhere on that frame.  The synthetic (random-weight) RMVPE has a flat, noise-like
+    salience -- median top-2 gap 2e-3, minimum ~1e-6 over 3200 frames -- so two fp32 evaluations of the same network
+    legitimately pick different bins on a frame now and then.  Returns the differing frame indices (all certified)."""
     n = min(len(f0_p), len(f0_o))
-    f0_p, f0_o = f0_p[:n], f0_o[:n]
-    differ = np.nonzero(np.abs(f0_p - f0_o) > 1e-3 * np.maximum(f0_o, 1.0))[0]
+    f0_p, f0_o, sal_p, sal_o = f0_p[:n], f0_o[:n], sal_p[:n], sal_o[:n]
+    assert np.abs(sal_p - sal_o).max() <= SAL_TIE, np.abs(sal_p - sal_o).max()
+    differ = np.nonzero(np.abs(f0_p - f0_o) > F0_NOISE * np.maximum(f0_o, 1.0))[0]
     for t in differ:
-        if f0_p[t] <= 0:      # voicing decision differs: max salience within SAL_TIE of the 0.03 threshold
-            assert abs(sal_o[t].max() - 0.03) <= SAL_TIE, (t, sal_o[t].max())
+        bp, bo = int(sal_p[t].argmax()), int(sal_o[t].argmax())
+        if bp == bo:          # same bin, so the voicing decision differs: max salience within SAL_TIE of the 0.03 threshold
+            assert abs(sal_o[t].max() - 0.03) <= SAL_TIE, (t, f0_p[t], f0_o[t], sal_o[t].max())
             continue
-        cents = 1200 * np.log2(f0_p[t] / 10)
-        b = int(np.clip(round((cents - 1997.3794084376191) / 20), 0, 359))
-        near = sal_o[t, max(0, b - 4): b + 5].max()          # the product's peak, wherever inside its averaging window
-        assert sal_o[t].max() - near <= SAL_TIE, f"frame {t}: product f0 {f0_p[t]:.2f} vs oracle {f0_o[t]:.2f} is not a salience near-tie ({sal_o[t].max() - near:.2e})"
+        assert sal_o[t, bo] - sal_o[t, bp] <= SAL_TIE, \
+            f"frame {t}: product bin {bp} vs oracle bin {bo} is not a salience near-tie ({sal_o[t, bo] - sal_o[t, bp]:.2e})"
     return differ
 
 
@@ -82,8 +85,9 @@ def _run_pair(S, sds, vc, hubert, cpt, audio, big, rate, seed, **okw):
     got = vc.vc.pipeline(hubert, vc.net_g, 0, audio.copy(), 0, "rmvpe", "", rate, True, 3, 1, "v2", 0.5, 128, False, 1, None,
                          noise_seed=seed)
     f0_p = vc.vc.debug_taps["f0_raw"].cpu().numpy()
+    sal_p = vc.vc.debug_taps["salience"].cpu().numpy()
     vc.vc.debug_taps = None
-    differ = _f0_tie_report(f0_p, taps["f0_raw"], taps["salience"])
+    differ = _f0_tie_report(f0_p, sal_p, taps["f0_raw"], taps["salience"])
     plain_err = rms(got - want) if got.shape == want.shape else float("nan")
     if len(differ):
         torch.manual_seed(seed)
@@ -103,9 +107,9 @@ def test_baseline_config_full_length_vs_oracle(S, hubert, sds, cfg):
     The NSF source integrates f0 into phase (hifigan.py:172-177), so ONE frame whose salience arg-max falls on another
     peak shifts the phase of everything after it (measured: a single flipped frame at second 23 of 30 -> 3e-2 RMS on the
     last 7 s; identical contours -> 4e-7 over the whole clip, tools/diag_fullsize.py).  The comparison is therefore
-    tie-aware exactly like the neighbour ids: contours must be equal to 1e-3 relative except on frames certified as
-    salience near-ties (_f0_tie_report), and the waveform gate is applied with the oracle following the product on
-    those frames."""
+    tie-aware exactly like the neighbour ids: contours must be equal to fp noise (2e-5 relative) except on frames
+    certified as salience near-ties (_f0_tie_report), and the waveform gate is applied with the oracle following the
+    product on those frames."""
     secs, sr, rows, rate = (30, 48000, 100_000, 0.75) if cfg == 2 else (10, 40000, 0, 0.0)
     cpt = S.make_synth_checkpoint(sr, "HiFi-GAN", seed=0)
     vc = _converter(S, sr, "HiFi-GAN", hubert)
@@ -121,7 +125,6 @@ def test_baseline_config_full_length_vs_oracle(S, hubert, sds, cfg):
           f"{info['f0_rel_max']:.1e} relative; waveform error before following the product on those frames: {info['plain_err']:.3e}")
     assert err <= 1e-3, err
     assert info["tie_frames"] <= 0.002 * info["n_frames"], info   # a handful per 30 s at most
-    assert info["f0_rel_max"] <= 1e-3
 
 
 def test_multi_segment_matches_reference_golden(S, hubert):

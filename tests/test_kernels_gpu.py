@@ -59,8 +59,8 @@ def _knn_case(native, dev, n_rows, n_q, seed):
     rng = np.random.default_rng(seed + 100)
     q = (big[rng.integers(0, n_rows, n_q)] + rng.standard_normal((n_q, 768)).astype(np.float32) * 0.03).astype(np.float32)
     index = torch.from_numpy(big).to(dev)
-    norms = native.knn_index_norms(index)
-    assert torch.allclose(norms.cpu(), torch.from_numpy((big.astype(np.float64) ** 2).sum(1)).float(), rtol=1e-5)
+    norms = native.knn_index_build(index)      # aux blob: row norms first, then statistics and the fp16 copy
+    assert torch.allclose(norms[:4 * n_rows].view(torch.float32).cpu(), torch.from_numpy((big.astype(np.float64) ** 2).sum(1)).float(), rtol=1e-5)
     d2, ids = native.knn_search(index, norms, torch.from_numpy(q).to(dev))
     d2, ids = d2.cpu().numpy(), ids.cpu().numpy()
     d2_ref, ids_ref = O.knn_search(big, q, 8, np.float64)
@@ -134,6 +134,67 @@ def test_knn_golden_and_blend(native, dev):
     assert np.array_equal(ids.cpu().numpy(), g["ids"])
     blended = native.knn_blend(index, q, d2, ids, 0.75).cpu().numpy()
     assert np.abs(blended - g["blended"][0]).max() <= 1e-4
+
+
+def _both_regimes(native, index, q):
+    aux = native.knn_index_build(index)
+    out = []
+    for mode in (1, 2):       # 1: exact fp32 GEMM / streaming regimes, 2: fp16-screened regime
+        native.knn_set_mode(mode)
+        try:
+            d2, ids = native.knn_search(index, aux, q)
+            torch.cuda.synchronize()
+        finally:
+            native.knn_set_mode(0)
+        out.append((d2.cpu(), ids.cpu()))
+    return out
+
+
+@pytest.mark.parametrize("n_rows,n_q,dim", [(100_000, 1599, 768), (40_000, 599, 768), (20_000, 300, 256), (16_500, 65, 768),
+                                            (4_096, 149, 768), (70_001, 257, 768)])
+def test_knn_screened_regime_equals_exact_regime(native, dev, n_rows, n_q, dim):
+    """The fp16 matrix-core screening pass only proposes candidates; ids AND distances must be bit-identical to the exact
+    fp32 regime's (pipeline.py:497-499 semantics), at the BASELINE cfg-2 shape, a v1 (256-dim) index, ragged tile counts."""
+    from rvc_amd.lib import synthetic as S
+    rng = np.random.default_rng(n_rows + n_q)
+    big = S.synth_index(n_rows, dim=dim, seed=1)
+    q = (big[rng.integers(0, n_rows, n_q)] + rng.standard_normal((n_q, dim)).astype(np.float32) * 0.03).astype(np.float32)
+    q[::3] = rng.standard_normal((len(q[::3]), dim)).astype(np.float32)      # queries far from every cluster, too
+    index, qd = torch.from_numpy(big).to(dev), torch.from_numpy(q).to(dev)
+    (d_exact, i_exact), (d_scr, i_scr) = _both_regimes(native, index, qd)
+    assert torch.equal(i_exact, i_scr)
+    assert torch.equal(d_exact, d_scr)
+    # and both are the true neighbours: float64 direct-difference distances of the returned rows, ascending, and no other
+    # row of a 64-query sample is closer than the 8th
+    sel = rng.integers(0, n_q, 64)
+    x64, q64 = big.astype(np.float64), q[sel].astype(np.float64)
+    d_all = (q64 ** 2).sum(1)[:, None] - 2 * q64 @ x64.T + (x64 ** 2).sum(1)[None, :]
+    d8 = np.sort(d_all, axis=1)[:, 7]
+    got = np.take_along_axis(d_all, i_scr.numpy()[sel], axis=1)
+    assert np.all(got[:, 7] <= d8 * (1 + 1e-6) + 1e-6)
+    assert np.allclose(d_scr.numpy()[sel], got, rtol=1e-5, atol=1e-5)
+
+
+def test_knn_screened_regime_survives_hostile_data(native, dev):
+    """Data built to defeat the screening pass -- thousands of exact duplicates of the nearest row (every candidate list
+    overflows), magnitudes fp16 cannot hold, an all-zero index -- must still give the exact regime's answer (the
+    overflowing queries are answered by the in-launch exact scan)."""
+    g = torch.Generator().manual_seed(9)
+    n, dim = 20_000, 768
+    index = torch.randn(n, dim, generator=g) * 0.3
+    index[5000:9000] = index[17]                                   # 4000 copies: > capacity of a candidate list
+    q = index[torch.randint(0, n, (130,), generator=g)] + 0.01 * torch.randn(130, dim, generator=g)
+    q[0] = index[17]
+    (d_exact, i_exact), (d_scr, i_scr) = _both_regimes(native, index.to(dev), q.to(dev))
+    assert torch.equal(i_exact, i_scr) and torch.equal(d_exact, d_scr)
+    assert i_scr[0].tolist() == [17] + list(range(5000, 5007))     # ties -> lower id first
+    big = torch.randn(n, dim, generator=g) * 3e4                   # |x| up to ~1.2e5: beyond fp16
+    (d_exact, i_exact), (d_scr, i_scr) = _both_regimes(native, big.to(dev), (big[:100] * 1.001).to(dev))
+    assert torch.equal(i_exact, i_scr) and torch.equal(d_exact, d_scr) and (i_scr[:, 0] == torch.arange(100)).all()
+    zero = torch.zeros(n, dim)
+    (d_exact, i_exact), (d_scr, i_scr) = _both_regimes(native, zero.to(dev), q.to(dev))
+    assert torch.equal(i_exact, i_scr) and torch.equal(d_exact, d_scr)
+    assert (i_scr == torch.arange(8)[None, :]).all()
 
 
 # ---- K4 log-mel --------------------------------------------------------------------------------------

@@ -65,7 +65,7 @@ print(f"integrated f0 difference (cycles): final {drift[-1]:+.4f}, max |.| {np.a
 f0_t = torch.from_numpy(np.ascontiguousarray(taps["f0"])).to(DEV)
 full = O.rmvpe_infer_from_audio(a, rm_sd)
 f0_full = torch.from_numpy(full).to(DEV)
-vc.vc.model_rmvpe.back_half_device = lambda gi, n_frames, thred=0.03: f0_full
+vc.vc.model_rmvpe.back_half_device = lambda gi, n_frames, thred=0.03, taps=None: f0_full
 got2 = product()
 print(f"product with the oracle's f0 injected: rms err {rms(got2 - want):.3e}")
 per = [rms(got2[i:i + 48000] - want[i:i + 48000]) for i in range(0, len(want), 48000)]
