@@ -614,6 +614,18 @@ extern "C" int rvc_knn_index_build(const float *index_dev, int64_t n_rows, int d
     return 0;
 }
 
+extern "C" int rvc_knn_rank_candidates(const float *index_dev, const void *aux_dev, int64_t n_rows, int dim, const float *queries_dev,
+                                       int64_t n_queries, const int32_t *cand_ids_dev, int cap, int k, float *out_d2_dev,
+                                       int64_t *out_ids_dev, void *stream) {
+    if (k != KNN_K) return fail("rvc_knn_rank_candidates: k must be 8, got %d", k);
+    if (!index_dev || !aux_dev || !queries_dev || !cand_ids_dev || !out_d2_dev || !out_ids_dev) return fail("rvc_knn_rank_candidates: null pointer");
+    if (dim % 256 != 0 || dim > 1024) return fail("rvc_knn_rank_candidates: dim must be 256, 512, 768 or 1024, got %d", dim);
+    if (cap <= 0 || n_rows <= 0) return fail("rvc_knn_rank_candidates: bad shape");
+    if (n_queries == 0) return 0;
+    return knn_finalize_launch(index_dev, n_rows, dim, queries_dev, n_queries, cand_ids_dev, nullptr, nullptr, aux_dev, cap, out_d2_dev,
+                               out_ids_dev, nullptr, (hipStream_t)stream);
+}
+
 extern "C" int rvc_knn_set_mode(int mode) {
     if (mode < 0 || mode > 2) return fail("rvc_knn_set_mode: 0 (auto), 1 (exact fp32 GEMM) or 2 (fp16-screened), got %d", mode);
     g_knn_mode = mode;

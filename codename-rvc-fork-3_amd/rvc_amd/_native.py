@@ -50,6 +50,8 @@ SYMBOLS = {
     "rvc_knn_index_aux_bytes": (c_int, [c_int64, c_int, POINTER(c_size_t)]),
     "rvc_knn_index_build": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
     "rvc_knn_set_mode": (c_int, [c_int]),
+    "rvc_knn_rank_candidates": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p,
+                                        c_void_p, c_void_p]),
     "rvc_knn_workspace_bytes": (c_int, [c_int64, c_int64, c_int, c_int, POINTER(c_size_t)]),
     "rvc_knn_search": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p,
                                c_void_p, c_size_t, c_void_p]),
@@ -174,6 +176,21 @@ def knn_search(index: torch.Tensor, aux: torch.Tensor, queries: torch.Tensor, k:
     _check(_lib.rvc_knn_search(index.data_ptr(), aux.data_ptr(), index.shape[0], index.shape[1], queries.data_ptr(),
                                nq, k, d2.data_ptr(), ids.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
            "rvc_knn_search")
+    return d2, ids
+
+
+def knn_rank_candidates(index: torch.Tensor, aux: torch.Tensor, queries: torch.Tensor, cand: torch.Tensor, k: int = 8):
+    """Exact top-k among the candidate rows cand [Q, cap] (int32, negative = empty) of each query."""
+    index, queries = _dev_f32(index, "index"), _dev_f32(queries, "queries")
+    if not cand.is_cuda or cand.dtype != torch.int32 or cand.dim() != 2 or cand.shape[0] != queries.shape[0]:
+        raise NativeError("cand must be an int32 HBM tensor [n_queries, cap]")
+    cand = cand.contiguous()
+    nq = queries.shape[0]
+    d2 = torch.empty((nq, k), dtype=torch.float32, device=index.device)
+    ids = torch.empty((nq, k), dtype=torch.int64, device=index.device)
+    _check(_lib.rvc_knn_rank_candidates(index.data_ptr(), aux.data_ptr(), index.shape[0], index.shape[1], queries.data_ptr(), nq,
+                                        cand.data_ptr(), cand.shape[1], k, d2.data_ptr(), ids.data_ptr(), _stream()),
+           "rvc_knn_rank_candidates")
     return d2, ids
 
 

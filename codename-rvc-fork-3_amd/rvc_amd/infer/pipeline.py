@@ -93,15 +93,27 @@ def _reflect_pad(x: torch.Tensor, pad: int) -> torch.Tensor:
 class FeatureIndex:
     """Device-resident replacement of the faiss index + ``big_npy`` pair (pipeline.py:553-556).
 
-    Exact squared-L2 search over the reconstructed vectors; truthy as a plain object, as the caller's
-    ``if index:`` requires (pipeline.py:456-458)."""
+    ``search_mode``:
+      "exact"  (default) squared-L2 over every reconstructed vector -- what ``big_npy`` admits and what the parity tests pin;
+      "ivf"    the reference's own approximate search: an ``IVF{n},Flat`` index probed with ``nprobe`` lists
+               (extract_index.py:62-64): nearest centroids first, then only the members of those lists.  Needs the
+               inverted-file structure of a ``.index`` file (``ivf=``).
+    Truthy as a plain object, as the caller's ``if index:`` requires (pipeline.py:456-458)."""
 
-    def __init__(self, big_npy, device):
+    def __init__(self, big_npy, device, ivf=None, search_mode: str = "exact"):
         if isinstance(big_npy, np.ndarray):
             big_npy = torch.from_numpy(np.ascontiguousarray(big_npy, dtype=np.float32))
         self.vectors = big_npy.to(device=device, dtype=torch.float32).contiguous()
         self.aux = _native.knn_index_build(self.vectors)   # ||x||^2, fp16 copy, screening statistics
         self.ntotal = int(self.vectors.shape[0])
+        self.search_mode = search_mode
+        self.ivf = None
+        if ivf is not None:
+            cent = torch.from_numpy(ivf.centroids).to(self.vectors.device)
+            self.ivf = {"centroids": cent, "aux": _native.knn_index_build(cent), "nprobe": max(1, min(int(ivf.nprobe), 8)),
+                        "lists": torch.from_numpy(ivf.padded_lists()).to(self.vectors.device)}
+        elif search_mode == "ivf":
+            raise ValueError("search_mode='ivf' needs the inverted lists of a faiss .index file")
         # built on the loading thread's stream; utterances on other streams (convert_batch) read it afterwards
         torch.cuda.current_stream(self.vectors.device).synchronize()
 
@@ -109,6 +121,11 @@ class FeatureIndex:
         return True
 
     def search_device(self, queries: torch.Tensor, k: int = 8):
+        if self.search_mode == "ivf" and self.ivf is not None:
+            _, near = _native.knn_search(self.ivf["centroids"], self.ivf["aux"], queries, k)       # nearest centroids
+            probe = near[:, :self.ivf["nprobe"]].clamp_min(0)
+            cand = self.ivf["lists"][probe].reshape(queries.shape[0], -1)                          # members of those lists
+            return _native.knn_rank_candidates(self.vectors, self.aux, queries, cand, k)
         return _native.knn_search(self.vectors, self.aux, queries, k)
 
     def search(self, npy: np.ndarray, k: int = 8):
@@ -121,12 +138,14 @@ class FeatureIndex:
 
 
 def _load_index_file(path: str):
-    """``.npy`` holds big_npy directly; ``.index`` needs faiss (the reference's format, pipeline.py:555-556)."""
+    """-> (big_npy, inverted-file structure or None).  ``.npy`` holds big_npy directly; anything else is parsed as the
+    reference's faiss ``IVF{n},Flat`` file (pipeline.py:555-556) by rvc_amd.lib.faiss_index -- faiss itself is not needed.
+    A file that cannot be parsed raises; the caller reports it the way pipeline.py:557-559 does."""
     if path.endswith(".npy"):
-        return np.load(path)
-    import faiss  # noqa: F401  (optional; absent in this image)
-    index = faiss.read_index(path)
-    return index.reconstruct_n(0, index.ntotal)
+        return np.load(path), None
+    from rvc_amd.lib.faiss_index import read_index
+    ivf = read_index(path)
+    return ivf.reconstruct_n(0, ivf.ntotal), ivf
 
 
 class Pipeline:
@@ -153,6 +172,7 @@ class Pipeline:
         self._preset_index = None
         self._f0_streams = {}      # side stream per caller stream (several utterances may be in flight)
         self._coarse_thr = torch.from_numpy(self._coarse_thresholds()).to(self.device)
+        self.index_search = "exact"   # "ivf": search faiss .index files the reference's way (nprobe lists); see FeatureIndex
         self.debug_taps = None     # tests: a dict here receives "f0_raw" and "salience" of the last call (device tensors)
         self.ref_freqs = REF_FREQS
         self.autotune = Autotune(self.ref_freqs)
@@ -175,7 +195,9 @@ class Pipeline:
                 index = self._index_cache.get(key)
                 if index is None:
                     try:
-                        index = FeatureIndex(_load_index_file(file_index), self.device)
+                        big_npy, ivf = _load_index_file(file_index)
+                        index = FeatureIndex(big_npy, self.device, ivf=ivf,
+                                             search_mode=self.index_search if ivf is not None else "exact")
                     except Exception as error:  # pipeline.py:557-559: warn and continue without retrieval
                         print(f"An error occurred reading the FAISS index: {error}")
                         return None

@@ -66,6 +66,15 @@ int rvc_knn_search(const float *index_dev, const void *aux_dev, int64_t n_rows, 
                    float *out_d2_dev, int64_t *out_ids_dev,
                    void *workspace_dev, size_t workspace_bytes, void *stream);
 
+/* Exact ranking of caller-supplied candidates: for every query the best k of the rows listed in cand_ids_dev
+ * [n_queries][cap] (int32 row ids, negative = empty) by sum_k (q_k - x_k)^2, ties -> lower id; -1 / +inf where fewer than k
+ * candidates exist.  This is the last step of every rvc_knn_search regime, exported for the inverted-file mode: a faiss
+ * `IVF{n},Flat` index searched with nprobe lists (extract_index.py:62-64, pipeline.py:499) is "nearest nprobe centroids
+ * (rvc_knn_search over the centroids), then rank the members of those lists".  dim: 256, 512, 768 or 1024. */
+int rvc_knn_rank_candidates(const float *index_dev, const void *aux_dev, int64_t n_rows, int dim, const float *queries_dev,
+                            int64_t n_queries, const int32_t *cand_ids_dev, int cap, int k, float *out_d2_dev,
+                            int64_t *out_ids_dev, void *stream);
+
 /* Test hook, process-wide: 0 = choose the regime by shape (default), 1 = never screen (fp32 GEMM / streaming only),
  * 2 = screen whenever the shape allows it (>= 4096 rows, dim a multiple of 256).  Results do not depend on it. */
 int rvc_knn_set_mode(int mode);

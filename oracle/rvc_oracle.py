@@ -423,6 +423,26 @@ def knn_search(big_npy: np.ndarray, q: np.ndarray, k: int = 8, dtype=np.float64,
     return best_d.astype(np.float32), best_i
 
 
+def ivf_search(centroids: np.ndarray, list_ids, big_npy: np.ndarray, q: np.ndarray, k: int = 8, nprobe: int = 1):
+    """faiss IndexIVFFlat.search as the reference configures it (extract_index.py:62-64: "IVF{n},Flat", nprobe = 1;
+    call site pipeline.py:499): the nprobe nearest coarse centroids of each query, then exact squared L2 over the members
+    of those inverted lists only; fewer than k members -> id -1, distance +inf.  float64; ties -> lower id.
+    faiss itself is absent here: restated from its published algorithm, parity unpinned."""
+    q64, c64 = q.astype(np.float64), centroids.astype(np.float64)
+    dc = (q64 ** 2).sum(1)[:, None] - 2 * q64 @ c64.T + (c64 ** 2).sum(1)[None, :]
+    probe = np.argsort(dc, axis=1, kind="stable")[:, :nprobe]
+    d2 = np.full((q.shape[0], k), np.inf)
+    ids = np.full((q.shape[0], k), -1, dtype=np.int64)
+    for i in range(q.shape[0]):
+        members = np.concatenate([np.asarray(list_ids[j], dtype=np.int64) for j in probe[i]])
+        if members.size == 0:
+            continue
+        d = ((q64[i][None, :] - big_npy[members].astype(np.float64)) ** 2).sum(1)
+        order = np.lexsort((members, d))[:k]
+        d2[i, :order.size], ids[i, :order.size] = d[order], members[order]
+    return d2, ids
+
+
 def knn_blend(feats: np.ndarray, score: np.ndarray, ix: np.ndarray, big_npy: np.ndarray, index_rate: float):
     """pipeline.py:500-506 on host arrays: w = (1/d^2)^2 normalised; sum_k w*x[ix]; blend."""
     weight = np.square(1 / score)
