@@ -18,6 +18,8 @@ struct ConvParams {
     int64_t l_in = 0;                // row length of x1 (and of x2 unless l_in2 is set)
     int64_t l_in2 = 0;               // row length of x2 (0 = same as l_in)
     const float *w = nullptr;        // [KW][c1 + c2][m_total]
+    const uint16_t *w16 = nullptr;   // the same slab stored as bf16 (BASELINE cfg 4); used instead of w when set
+                                     // (regular mode, 3 / 7 / 11 taps: the ResBlock / MRF-layer convs)
     const float *bias = nullptr;     // [c_out] (+ b * bias_bstride)
     int64_t bias_bstride = 0;
     const float *res = nullptr;      // [batch][c_out][l_out], regular mode only
@@ -50,6 +52,14 @@ int launch_conv(const ConvParams &p, hipStream_t stream);
 bool resblock_layer_supported(int c, int k);
 int launch_resblock_layer(const float *x, const float *w1, const float *b1, const float *w2, const float *b2, const float *accin,
                           float *y, int batch, int c, int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream);
+
+// fp32 -> bf16, round to nearest even (what torch's .bfloat16() does); NaN stays NaN
+static inline uint16_t bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
 
 // host-side repacks (return freshly hipMalloc'ed device buffers)
 // regular conv weight [c_out][c_in][k] -> [k][c_in][c_out]

@@ -25,7 +25,9 @@ constexpr int CONV_MAX_DIL = 5;
 
 // CONV_CIC = input channels per staged chunk
 // UP: scatter-mode epilogue (polyphase ConvTranspose1d), see conv.h
-template <int KW, int MT, int NT, int WM, int WN, int CONV_CIC, bool UP>
+// WB16: the weight slab is read from HBM as bf16 (p.w16) and widened to fp32 on its way into LDS -- the arithmetic is the
+// fp32 one on bf16-valued weights, bit for bit what the fp32 path computes on the same (bf16-rounded) values
+template <int KW, int MT, int NT, int WM, int WN, int CONV_CIC, bool UP, bool WB16 = false>
 __global__ void __launch_bounds__(WM *WN * 64) __attribute__((amdgpu_waves_per_eu(MT == 1 ? 2 : 3, MT == 1 ? 2 : 3)))
 conv_mfma_kernel(const ConvParams p) {
     constexpr int BM = 32 * MT * WM;
@@ -57,6 +59,7 @@ conv_mfma_kernel(const ConvParams p) {
     const float *const px1 = p.x1 + (int64_t)b * p.x1_bstride;
     const float *const px2 = p.x2 ? p.x2 + (int64_t)b * p.x2_bstride : nullptr;
     const float *const pw = p.w;
+    const uint16_t *const pw16 = p.w16;
     const int c1 = p.c1;
     const int ctot = p.c1 + p.c2;
     const int m_total = p.m_total;
@@ -68,7 +71,9 @@ conv_mfma_kernel(const ConvParams p) {
     const int dil = p.dil;
 
     float xr[XN];
-    f32x4 wr[WN4];  // native vector, not HIP's float4 struct: struct copies become memcpys that keep the array in scratch
+    f32x4 wr[WB16 ? 1 : WN4];  // native vector, not HIP's float4 struct: struct copies become memcpys that keep the array in scratch
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 wr16[WB16 ? WN4 : 1];   // four bf16 weights per 8-byte load
 
     // Every global load below is unconditional (clamped address, value masked later): a load inside a divergent
     // branch makes the compiler wait for it (s_waitcnt vmcnt(0)) before the branch closes, which serialised the
@@ -110,7 +115,9 @@ conv_mfma_kernel(const ConvParams p) {
             const int c4 = idx4 - row * (BM / 4);
             const int tap = row / CONV_CIC;
             const int ci = row - tap * CONV_CIC;
-            wr[i] = *reinterpret_cast<const f32x4 *>(pw + ((int64_t)tap * ctot + ci0 + ci) * m_total + m0 + c4 * 4);
+            const int64_t woff = ((int64_t)tap * ctot + ci0 + ci) * m_total + m0 + c4 * 4;
+            if constexpr (WB16) wr16[i] = *reinterpret_cast<const u32x2 *>(pw16 + woff);
+            else wr[i] = *reinterpret_cast<const f32x4 *>(pw + woff);
         }
     };
     auto store_chunk = [&](int buf, int c) __attribute__((always_inline)) {
@@ -130,7 +137,15 @@ conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
         for (int i = 0; i < WN4; ++i) {
             const int idx4 = tid + i * NTH;
-            if (idx4 < W4TOT) *reinterpret_cast<f32x4 *>(&ws[buf * WTOT + idx4 * 4]) = wr[i];
+            if (idx4 < W4TOT) {
+                if constexpr (WB16) {
+                    const f32x4 wv = {__uint_as_float(wr16[i].x << 16), __uint_as_float(wr16[i].x & 0xffff0000u),
+                                      __uint_as_float(wr16[i].y << 16), __uint_as_float(wr16[i].y & 0xffff0000u)};
+                    *reinterpret_cast<f32x4 *>(&ws[buf * WTOT + idx4 * 4]) = wv;
+                } else {
+                    *reinterpret_cast<f32x4 *>(&ws[buf * WTOT + idx4 * 4]) = wr[i];
+                }
+            }
         }
     };
 
@@ -329,6 +344,13 @@ static int launch_cfg(const ConvParams &p, hipStream_t stream) {
         } else {
             return fail("conv: scatter mode is built for 2-tap (polyphase) kernels only, got %d taps", KW);
         }
+    } else if (p.w16) {
+        // bf16 weight slabs exist for the ResBlock / MRF-layer shapes only (3, 7, 11 taps at their usual chunk depth)
+        if constexpr ((KW == 3 && CIC == 8) || ((KW == 7 || KW == 11) && CIC == 4)) {
+            hipLaunchKernelGGL((conv_mfma_kernel<KW, MT, NT, WM, WN, CIC, false, true>), grid, dim3(64 * WM * WN), 0, stream, p);
+        } else {
+            return fail("conv: no bf16-weight kernel for %d taps at chunk depth %d", KW, CIC);
+        }
     } else {
         hipLaunchKernelGGL((conv_mfma_kernel<KW, MT, NT, WM, WN, CIC, false>), grid, dim3(64 * WM * WN), 0, stream, p);
     }
@@ -355,7 +377,7 @@ static int launch_kw(const ConvParams &p, hipStream_t stream) {
     // chunk depth: deep kernels (7, 11 taps) stage 4 channels per chunk (staging registers, 3 blocks/CU);
     // shallow ones amortise the barrier over more channels
     int cic = KW >= 7 ? 4 : 8;
-    if (cic_env) cic = cic_env;
+    if (cic_env && !p.w16) cic = cic_env;
     if ((p.c1 % cic) || (p.c2 % cic)) cic = 8;
     if (p.m_total % 128 == 0) {
         // few 128 x 128 tiles (the 38k-column first vocoder stage: 600 tiles over 768 block slots, 3 on some CUs and 2

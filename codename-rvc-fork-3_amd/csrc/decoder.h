@@ -28,8 +28,20 @@ struct DevBuf {
     }
 };
 
+struct DevBuf16 {
+    uint16_t *p = nullptr;
+    ~DevBuf16() { if (p) (void)hipFree(p); }
+    int upload(const std::vector<uint16_t> &h) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        hipError_t e = hipMalloc((void **)&p, h.size() * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipMemcpy(p, h.data(), h.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+        return e == hipSuccess ? 0 : fail("device upload of %zu bf16 values failed: %s", h.size(), hipGetErrorString(e));
+    }
+};
+
 struct ConvW {
     DevBuf w, b;
+    DevBuf16 w16;                 // set instead of w when the handle stores its ResBlock weights as bf16
     int c_in = 0, c_out = 0, k = 0;
 };
 
@@ -83,7 +95,7 @@ struct rvc_decoder {
 namespace rvc {
 const HostTensor *find(const rvc_decoder *d, const std::string &name);
 int need(const rvc_decoder *d, const std::string &name, const HostTensor **out, std::vector<int64_t> shape);
-int build_conv(const rvc_decoder *d, const std::string &prefix, int c_out, int c_in, int k, bool bias, ConvW *out);
+int build_conv(const rvc_decoder *d, const std::string &prefix, int c_out, int c_in, int k, bool bias, ConvW *out, bool as_bf16 = false);
 
 // small kernels shared by both schedules (launch wrappers defined in decoder.hip)
 int launch_unfold_src(const float *har, int batch, int64_t L, int64_t S, int64_t P, int k_valid, int k_rows, int64_t nq, float *V,

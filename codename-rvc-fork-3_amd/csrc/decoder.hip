@@ -366,7 +366,7 @@ int need(const rvc_decoder *d, const std::string &name, const HostTensor **out, 
     return 0;
 }
 
-int build_conv(const rvc_decoder *d, const std::string &prefix, int c_out, int c_in, int k, bool bias, ConvW *out) {
+int build_conv(const rvc_decoder *d, const std::string &prefix, int c_out, int c_in, int k, bool bias, ConvW *out, bool as_bf16) {
     const HostTensor *w, *b;
     if (need(d, prefix + ".weight", &w, {c_out, c_in, k})) return 1;
     std::vector<float> packed((size_t)c_out * c_in * k);
@@ -374,7 +374,13 @@ int build_conv(const rvc_decoder *d, const std::string &prefix, int c_out, int c
         for (int ci = 0; ci < c_in; ++ci)
             for (int t = 0; t < k; ++t)
                 packed[((size_t)t * c_in + ci) * c_out + co] = w->data[((size_t)co * c_in + ci) * k + t];
-    if (out->w.upload(packed)) return 1;
+    if (as_bf16) {   // HBM copy in bf16 (round to nearest even; exact when the caller hands over bf16-valued weights)
+        std::vector<uint16_t> half(packed.size());
+        for (size_t i = 0; i < packed.size(); ++i) half[i] = bf16_rne(packed[i]);
+        if (out->w16.upload(half)) return 1;
+    } else if (out->w.upload(packed)) {
+        return 1;
+    }
     if (bias) {
         if (need(d, prefix + ".bias", &b, {c_out})) return 1;
         if (out->b.upload(b->data)) return 1;
@@ -391,6 +397,9 @@ extern "C" int rvc_decoder_create(const rvc_decoder_config *cfg, rvc_decoder **o
     if (cfg->n_ups < 1 || cfg->n_ups > 8) return fail("rvc_decoder_create: n_ups out of range");
     if (cfg->n_res_kernels < 1 || cfg->n_res_kernels > 4 || cfg->n_res_dilations < 1 || cfg->n_res_dilations > 4)
         return fail("rvc_decoder_create: resblock configuration out of range");
+    if (cfg->weight_storage != 0 && cfg->weight_storage != 1) return fail("rvc_decoder_create: weight_storage must be 0 (fp32) or 1 (bf16)");
+    if (cfg->weight_storage == 1 && cfg->kind == RVC_DEC_REFINE)
+        return fail("rvc_decoder_create: bf16 weight storage is built for the NSF / MRF decoders (BASELINE cfg 4), not RefineGAN");
     if (cfg->in_channels % 8 || cfg->upsample_initial_channel % (32 << cfg->n_ups))
         return fail("rvc_decoder_create: channel counts must keep every stage a multiple of 32");
     rvc_decoder *d = new rvc_decoder();
@@ -518,8 +527,9 @@ extern "C" int rvc_decoder_finalize(rvc_decoder *d) {
                     p2 = base + ".convs2." + std::to_string(j);
                 }
                 const int k = c.res_kernel_sizes[m];
-                if (build_conv(d, p1, s.c_out, s.c_out, k, true, &s.c1[m * c.n_res_dilations + j])) return 1;
-                if (build_conv(d, p2, s.c_out, s.c_out, k, true, &s.c2[m * c.n_res_dilations + j])) return 1;
+                const bool b16 = c.weight_storage == 1 && (k == 3 || k == 7 || k == 11);
+                if (build_conv(d, p1, s.c_out, s.c_out, k, true, &s.c1[m * c.n_res_dilations + j], b16)) return 1;
+                if (build_conv(d, p2, s.c_out, s.c_out, k, true, &s.c2[m * c.n_res_dilations + j], b16)) return 1;
             }
     }
     // conv_post: [1][c_last][7]
@@ -698,7 +708,7 @@ extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const flo
         for (int m = 0; m < nk; ++m) {
             const int k = c.res_kernel_sizes[m];
             const float *xin = X;
-            if (resblock_layer_supported(s.c_out, k)) {
+            if (resblock_layer_supported(s.c_out, k) && !s.c1[m * nd].w16.p) {
                 // narrow stages: one fused launch per layer; no in-place update (blocks read neighbours' columns),
                 // so the layer outputs ping-pong between Y and T1
                 for (int j = 0; j < nd; ++j) {
@@ -718,13 +728,13 @@ extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const flo
                 const int dil = c.res_dilations[j];
                 ConvParams p;
                 p.x1 = xin; p.c1 = s.c_out; p.slope1 = 0.1f; p.x1_bstride = bs; p.l_in = len;
-                p.w = s.c1[m * nd + j].w.p; p.bias = s.c1[m * nd + j].b.p;
+                p.w = s.c1[m * nd + j].w.p; p.w16 = s.c1[m * nd + j].w16.p; p.bias = s.c1[m * nd + j].b.p;
                 p.y = T1; p.y_bstride = bs; p.m_total = s.c_out; p.c_out = s.c_out; p.n_cols = len; p.l_out = len;
                 p.kw = k; p.dil = dil; p.padl = (k - 1) / 2 * dil; p.batch = batch;
                 if (launch_conv(p, stream)) return 1;
                 ConvParams q;
                 q.x1 = T1; q.c1 = s.c_out; q.slope1 = 0.1f; q.x1_bstride = bs; q.l_in = len;
-                q.w = s.c2[m * nd + j].w.p; q.bias = s.c2[m * nd + j].b.p;
+                q.w = s.c2[m * nd + j].w.p; q.w16 = s.c2[m * nd + j].w16.p; q.bias = s.c2[m * nd + j].b.p;
                 q.res = xin;
                 q.y_bstride = bs; q.m_total = s.c_out; q.c_out = s.c_out; q.n_cols = len; q.l_out = len;
                 q.kw = k; q.dil = 1; q.padl = (k - 1) / 2; q.batch = batch;

@@ -35,7 +35,7 @@ class DecoderConfig(ctypes.Structure):
         ("kind", c_int), ("sample_rate", c_int), ("in_channels", c_int), ("upsample_initial_channel", c_int),
         ("gin_channels", c_int), ("n_ups", c_int), ("upsample_rates", c_int * 8), ("upsample_kernel_sizes", c_int * 8),
         ("n_res_kernels", c_int), ("res_kernel_sizes", c_int * 4), ("res_dilations", c_int * 4),
-        ("n_res_dilations", c_int),
+        ("n_res_dilations", c_int), ("weight_storage", c_int),
     ]
 
 
@@ -448,7 +448,7 @@ class Decoder:
 
     def __init__(self, vocoder: str, sr: int, folded_weights: dict, *, in_channels=192, upsample_initial_channel=512,
                  gin_channels=256, upsample_rates=(12, 10, 2, 2), upsample_kernel_sizes=(24, 20, 4, 4),
-                 res_kernel_sizes=(3, 7, 11), res_dilations=(1, 3, 5)):
+                 res_kernel_sizes=(3, 7, 11), res_dilations=(1, 3, 5), weight_storage: str = "f32"):
         if not torch.cuda.is_available():
             raise NativeError("rvc_amd.Decoder needs a HIP device (no CPU fallback)")
         cfg = DecoderConfig()
@@ -464,6 +464,7 @@ class Decoder:
         cfg.n_res_kernels = len(res_kernel_sizes)
         for i, k in enumerate(res_kernel_sizes):
             cfg.res_kernel_sizes[i] = int(k)
+        cfg.weight_storage = {"f32": 0, "bf16": 1}[weight_storage]
         cfg.n_res_dilations = len(res_dilations)
         for i, d in enumerate(res_dilations):
             cfg.res_dilations[i] = int(d)

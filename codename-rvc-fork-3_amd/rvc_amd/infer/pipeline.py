@@ -109,9 +109,9 @@ class FeatureIndex:
         self.search_mode = search_mode
         self.ivf = None
         if ivf is not None:
-            cent = torch.from_numpy(ivf.centroids).to(self.vectors.device)
+            cent = torch.from_numpy(np.array(ivf.centroids, dtype=np.float32)).to(self.vectors.device)
             self.ivf = {"centroids": cent, "aux": _native.knn_index_build(cent), "nprobe": max(1, min(int(ivf.nprobe), 8)),
-                        "lists": torch.from_numpy(ivf.padded_lists()).to(self.vectors.device)}
+                        "lists": torch.from_numpy(np.array(ivf.padded_lists())).to(self.vectors.device)}
         elif search_mode == "ivf":
             raise ValueError("search_mode='ivf' needs the inverted lists of a faiss .index file")
         # built on the loading thread's stream; utterances on other streams (convert_batch) read it afterwards

@@ -80,7 +80,7 @@ class Synthesizer:
                                            gin_channels=self.gin_channels, upsample_rates=self.upsample_rates,
                                            upsample_kernel_sizes=self.upsample_kernel_sizes,
                                            res_kernel_sizes=self.resblock_kernel_sizes,
-                                           res_dilations=self.resblock_dilations)
+                                           res_dilations=self.resblock_dilations, weight_storage=self.dec_weight_dtype)
 
     def to(self, device):
         device = torch.device(device)

@@ -190,6 +190,9 @@ typedef struct rvc_decoder_config {
     int res_kernel_sizes[4];  /* 3,7,11 */
     int res_dilations[4];     /* 1,3,5 (same for every kernel size) */
     int n_res_dilations;      /* 3 */
+    int weight_storage;       /* 0: fp32.  1: the ResBlock / MRF-layer conv weights (98 % of the vocoder's weight bytes) are kept
+                                 in HBM as bf16 and widened to fp32 inside the conv kernel (BASELINE cfg 4: "bf16 weights ...
+                                 alt ResBlock kernel path"); the arithmetic stays fp32.  NSF / MRF only. */
 } rvc_decoder_config;
 
 int rvc_decoder_create(const rvc_decoder_config *cfg, rvc_decoder **out);

@@ -802,7 +802,8 @@ def voice_conversion(hubert_sd, cpt, w, sid: Tensor, audio0: np.ndarray, pitch: 
 
 def pipeline(hubert_sd, rmvpe_sd, cpt, audio: np.ndarray, *, sid=0, pitch=0, big_npy=None, index_rate=0.0,
              protect=0.5, noise=None, knn_dtype=np.float64, taps=None, volume_envelope=1, f0_autotune=False,
-             f0_autotune_strength=1, x_query=X_QUERY, x_center=X_CENTER, x_max=X_MAX, f0_override=None) -> np.ndarray:
+             f0_autotune_strength=1, x_query=X_QUERY, x_center=X_CENTER, x_max=X_MAX, f0_override=None,
+             dec_bf16=False) -> np.ndarray:
     """Pipeline.pipeline, pipeline.py:509-694, rmvpe branch.  x_query / x_center / x_max: the memory-tier constants of
     rvc/configs/config.py:116-121 that Pipeline.__init__ reads from its config object (pipeline.py:124-127).
     f0_override (test infrastructure, not a reference argument): the raw RMVPE contour to use instead of evaluating the
@@ -810,6 +811,8 @@ def pipeline(hubert_sd, rmvpe_sd, cpt, audio: np.ndarray, *, sid=0, pitch=0, big
     salience arg-max is a certified near-tie (taps["salience"] holds this side's salience for that certificate)."""
     tgt_sr = cpt["config"][-1]
     w = fold_weight_norm(cpt["weight"])
+    if dec_bf16:   # BASELINE cfg 4: fp32 math on the vocoder weights a bf16 copy holds (SURVEY §8d)
+        w = {k: (v.float().bfloat16().float() if k.startswith("dec.") else v) for k, v in w.items()}
     t_pad, t_pad_tgt = 16000 * X_PAD, tgt_sr * X_PAD
     audio = highpass(audio)
     opt_ts = split_points(audio, x_query, x_center, x_max)

@@ -451,25 +451,39 @@ def test_filtfilt_matches_scipy(native, dev, n):
 
 
 # ---- BASELINE cfg 4 / cfg 5 shapes ---------------------------------------------------------------------
-def test_cfg4_mrf_bf16_rounded_weights(native, dev, ref_inputs):
-    """cfg 4: MRF vocoder with bf16-stored weights.  Oracle = fp32 math on the SAME bf16-rounded tensors."""
+@pytest.mark.parametrize("voc", ["MRF HiFi-GAN", "HiFi-GAN"])
+def test_cfg4_bf16_weight_storage(native, dev, ref_inputs, voc):
+    """cfg 4: vocoder with bf16 weights.  The folded weights are rounded to bf16 (what a bf16 copy holds); the handle keeps
+    the ResBlock / MRF-layer conv weights as bf16 in HBM (weight_storage="bf16": conv_mfma_kernel<..., WB16>) and must
+    reproduce, to fp32 accumulation noise, (a) the oracle's fp32 math on the SAME bf16-valued weights and
+    (b) the fp32-storage handle fed with the same values -- bit for bit, since widening bf16 -> fp32 is exact."""
     from oracle import rvc_oracle as O
     from rvc_amd.lib import synthetic as S
-    from rvc_amd.lib.algorithm.weights import fold_weight_norm
     T = 48
-    cpt = S.make_synth_checkpoint(48000, "MRF HiFi-GAN", seed=0)
-    cpt["weight"] = {k: (v.to(torch.bfloat16).float() if v.is_floating_point() else v) for k, v in cpt["weight"].items()}
-    w = O.fold_weight_norm(cpt["weight"])
+    cpt = S.make_synth_checkpoint(48000, voc, seed=0)
+    w = {k: (v.float().bfloat16().float() if k.startswith("dec.") else v) for k, v in O.fold_weight_norm(cpt["weight"]).items()}
     rates, ksizes = cpt["config"][12], cpt["config"][14]
     gen = torch.Generator().manual_seed(3)
     z, g = torch.randn(1, 192, T, generator=gen), torch.randn(1, 256, 1, generator=gen)
     f0 = _decoder_inputs(ref_inputs, T)
-    src_rand, src_randn = torch.rand(1, 9, generator=gen), torch.randn(1, T * 480, 9, generator=gen)
-    ref = O.decoder_mrf(w, z, f0, g, rates, ksizes, 48000, O.ListNoise([src_rand.clone(), src_randn])).numpy()
-    folded = {k[4:]: v for k, v in fold_weight_norm(cpt["weight"]).items() if k.startswith("dec.")}
-    dec = native.Decoder("MRF HiFi-GAN", 48000, folded)
-    out = dec.forward(z.to(dev), f0.to(dev), g[:, :, 0].to(dev), src_randn=src_randn.to(dev), src_rand=src_rand.to(dev)).cpu().numpy()
-    assert rms(out - ref) <= 5e-5, rms(out - ref)
+    mrf = voc.startswith("MRF")
+    dim = 9 if mrf else 1
+    src_rand, src_randn = torch.rand(1, dim, generator=gen), torch.randn(1, T * 480, dim, generator=gen)
+    if mrf:
+        ref = O.decoder_mrf(w, z, f0, g, rates, ksizes, 48000, O.ListNoise([src_rand.clone(), src_randn])).numpy()
+    else:
+        ref = O.decoder_nsf(w, z, f0, g, rates, ksizes, 48000, O.ListNoise([torch.zeros(1, 1, 1), src_randn])).numpy()
+    folded = {k[4:]: v for k, v in w.items() if k.startswith("dec.")}
+    outs = {}
+    for storage in ("bf16", "f32"):
+        dec = native.Decoder(voc, 48000, folded, weight_storage=storage)
+        outs[storage] = dec.forward(z.to(dev), f0.to(dev), g[:, :, 0].to(dev), src_randn=src_randn.to(dev),
+                                    src_rand=src_rand.to(dev)).cpu().numpy()
+    assert rms(outs["bf16"] - ref) <= 5e-5, rms(outs["bf16"] - ref)
+    # same values, same fp32 arithmetic; the C = 32 stage takes the unfused conv pair instead of the fused layer kernel
+    assert rms(outs["bf16"] - outs["f32"]) <= 2e-6, rms(outs["bf16"] - outs["f32"])
+    with pytest.raises(native.NativeError):
+        native.Decoder("RefineGAN", 48000, {}, weight_storage="bf16")
 
 
 def test_cfg5_two_million_row_index(native, dev):
