@@ -71,3 +71,41 @@ extern "C" int rvc_bias_relu_add_f32(const float *x_dev, const float *bias_dev, 
     RVC_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- polyphase FIR resampler (load_audio / load_audio_infer: rvc/lib/utils.py:21-50, 53-85 resample to 16 kHz) ----------
+// y[j] = sum_m h[m] * xup[j * down + centre - m], xup = x with (up - 1) zeros between samples (scipy.signal.upfirdn /
+// resample_poly convention, centre = (n_taps - 1) / 2).  Only every up-th tap meets a non-zero sample: ~n_taps / up
+// multiply-adds per output, in float64 (the filter is designed for > 140 dB of stop-band attenuation, fp32 accumulation
+// would sit above its noise floor).  One thread per output sample; x and h are re-read from L2.
+namespace rvc {
+__global__ void __launch_bounds__(256)
+resample_poly_kernel(const double *__restrict__ x, int64_t n_in, int up, int down, const double *__restrict__ h, int64_t n_taps,
+                     double *__restrict__ y, int64_t n_out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_out) return;
+    const int64_t centre = (n_taps - 1) / 2;
+    const int64_t t = j * down + centre;         // position on the up-sampled grid
+    // taps m with (t - m) % up == 0 and 0 <= (t - m) / up < n_in
+    int64_t m = t % up;                           // smallest m >= 0 with (t - m) divisible by up
+    int64_t i = (t - m) / up;                     // input sample that tap m meets
+    if (i >= n_in) {
+        const int64_t skip = i - (n_in - 1);
+        m += skip * up;
+        i = n_in - 1;
+    }
+    double acc = 0.0;
+    for (; m < n_taps && i >= 0; m += up, --i) acc = fma(h[m], x[i], acc);
+    y[j] = acc;
+}
+}  // namespace rvc
+
+extern "C" int rvc_resample_poly_f64(const double *x_dev, int64_t n_in, int up, int down, const double *h_dev, int64_t n_taps,
+                                     double *y_dev, int64_t n_out, void *stream) {
+    if (!x_dev || !h_dev || !y_dev) return rvc::fail("rvc_resample_poly_f64: null pointer");
+    if (n_in <= 0 || up <= 0 || down <= 0 || n_taps <= 0 || n_out < 0) return rvc::fail("rvc_resample_poly_f64: bad argument");
+    if (n_out == 0) return 0;
+    hipLaunchKernelGGL(rvc::resample_poly_kernel, dim3((unsigned)rvc::ceil_div(n_out, 256)), dim3(256), 0, (hipStream_t)stream, x_dev,
+                       n_in, up, down, h_dev, n_taps, y_dev, n_out);
+    RVC_LAUNCH_CHECK();
+    return 0;
+}

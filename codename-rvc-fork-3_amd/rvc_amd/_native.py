@@ -59,6 +59,12 @@ SYMBOLS = {
                               c_void_p]),
     "rvc_logmel_workspace_bytes": (c_int, [c_int, c_int64, POINTER(c_size_t)]),
     "rvc_logmel_rmvpe": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+    "rvc_mel_create": (c_int, [c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_int, POINTER(c_void_p)]),
+    "rvc_mel_destroy": (c_int, [c_void_p]),
+    "rvc_mel_frames": (c_int, [c_void_p, c_int64, POINTER(c_int64)]),
+    "rvc_mel_workspace_bytes": (c_int, [c_void_p, c_int, c_int64, POINTER(c_size_t)]),
+    "rvc_mel_forward": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rvc_resample_poly_f64": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "rvc_filtfilt_workspace_bytes": (c_int, [c_int64, POINTER(c_size_t)]),
     "rvc_filtfilt_order5": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rvc_bigru_workspace_bytes": (c_int, [c_int, POINTER(c_size_t)]),
@@ -247,6 +253,57 @@ def logmel_rmvpe(audio: torch.Tensor, pad_to: int = 32) -> tuple[torch.Tensor, i
     _check(_lib.rvc_logmel_rmvpe(audio.data_ptr(), b, n, mel.data_ptr(), t_pad, ws.data_ptr(), ws.numel(), _stream()),
            "rvc_logmel_rmvpe")
     return mel, t
+
+
+class MelTransform:
+    """Handle on rvc_mel_*: STFT magnitude / log-mel for any (n_fft, hop, window, pad, mel matrix) on the device."""
+
+    def __init__(self, n_fft: int, hop: int, win_length: int, pad: int, mel_matrix, mag_eps: float = 0.0, log_floor: float = 1e-5):
+        import numpy as np
+        m = np.ascontiguousarray(mel_matrix, dtype=np.float32)
+        if m.ndim != 2 or m.shape[1] != n_fft // 2 + 1:
+            raise NativeError(f"mel matrix must be [n_mels, {n_fft // 2 + 1}], got {m.shape}")
+        self.n_fft, self.hop, self.n_mels, self.bins = n_fft, hop, m.shape[0], n_fft // 2 + 1
+        self._h = c_void_p()
+        _check(_lib.rvc_mel_create(n_fft, hop, win_length, pad, float(mag_eps), float(log_floor), m.ctypes.data, m.shape[0],
+                                   ctypes.byref(self._h)), "rvc_mel_create")
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.rvc_mel_destroy(self._h)
+            self._h = None
+
+    def n_frames(self, n_samples: int) -> int:
+        t = c_int64()
+        _check(_lib.rvc_mel_frames(self._h, n_samples, ctypes.byref(t)), "rvc_mel_frames")
+        return t.value
+
+    def forward(self, audio: torch.Tensor, want_mel: bool = True, want_spec: bool = False):
+        """audio [B, n] float32 on the device -> (log-mel [B, n_mels, T] or None, magnitude [B, n_fft/2+1, T] or None)."""
+        audio = _dev_f32(audio, "audio")
+        b, n = audio.shape
+        t = self.n_frames(n)
+        mel = torch.empty((b, self.n_mels, t), dtype=torch.float32, device=audio.device) if want_mel else None
+        spec = torch.empty((b, self.bins, t), dtype=torch.float32, device=audio.device) if want_spec else None
+        need = c_size_t()
+        _check(_lib.rvc_mel_workspace_bytes(self._h, b, n, ctypes.byref(need)), "rvc_mel_workspace_bytes")
+        ws = _ws.get("mel", need.value, audio.device)
+        _check(_lib.rvc_mel_forward(self._h, audio.data_ptr(), b, n, mel.data_ptr() if mel is not None else None,
+                                    spec.data_ptr() if spec is not None else None, ws.data_ptr(), ws.numel(), _stream()),
+               "rvc_mel_forward")
+        return mel, spec
+
+
+def resample_poly(x: torch.Tensor, up: int, down: int, h: torch.Tensor) -> torch.Tensor:
+    """x [n] float64 on the device, h the FIR (float64, device) -> ceil(n * up / down) samples (resample_poly convention)."""
+    if not (x.is_cuda and x.dtype == torch.float64 and x.dim() == 1 and h.is_cuda and h.dtype == torch.float64):
+        raise NativeError("resample_poly wants 1-D float64 HBM tensors")
+    x, h = x.contiguous(), h.contiguous()
+    n_out = -(-x.numel() * up // down)
+    y = torch.empty(n_out, dtype=torch.float64, device=x.device)
+    _check(_lib.rvc_resample_poly_f64(x.data_ptr(), x.numel(), int(up), int(down), h.data_ptr(), h.numel(), y.data_ptr(), n_out,
+                                      _stream()), "rvc_resample_poly_f64")
+    return y
 
 
 # ---- K6 ------------------------------------------------------------------------------------------

@@ -1,7 +1,8 @@
 """``VoiceConverter`` -- orchestration around the pipeline with the reference's surface
 (rvc/infer/infer.py:41-493).  File decoding/resampling, noise reduction and the pedalboard effects are out of
-scope: ``convert_audio`` handles WAV I/O through the standard library and expects
-16 kHz mono input, or use ``convert_array`` with a NumPy signal.
+scope: ``convert_audio`` reads WAV files of any rate / channel count / PCM or float encoding
+(rvc_amd.lib.audio: own RIFF parser, device-side polyphase resampler to 16 kHz in place of soxr) and writes 16-bit WAV, or
+use ``convert_array`` with a NumPy signal.
 """
 from __future__ import annotations
 
@@ -15,23 +16,10 @@ import torch
 
 from rvc_amd.configs.config import Config
 from rvc_amd.infer.pipeline import Pipeline as VC
+from rvc_amd.lib.audio import load_audio_infer
 from rvc_amd.lib.algorithm.synthesizers import Synthesizer
 from rvc_amd.lib.hubert import HubertModelWithFinalProj
 from rvc_amd.lib.tools.split_audio import merge_audio, process_audio
-
-
-def _read_wav_16k_mono(path):
-    with wave.open(path, "rb") as f:
-        sr, ch, sw, n = f.getframerate(), f.getnchannels(), f.getsampwidth(), f.getnframes()
-        raw = f.readframes(n)
-    if sw != 2:
-        raise RuntimeError("only 16-bit PCM WAV input is supported without soundfile")
-    a = np.frombuffer(raw, dtype="<i2").astype(np.float64) / 32768.0
-    if ch > 1:
-        a = a.reshape(-1, ch).mean(1)
-    if sr != 16000:
-        raise RuntimeError(f"input must be 16 kHz (got {sr}); resampling (soxr) is outside the hot path")
-    return a
 
 
 def _write_wav(path, audio, sr):
@@ -223,7 +211,7 @@ class VoiceConverter:
             if clean_audio or post_process or export_format != "WAV":
                 raise NotImplementedError("clean_audio / post_process / non-WAV export are outside the hot path "
                                           "(SURVEY §2 items 2, 9)")
-            audio = _read_wav_16k_mono(audio_input_path)
+            audio = load_audio_infer(audio_input_path, 16000, device=self.config.device)   # infer.py:257-260
             if not self.hubert_model or embedder_model != self.last_embedder_model:
                 self.load_hubert(embedder_model, embedder_model_custom)
                 self.last_embedder_model = embedder_model

@@ -98,6 +98,32 @@ int rvc_logmel_workspace_bytes(int batch, int64_t n_samples, size_t *bytes);
 int rvc_logmel_rmvpe(const float *audio_dev, int batch, int64_t n_samples, float *mel_dev,
                      int64_t n_frames_padded, void *workspace_dev, size_t workspace_bytes, void *stream);
 
+/* ---- K4b: the same transform as a handle, for the training-side features --------------------------------------- *
+ * Replaces `spectrogram_torch` / `mel_spectrogram_torch` of rvc/train/mel_processing.py:53-146 (feature side of
+ * rvc/train/extract): reflect pad `pad` samples per side, frames of n_fft every hop (center = False
+ * in torch.stft terms), periodic hann(win_length) centred in n_fft, |X| = sqrt(re^2 + im^2 + mag_eps),
+ * mel = log(max(M |X|, log_floor)) with the caller's mel matrix M [n_mels][n_fft/2+1] (host, fp32; librosa.filters.mel in
+ * the reference, mel_processing.py:113-119).  The reference's values: n_fft 2048, hop 480 (sr / 100), win 2048,
+ * pad (n_fft - hop) / 2, mag_eps 1e-6, log_floor 1e-5, 128 bands at 48 kHz (rvc/configs/48000.json).
+ * audio_dev [batch][n_samples]; mel_dev [batch][n_mels][n_frames] and/or spec_dev [batch][n_fft/2+1][n_frames] (either may
+ * be NULL); n_frames from rvc_mel_frames.  The handle is read-only after creation. */
+typedef struct rvc_mel rvc_mel;
+int rvc_mel_create(int n_fft, int hop, int win_length, int pad, float mag_eps, float log_floor, const float *mel_host, int n_mels,
+                   rvc_mel **out);
+int rvc_mel_destroy(rvc_mel *h);
+int rvc_mel_frames(const rvc_mel *h, int64_t n_samples, int64_t *n_frames);
+int rvc_mel_workspace_bytes(const rvc_mel *h, int batch, int64_t n_samples, size_t *bytes);
+int rvc_mel_forward(const rvc_mel *h, const float *audio_dev, int batch, int64_t n_samples, float *mel_dev, float *spec_dev,
+                    void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* ---- input front end: rational resampling --------------------------------------------------------------------- *
+ * Replaces `librosa.resample(audio, orig_sr=sr, target_sr=sample_rate, res_type="soxr_vhq")` of `load_audio` /
+ * `load_audio_infer` (rvc/lib/utils.py:21-50, 53-85; soxr is third-party and absent: parity unpinned, the filter is this
+ * build's own Kaiser design).  y[j] = sum_m h[m] * xup[j * down + (n_taps - 1) / 2 - m] with xup the input zero-stuffed by
+ * `up` (scipy.signal.upfirdn / resample_poly convention); float64 throughout. h_dev: the caller's FIR, gain `up`. */
+int rvc_resample_poly_f64(const double *x_dev, int64_t n_in, int up, int down, const double *h_dev, int64_t n_taps,
+                          double *y_dev, int64_t n_out, void *stream);
+
 /* ---- K6: zero-phase high-pass ------------------------------------------------------------------ *
  * Replaces `signal.filtfilt(bh, ah, audio)` (rvc/infer/pipeline.py:562; 5th-order Butterworth, pipeline.py:23-28)
  * with SciPy's defaults (padtype "odd", padlen 18, lfilter_zi initial conditions), float64, on the device.

@@ -840,3 +840,56 @@ def pipeline(hubert_sd, rmvpe_sd, cpt, audio: np.ndarray, *, sid=0, pitch=0, big
     if audio_max > 1:
         audio_opt /= audio_max
     return audio_opt
+
+
+# ----------------------------------------------------------------------------------------------
+# training-side features: rvc/train/mel_processing.py, rvc/train/extract/extract.py
+# ----------------------------------------------------------------------------------------------
+
+
+def slaney_mel_basis(sr: int, n_fft: int, n_mels: int, fmin: float = 0.0, fmax=None) -> np.ndarray:
+    """librosa.filters.mel with its defaults (htk=False, norm="slaney"), what mel_processing.py:113-115 asks for.  Third
+    party and absent here: restated from librosa 0.11's published algorithm; pinned by the fixture basis_* of
+    tests/golden/train_features.npz, which comes from the reference's own vendored clone of that function."""
+    fmax = sr / 2 if fmax is None else fmax
+    f_sp, min_log_hz, logstep = 200.0 / 3, 1000.0, np.log(6.4) / 27.0
+
+    def hz_to_mel(f):
+        f = np.asarray(f, dtype=np.float64)
+        return np.where(f >= min_log_hz, min_log_hz / f_sp + np.log(np.maximum(f, 1e-300) / min_log_hz) / logstep, f / f_sp)
+
+    def mel_to_hz(m):
+        m = np.asarray(m, dtype=np.float64)
+        return np.where(m >= min_log_hz / f_sp, min_log_hz * np.exp(logstep * (m - min_log_hz / f_sp)), f_sp * m)
+
+    freqs = np.fft.rfftfreq(n_fft, 1.0 / sr)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2))
+    fdiff, ramps = np.diff(mel_f), np.subtract.outer(mel_f, freqs)
+    w = np.zeros((n_mels, n_fft // 2 + 1), dtype=np.float32)
+    for i in range(n_mels):
+        w[i] = np.maximum(0, np.minimum(-ramps[i] / fdiff[i], ramps[i + 2] / fdiff[i + 1]))
+    w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return w
+
+
+def spectrogram(y: Tensor, n_fft: int, hop: int, win: int) -> Tensor:
+    """spectrogram_torch, mel_processing.py:53-97 (center=False): reflect pad (n_fft - hop) / 2, periodic hann, |X| with
+    the 1e-6 inside the square root."""
+    pad = int((n_fft - hop) / 2)
+    y = F.pad(y.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
+    spec = torch.stft(y, n_fft=n_fft, hop_length=hop, win_length=win, window=torch.hann_window(win, dtype=y.dtype), center=False,
+                      normalized=False, onesided=True, return_complex=True)
+    return torch.sqrt(spec.real.pow(2) + spec.imag.pow(2) + 1e-6)
+
+
+def mel_spectrogram(y: Tensor, n_fft: int, n_mels: int, sr: int, hop: int, win: int, fmin: float = 0.0, fmax=None) -> Tensor:
+    """mel_spectrogram_torch, mel_processing.py:126-146: log(clamp(M |X|, 1e-5))."""
+    basis = torch.from_numpy(slaney_mel_basis(sr, n_fft, n_mels, fmin, fmax))
+    return torch.log(torch.clamp(torch.matmul(basis, spectrogram(y, n_fft, hop, win)), min=1e-5))
+
+
+def extract_coarse_f0(f0: np.ndarray) -> np.ndarray:
+    """FeatureInput.coarse_f0, extract.py:76-87."""
+    f0_mel = 1127.0 * np.log(1.0 + f0 / 700.0)
+    f0_mel = np.clip((f0_mel - F0_MEL_MIN) * 254 / (F0_MEL_MAX - F0_MEL_MIN) + 1, 1, 255)
+    return np.rint(f0_mel).astype(int)
