@@ -42,13 +42,26 @@ namespace rvc {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int KS_BM = 256;        // index rows per tile
-constexpr int KS_BN = 256;        // queries per block
-constexpr int KS_BK = 64;         // halves per staged chunk (128 B)
-constexpr int KS_THREADS = 512;
-constexpr int KS_ROWB = 144;      // LDS bytes per staged row: 128 + 16 pad
-constexpr int KS_SLOTS_PER_TILE = 4;   // (wave row half) x (lane half): disjoint row subsets of a tile
-constexpr size_t KS_LDS_BYTES = 2 * (size_t)(KS_BM + KS_BN) * KS_ROWB + 2 * KS_BM * sizeof(float);
+constexpr int KS_BN = 256;        // queries per block (4 wave columns x 64)
+// Tile shape, template parameters of the GEMM kernel:
+//   WM  wave rows per block: block = 128 WM index rows x 256 queries, 4 WM waves, each wave 128 rows x 64 queries
+//   BK  halves of K per staged chunk (64: 128-byte rows, 4 MFMA steps per chunk; 32: 64-byte rows, 2 steps)
+// LDS rows are padded by 16 B (conflict-free ds_read_b128 for both row lengths); two chunk buffers.
+//   WM 2, BK 64: 147 KB -> one 8-wave block per CU: every wave of the CU meets at the same barrier each chunk
+//   WM 1, BK 32:  61 KB -> two 4-wave blocks per CU with independent barriers: one block's staging overlaps the other's MFMAs
+template <int WM, int BK>
+struct ScreenTile {
+    static constexpr int BM = 128 * WM;
+    static constexpr int THREADS = 256 * WM;
+    static constexpr int ROWB = 2 * BK + 16;
+    static constexpr int KSTEPS = BK / 16;
+    static constexpr int PIECES = BK / 8;                          // 16-byte pieces per staged row
+    static constexpr int A_LOADS = BM * PIECES / THREADS;          // per thread per chunk
+    static constexpr int B_LOADS = KS_BN * PIECES / THREADS;
+    static constexpr int ROWS_PER_PASS = THREADS / PIECES;         // rows one staging pass of the block covers
+    static constexpr int SLOTS_PER_TILE = 2 * WM;                  // (wave row) x (lane half): disjoint row subsets of a tile
+    static constexpr size_t LDS_BYTES = 2 * (size_t)(BM + KS_BN) * ROWB + 2 * BM * sizeof(float);
+};
 
 // ---- fp32 -> fp16 rows with the measured rounding residual --------------------------------------------------------
 // one wave per row.  norms (optional): sum x^2 in the order knn_norms_kernel uses.  rowstat (optional): {sum x^2,
@@ -118,13 +131,15 @@ struct ScreenParams {
     int n_slots;
 };
 
-template <bool APPEND>
-__global__ void __launch_bounds__(KS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <bool APPEND, int WM, int BK>
+__global__ void __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(2, 2)))
 knn_screen_kernel(const ScreenParams p) {
+    using TL = ScreenTile<WM, BK>;
+    constexpr int BM = TL::BM, ROWB = TL::ROWB;
     extern __shared__ __attribute__((aligned(16))) unsigned char ks_smem[];
-    unsigned char *As = ks_smem;                                   // [2][KS_BM][KS_ROWB]
-    unsigned char *Bs = ks_smem + 2 * KS_BM * KS_ROWB;             // [2][KS_BN][KS_ROWB]
-    float *xn_s = reinterpret_cast<float *>(ks_smem + 2 * (KS_BM + KS_BN) * KS_ROWB);   // [2][KS_BM]
+    unsigned char *As = ks_smem;                                   // [2][BM][ROWB]
+    unsigned char *Bs = ks_smem + 2 * BM * ROWB;                   // [2][KS_BN][ROWB]
+    float *xn_s = reinterpret_cast<float *>(ks_smem + 2 * (BM + KS_BN) * ROWB);   // [2][BM]
 
     // XCD-aware placement: consecutive block ids go round the 8 XCDs; the query tiles of one stripe share an XCD
     const int b = blockIdx.x;
@@ -137,7 +152,7 @@ knn_screen_kernel(const ScreenParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3, h = lane >> 5, l31 = lane & 31;
     const int dim = p.dim;
-    const int n_kc = dim / KS_BK;
+    const int n_kc = dim / BK;
     const int64_t q0 = (int64_t)qtile * KS_BN;
     const int first = stripe * p.tiles_per_block;
     int n_my = p.tiles_per_block;
@@ -148,36 +163,40 @@ knn_screen_kernel(const ScreenParams p) {
     }
     const int n_chunks = n_my * n_kc;
 
-    f16x8 ar[4], br[4];   // staging registers: 4 x 16 B of the row tile and of the query tile per thread
-    const int srow = tid >> 3, sc = tid & 7;       // piece i: row srow + 64 i, 16-byte column sc
+    f16x8 ar[TL::A_LOADS], br[TL::B_LOADS];   // staging registers: 16-byte pieces of the row tile and of the query tile
+    const int srow = tid / TL::PIECES, sc = tid % TL::PIECES;      // piece i: row srow + ROWS_PER_PASS i, 16-byte column sc
     const _Float16 *const xh = p.xh;
     const _Float16 *const qh = p.qh;
     const int64_t n_rows = p.n_rows, n_queries = p.n_queries;
 
-    auto tile_row0 = [&](int t) __attribute__((always_inline)) { return (int64_t)(first + t) * p.tile_step * KS_BM; };
+    auto tile_row0 = [&](int t) __attribute__((always_inline)) { return (int64_t)(first + t) * p.tile_step * BM; };
     auto load_chunk = [&](int c) __attribute__((always_inline)) {
         const int t = c / n_kc, kc = c - t * n_kc;
         const int64_t r0 = tile_row0(t);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int64_t r = r0 + srow + 64 * i;
+        for (int i = 0; i < TL::A_LOADS; ++i) {
+            int64_t r = r0 + srow + TL::ROWS_PER_PASS * i;
             r = r < n_rows ? r : n_rows - 1;                         // clamped: the row's ||x||^2 is +inf in xn_s
-            ar[i] = *reinterpret_cast<const f16x8 *>(xh + r * dim + kc * KS_BK + sc * 8);
-            int64_t q = q0 + srow + 64 * i;
+            ar[i] = *reinterpret_cast<const f16x8 *>(xh + r * dim + kc * BK + sc * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < TL::B_LOADS; ++i) {
+            int64_t q = q0 + srow + TL::ROWS_PER_PASS * i;
             q = q < n_queries ? q : n_queries - 1;
-            br[i] = *reinterpret_cast<const f16x8 *>(qh + q * dim + kc * KS_BK + sc * 8);
+            br[i] = *reinterpret_cast<const f16x8 *>(qh + q * dim + kc * BK + sc * 8);
         }
     };
     auto store_chunk = [&](int buf, int c) __attribute__((always_inline)) {
         const int t = c / n_kc, kc = c - t * n_kc;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f16x8 *>(As + ((size_t)buf * KS_BM + srow + 64 * i) * KS_ROWB + sc * 16) = ar[i];
-            *reinterpret_cast<f16x8 *>(Bs + ((size_t)buf * KS_BN + srow + 64 * i) * KS_ROWB + sc * 16) = br[i];
-        }
-        if (kc == 0 && tid < KS_BM) {
+        for (int i = 0; i < TL::A_LOADS; ++i)
+            *reinterpret_cast<f16x8 *>(As + ((size_t)buf * BM + srow + TL::ROWS_PER_PASS * i) * ROWB + sc * 16) = ar[i];
+#pragma unroll
+        for (int i = 0; i < TL::B_LOADS; ++i)
+            *reinterpret_cast<f16x8 *>(Bs + ((size_t)buf * KS_BN + srow + TL::ROWS_PER_PASS * i) * ROWB + sc * 16) = br[i];
+        if (kc == 0 && tid < BM) {
             const int64_t r = tile_row0(t) + tid;
-            xn_s[(t & 1) * KS_BM + tid] = r < n_rows ? p.xn[r] : INFINITY;
+            xn_s[(t & 1) * BM + tid] = r < n_rows ? p.xn[r] : INFINITY;
         }
     };
 
@@ -205,19 +224,20 @@ knn_screen_kernel(const ScreenParams p) {
     __syncthreads();
     for (int c = 0; c < n_chunks; ++c) {
         const int buf = c & 1;
-        const unsigned char *ab = As + ((size_t)buf * KS_BM + 128 * wm + l31) * KS_ROWB + 64 * h;
-        const unsigned char *bb = Bs + ((size_t)buf * KS_BN + 64 * wn + l31) * KS_ROWB + 64 * h;
+        // lane (row i, half h) owns bytes [BK h, BK h + BK) of its row's chunk: KSTEPS operands of 8 halves
+        const unsigned char *ab = As + ((size_t)buf * BM + 128 * wm + l31) * ROWB + BK * h;
+        const unsigned char *bb = Bs + ((size_t)buf * KS_BN + 64 * wn + l31) * ROWB + BK * h;
         f16x8 a[2][4], bq[2][2];
         auto frag = [&](int t, f16x8 (&av)[4], f16x8 (&bv)[2]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f16x8 *>(ab + (size_t)m * 32 * KS_ROWB + 16 * t);
+            for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f16x8 *>(ab + (size_t)m * 32 * ROWB + 16 * t);
 #pragma unroll
-            for (int n = 0; n < 2; ++n) bv[n] = *reinterpret_cast<const f16x8 *>(bb + (size_t)n * 32 * KS_ROWB + 16 * t);
+            for (int n = 0; n < 2; ++n) bv[n] = *reinterpret_cast<const f16x8 *>(bb + (size_t)n * 32 * ROWB + 16 * t);
         };
         frag(0, a[0], bq[0]);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (t + 1 < 4) frag(t + 1, a[(t + 1) & 1], bq[(t + 1) & 1]);
+        for (int t = 0; t < TL::KSTEPS; ++t) {
+            if (t + 1 < TL::KSTEPS) frag(t + 1, a[(t + 1) & 1], bq[(t + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
@@ -229,7 +249,7 @@ knn_screen_kernel(const ScreenParams p) {
         const int t_cur = c / n_kc;
         if (c - t_cur * n_kc == n_kc - 1) {
             // the tile is complete: s~ = ||x||^2 - 2 q~.x~ for this lane's 64 rows x 2 queries
-            const float *xn_t = xn_s + (t_cur & 1) * KS_BM + 128 * wm + 4 * h;
+            const float *xn_t = xn_s + (t_cur & 1) * BM + 128 * wm + 4 * h;
             const int row_base = (int)(tile_row0(t_cur)) + 128 * wm + 4 * h;
 #pragma unroll
             for (int m = 0; m < 4; ++m)
@@ -263,8 +283,172 @@ knn_screen_kernel(const ScreenParams p) {
         }
     }
     if (!APPEND) {
-        // one minimum per (query, tile quarter): the row subsets of different slots are disjoint
-        const int slot = (first / 1) * KS_SLOTS_PER_TILE + wm * 2 + h;   // MIN passes run one tile per block: first == stripe
+        // one minimum per (query, row subset of the tile): the subsets of different slots are disjoint
+        const int slot = first * TL::SLOTS_PER_TILE + wm * 2 + h;   // MIN passes run one tile per block: first == stripe
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int64_t q = q0 + 64 * wn + 32 * n + l31;
+            if (q < n_queries) p.mins[q * p.n_slots + slot] = mn[n];
+        }
+    }
+}
+
+// ---- the same GEMM with LDS-DMA staging (global_load_lds, 16 B per lane): WM = 2, BK = 64 -----------------------------
+// Register staging costs the block a store phase per chunk in which all 8 waves push 64 ds_write_b128 through the LDS write
+// path while the matrix pipe idles (PMC: 36 % of wave time parked in s_waitcnt / barrier), and 32 staging VGPRs.  Here the
+// chunk goes HBM/L2 -> LDS directly.  An LDS-DMA instruction writes lane l at base + 16 l, so padded rows are impossible;
+// the conflict-free image is built from 8-row groups instead: group g (8 rows x 128 B) at g * 1152 B (128 B of padding per
+// group) with the 16-byte pieces of row r XOR-permuted by (r & 7) -- the permutation is applied to the per-lane SOURCE
+// address, the LDS side stays linear.  ds_read_b128 of a fragment (16 rows per lane group, one piece each) then hits 16
+// distinct 16-byte bank slots (checked exhaustively for every lane group, half and k-step).  Two buffers: the DMA of chunk
+// c + 1 is issued at the top of iteration c, runs under its 32 MFMAs, and is retired by s_waitcnt vmcnt(0) + barrier.
+constexpr int KG_GROUP = 1152;                      // bytes per 8-row group
+constexpr int KG_BUF = 32 * KG_GROUP;               // one operand buffer: 256 rows
+
+template <bool APPEND>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+knn_screen_glds_kernel(const ScreenParams p) {
+    constexpr int BM = 256, BK = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ks_smem[];
+    unsigned char *As = ks_smem;                                   // [2][32 groups][1152]
+    unsigned char *Bs = ks_smem + 2 * KG_BUF;
+    float *xn_s = reinterpret_cast<float *>(ks_smem + 4 * KG_BUF); // [2][BM]
+
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int j = b >> 3;
+    const int stripe = (j / p.n_qtiles) * 8 + xcd;
+    const int qtile = j % p.n_qtiles;
+    if (stripe >= p.n_stripes) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3, h = lane >> 5, l31 = lane & 31;
+    const int dim = p.dim;
+    const int n_kc = dim / BK;
+    const int64_t q0 = (int64_t)qtile * KS_BN;
+    const int first = stripe * p.tiles_per_block;
+    int n_my = p.tiles_per_block;
+    {
+        const int last_tile = (p.n_tiles - 1) / p.tile_step;
+        if (first > last_tile) return;
+        if (first + n_my - 1 > last_tile) n_my = last_tile - first + 1;
+    }
+    const int n_chunks = n_my * n_kc;
+    const _Float16 *const xh = p.xh;
+    const _Float16 *const qh = p.qh;
+    const int64_t n_rows = p.n_rows, n_queries = p.n_queries;
+    auto tile_row0 = [&](int t) __attribute__((always_inline)) { return (int64_t)(first + t) * p.tile_step * BM; };
+
+    typedef const void __attribute__((address_space(1))) *gptr_t;
+    typedef void __attribute__((address_space(3))) *lptr_t;
+    const int rr = lane >> 3;                       // row inside the 8-row group this lane fetches
+    const int piece = (lane & 7) ^ rr;              // 16-byte piece of that row (XOR swizzle on the source side)
+    auto dma_chunk = [&](int buf, int c) __attribute__((always_inline)) {
+        const int t = c / n_kc, kc = c - t * n_kc;
+        const int64_t r0 = tile_row0(t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int g = wave * 4 + i;             // wave-uniform group index: rows 8 g .. 8 g + 7 of both tiles
+            int64_t r = r0 + g * 8 + rr;
+            r = r < n_rows ? r : n_rows - 1;        // clamped; such rows are masked in the epilogue
+            __builtin_amdgcn_global_load_lds((gptr_t)(xh + r * dim + kc * BK + piece * 8),
+                                             (lptr_t)(As + (size_t)buf * KG_BUF + g * KG_GROUP), 16, 0, 0);
+            int64_t q = q0 + g * 8 + rr;
+            q = q < n_queries ? q : n_queries - 1;
+            __builtin_amdgcn_global_load_lds((gptr_t)(qh + q * dim + kc * BK + piece * 8),
+                                             (lptr_t)(Bs + (size_t)buf * KG_BUF + g * KG_GROUP), 16, 0, 0);
+        }
+        if (kc == 0 && wave < 4) {                  // ||x||^2 of the tile's 256 rows: 4 bytes per lane, same engine
+            int64_t r = r0 + wave * 64 + lane;
+            r = r < n_rows ? r : n_rows - 1;
+            __builtin_amdgcn_global_load_lds((gptr_t)(p.xn + r), (lptr_t)(xn_s + (t & 1) * BM + wave * 64), 4, 0, 0);
+        }
+    };
+
+    float thr[2], mn[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int64_t q = q0 + 64 * wn + 32 * n + l31;
+        mn[n] = INFINITY;
+        thr[n] = -INFINITY;
+        if (APPEND && q < n_queries) thr[n] = p.thr[q];
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    // fragment addressing: row 128 wm + 32 m + l31 -> group (row >> 3), row-in-group l31 & 7, piece (4 h + t) ^ (l31 & 7)
+    const int sw = l31 & 7;
+    const int a_row_off = ((128 * wm + l31) >> 3) * KG_GROUP + sw * 128;     // + m * 4 groups
+    const int b_row_off = ((64 * wn + l31) >> 3) * KG_GROUP + sw * 128;      // + n * 4 groups
+
+    dma_chunk(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c = 0; c < n_chunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < n_chunks) dma_chunk(buf ^ 1, c + 1);     // buffer buf ^ 1 was last read in iteration c - 1 (barrier passed)
+        const unsigned char *ab = As + (size_t)buf * KG_BUF + a_row_off;
+        const unsigned char *bb = Bs + (size_t)buf * KG_BUF + b_row_off;
+        f16x8 a[2][4], bq[2][2];
+        auto frag = [&](int t, f16x8 (&av)[4], f16x8 (&bv)[2]) __attribute__((always_inline)) {
+            const int po = ((4 * h + t) ^ sw) * 16;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f16x8 *>(ab + m * 4 * KG_GROUP + po);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) bv[n] = *reinterpret_cast<const f16x8 *>(bb + n * 4 * KG_GROUP + po);
+        };
+        frag(0, a[0], bq[0]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t + 1 < 4) frag(t + 1, a[(t + 1) & 1], bq[(t + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t & 1][m], bq[t & 1][n], acc[m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int t_cur = c / n_kc;
+        if (c - t_cur * n_kc == n_kc - 1) {
+            const float *xn_t = xn_s + (t_cur & 1) * BM + 128 * wm + 4 * h;
+            const int row_base = (int)(tile_row0(t_cur)) + 128 * wm + 4 * h;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = m * 32 + (r & 3) + 8 * (r >> 2);
+                    const float xnv = row_base + ro < n_rows ? xn_t[ro] : INFINITY;
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const float v = fmaf(-2.f, acc[m][n][r], xnv);
+                        if (APPEND) {
+                            if (!(v >= thr[n])) {
+                                const int64_t q = q0 + 64 * wn + 32 * n + l31;
+                                if (q < n_queries && row_base + ro < n_rows) {
+                                    const int pos = atomicAdd(&p.cand_cnt[q], 1);
+                                    if (pos < p.cap) p.cand_id[q * p.cap + pos] = row_base + ro;
+                                }
+                            }
+                        } else {
+                            mn[n] = fminf(mn[n], v);
+                        }
+                        acc[m][n][r] = 0.f;
+                    }
+                }
+        }
+        if (c + 1 < n_chunks) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of chunk c + 1 have landed
+            __syncthreads();                                   // ... and everybody's; everybody is done reading buf
+        }
+    }
+    if (!APPEND) {
+        const int slot = first * 4 + wm * 2 + h;
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const int64_t q = q0 + 64 * wn + 32 * n + l31;
@@ -311,8 +495,10 @@ knn_select_kernel(const float *__restrict__ mins, int n_slots, const f32x4 *__re
 // not re-scored (the lists hold 8 entries per row subset, thousands per query).
 constexpr int KF_CHUNK = 2048;
 
+constexpr int KF_WAVES = 8;
+
 template <int J>   // dim = 256 J
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * KF_WAVES)
 knn_finalize_kernel(const float *__restrict__ index, int64_t n_rows, const float *__restrict__ queries,
                     const int *__restrict__ cand_id, const int *__restrict__ cand_cnt, const float *__restrict__ cand_s,
                     const unsigned *__restrict__ xstats, int cap, float *__restrict__ out_d2, int64_t *__restrict__ out_ids,
@@ -322,8 +508,8 @@ knn_finalize_kernel(const float *__restrict__ index, int64_t n_rows, const float
     __shared__ int id_s[KF_CHUNK];
     __shared__ float best_d[KNN_K];
     __shared__ int best_i[KNN_K];
-    __shared__ float wtop[4][KNN_K];
-    __shared__ int wtopi[4][KNN_K];
+    __shared__ float wtop[KF_WAVES][KNN_K];
+    __shared__ int wtopi[KF_WAVES][KNN_K];
     __shared__ int keep_s[KF_CHUNK];
     __shared__ int n_keep;
     const int64_t q = blockIdx.x;
@@ -351,14 +537,15 @@ knn_finalize_kernel(const float *__restrict__ index, int64_t n_rows, const float
         int id[KNN_K];
 #pragma unroll
         for (int i = 0; i < KNN_K; ++i) { d[i] = INFINITY; id[i] = 0x7fffffff; }
-        for (int c = tid; c < total; c += 256)
+        for (int c = tid; c < total; c += 64 * KF_WAVES)
             if (cand_id[q * cap + c] >= 0) list_insert(d, id, cand_s[q * cap + c], c);
         wave_top8(d, id, lane, wtop[wave], wtopi[wave]);
         __syncthreads();
         if (wave == 0) {
 #pragma unroll
             for (int i = 0; i < KNN_K; ++i) { d[i] = INFINITY; id[i] = 0x7fffffff; }
-            if (lane < 4 * KNN_K) { d[0] = wtop[lane >> 3][lane & 7]; id[0] = wtopi[lane >> 3][lane & 7]; }
+            static_assert(KF_WAVES * KNN_K <= 64, "one candidate per lane in the second merge level");
+            if (lane < KF_WAVES * KNN_K) { d[0] = wtop[lane >> 3][lane & 7]; id[0] = wtopi[lane >> 3][lane & 7]; }
             wave_top8(d, id, lane, wtop[0], wtopi[0]);
         }
         __syncthreads();
@@ -377,7 +564,7 @@ knn_finalize_kernel(const float *__restrict__ index, int64_t n_rows, const float
         // keep the entries under the cut-off (a dozen out of thousands), compacted in LDS
         if (tid == 0) n_keep = 0;
         __syncthreads();
-        for (int c = tid; c < total; c += 256) {
+        for (int c = tid; c < total; c += 64 * KF_WAVES) {
             const int id = cand_id[q * cap + c];
             if (id >= 0 && cand_s[q * cap + c] <= tau) {
                 const int pos = atomicAdd(&n_keep, 1);
@@ -392,7 +579,7 @@ knn_finalize_kernel(const float *__restrict__ index, int64_t n_rows, const float
     for (int64_t base = 0; base < total; base += KF_CHUNK) {
         const int n = (int)((total - base) < KF_CHUNK ? (total - base) : KF_CHUNK);
         constexpr int U = 4;                                  // candidates per wave per trip: their row loads overlap
-        for (int c0 = U * wave; c0 < n; c0 += 4 * U) {
+        for (int c0 = U * wave; c0 < n; c0 += KF_WAVES * U) {
             int id[U];
             f32x4 xv[U][J];
 #pragma unroll
@@ -463,6 +650,7 @@ static KnnAux knn_aux(int64_t n_rows, int dim) {
 }
 
 struct ScreenPlan {
+    int wm, bk, bm, slots_per_tile;     // tile shape (ScreenTile<WM, BK>)
     int n_tiles, n_qtiles;
     int sample_tiles, sample_step;      // MIN pass
     int tiles_per_block, n_stripes;     // APPEND pass
@@ -477,15 +665,23 @@ static int env_i(const char *name, int dflt) {
 
 static ScreenPlan screen_plan(int64_t n_rows, int64_t n_queries, int dim) {
     ScreenPlan s;
-    s.n_tiles = (int)ceil_div(n_rows, KS_BM);
+    // measured at 1599 x 100 k / 2 M (ms per search): WM 2 BK 64 0.541 / 8.77; WM 2 BK 32 0.557; WM 1 BK 32 (two blocks per CU)
+    // 0.607 / 11.9; WM 1 BK 64 spills (1.13).  Both operands stream at ~11 B/clk/CU: the large tile's lower traffic per flop wins.
+    static const int tile_env = env_i("RVC_KNN_TILE", 0);      // 264 = WM 2 / BK 64 (default), 132 = WM 1 / BK 32
+    const int tile = tile_env == 132 ? 132 : 264;
+    s.wm = tile / 100;
+    s.bk = tile % 100;
+    s.bm = 128 * s.wm;
+    s.slots_per_tile = 2 * s.wm;
+    s.n_tiles = (int)ceil_div(n_rows, s.bm);
     s.n_qtiles = (int)ceil_div(n_queries, KS_BN);
     // sample size ~ sqrt(2560 N) rows balances the sample pass against the exact re-scoring of ~8 N / sample survivors
     static const int sample_env = env_i("RVC_KNN_SAMPLE_TILES", 0);
     int64_t want = 1;
-    while (want * want * KS_BM * KS_BM < 2560 * n_rows) ++want;
+    while (want * want * s.bm * s.bm < 2560 * n_rows) ++want;
     if (sample_env) want = sample_env;
     if (want < 16) want = 16;
-    if (want > 256) want = 256;
+    if (want > 512) want = 512;
     if (want > s.n_tiles) want = s.n_tiles;
     s.sample_step = s.n_tiles / (int)want;
     s.sample_tiles = (int)want;
@@ -500,7 +696,7 @@ static ScreenPlan screen_plan(int64_t n_rows, int64_t n_queries, int dim) {
     size_t off = 0;
     s.qh = off; off += align_up((size_t)n_queries * dim * sizeof(_Float16), 256);
     s.qstat = off; off += align_up((size_t)n_queries * sizeof(f32x4), 256);
-    s.mins = off; off += align_up((size_t)n_queries * s.sample_tiles * KS_SLOTS_PER_TILE * sizeof(float), 256);
+    s.mins = off; off += align_up((size_t)n_queries * 512 * 4 * sizeof(float), 256);   // room for any tile shape
     s.thr = off; off += align_up((size_t)n_queries * sizeof(float), 256);
     s.cnt = off; off += align_up((size_t)(n_queries + 1) * sizeof(int), 256);     // + the exact-scan counter
     s.cand = off; off += align_up((size_t)n_queries * s.cap * sizeof(int), 256);
@@ -513,8 +709,8 @@ static int g_knn_mode = 0;   // rvc_knn_set_mode: 0 auto, 1 exact fp32 GEMM, 2 s
 bool knn_screen_applicable(int64_t n_rows, int64_t n_queries, int dim) {
     if (g_knn_mode == 1) return false;
     if (dim % 256 != 0 || dim > 1024) return false;
-    if (n_rows >= ((int64_t)1 << 31) - KS_BM) return false;
-    if (g_knn_mode == 2) return n_rows >= KS_BM * 16;
+    if (n_rows >= ((int64_t)1 << 31) - 256) return false;
+    if (g_knn_mode == 2) return n_rows >= 4096;
     return n_queries > 64 && n_rows >= 16384;
 }
 
@@ -523,7 +719,7 @@ size_t knn_screen_workspace_bytes(int64_t n_rows, int64_t n_queries, int dim) { 
 int knn_finalize_launch(const float *index, int64_t n_rows, int dim, const float *queries, int64_t n_queries, const int *cand_id,
                         const int *cand_cnt, const float *cand_s, const void *aux_dev, int cap, float *out_d2, int64_t *out_ids,
                         int *n_exact_scans, hipStream_t stream) {
-    const dim3 grid((unsigned)n_queries), block(256);
+    const dim3 grid((unsigned)n_queries), block(64 * KF_WAVES);
     const unsigned *xstats = (const unsigned *)((const char *)aux_dev + knn_aux(n_rows, dim).stats);
 #define RVC_FIN(JJ)                                                                                                        \
     hipLaunchKernelGGL(knn_finalize_kernel<JJ>, grid, block, 0, stream, index, n_rows, queries, cand_id, cand_cnt, cand_s, xstats, \
@@ -556,14 +752,20 @@ int knn_screened_search(const float *index, const void *aux_dev, int64_t n_rows,
     static std::once_flag lds_once;
     static hipError_t lds_err = hipSuccess;
     std::call_once(lds_once, [] {
-        lds_err = hipFuncSetAttribute((const void *)knn_screen_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KS_LDS_BYTES);
-        if (lds_err == hipSuccess)
-            lds_err = hipFuncSetAttribute((const void *)knn_screen_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KS_LDS_BYTES);
+        auto reserve = [](const void *fn, size_t bytes) {
+            if (lds_err == hipSuccess) lds_err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        };
+        reserve((const void *)knn_screen_glds_kernel<true>, ScreenTile<2, 64>::LDS_BYTES);
+        reserve((const void *)knn_screen_glds_kernel<false>, ScreenTile<2, 64>::LDS_BYTES);
+        reserve((const void *)knn_screen_kernel<true, 2, 64>, ScreenTile<2, 64>::LDS_BYTES);
+        reserve((const void *)knn_screen_kernel<false, 2, 64>, ScreenTile<2, 64>::LDS_BYTES);
+        reserve((const void *)knn_screen_kernel<true, 1, 32>, ScreenTile<1, 32>::LDS_BYTES);
+        reserve((const void *)knn_screen_kernel<false, 1, 32>, ScreenTile<1, 32>::LDS_BYTES);
     });
-    if (lds_err != hipSuccess) return fail("knn screen: cannot reserve %zu bytes of LDS: %s", KS_LDS_BYTES, hipGetErrorString(lds_err));
+    if (lds_err != hipSuccess) return fail("knn screen: cannot reserve LDS: %s", hipGetErrorString(lds_err));
 
     RVC_HIP(hipMemsetAsync(cnt, 0, (size_t)(n_queries + 1) * sizeof(int), stream));
-    RVC_HIP(hipMemsetD32Async((hipDeviceptr_t)mins, 0x7f800000, (size_t)n_queries * s.sample_tiles * KS_SLOTS_PER_TILE, stream));   // +inf
+    RVC_HIP(hipMemsetD32Async((hipDeviceptr_t)mins, 0x7f800000, (size_t)n_queries * s.sample_tiles * s.slots_per_tile, stream));   // +inf
     hipLaunchKernelGGL(knn_to_half_kernel, dim3((unsigned)ceil_div(n_queries, 4)), dim3(256), 0, stream, queries, n_queries, dim, qh,
                        (float *)nullptr, qstat, (unsigned *)nullptr);
     RVC_LAUNCH_CHECK();
@@ -574,11 +776,23 @@ int knn_screened_search(const float *index, const void *aux_dev, int64_t n_rows,
     p.n_rows = n_rows; p.dim = dim; p.qh = qh; p.n_queries = n_queries;
     p.n_qtiles = s.n_qtiles; p.n_tiles = s.n_tiles;
     p.thr = thr; p.cand_id = cand; p.cand_cnt = cnt; p.cap = s.cap;
-    p.mins = mins; p.n_slots = s.sample_tiles * KS_SLOTS_PER_TILE;
+    p.mins = mins; p.n_slots = s.sample_tiles * s.slots_per_tile;
     // sample pass: one tile per block, tiles sample_step apart
     p.n_stripes = s.sample_tiles; p.tiles_per_block = 1; p.tile_step = s.sample_step;
     unsigned blocks = (unsigned)(ceil_div(p.n_stripes, 8) * 8 * p.n_qtiles);
-    hipLaunchKernelGGL(knn_screen_kernel<false>, dim3(blocks), dim3(KS_THREADS), KS_LDS_BYTES, stream, p);
+    auto launch = [&](bool append, unsigned nblocks) {
+#define RVC_SCREEN(AP, W, K)                                                                                               \
+    hipLaunchKernelGGL((knn_screen_kernel<AP, W, K>), dim3(nblocks), dim3((ScreenTile<W, K>::THREADS)),                   \
+                       (ScreenTile<W, K>::LDS_BYTES), stream, p)
+        static const int glds_env = env_i("RVC_KNN_GLDS", 0);   // 1: the LDS-DMA staged variant (measured equal: 0.555 vs 0.545 ms)
+        if (s.wm == 2 && s.bk == 64 && glds_env) {
+            if (append) hipLaunchKernelGGL(knn_screen_glds_kernel<true>, dim3(nblocks), dim3(512), (ScreenTile<2, 64>::LDS_BYTES), stream, p);
+            else hipLaunchKernelGGL(knn_screen_glds_kernel<false>, dim3(nblocks), dim3(512), (ScreenTile<2, 64>::LDS_BYTES), stream, p);
+        } else if (s.wm == 2 && s.bk == 64) { if (append) RVC_SCREEN(true, 2, 64); else RVC_SCREEN(false, 2, 64); }
+        else { if (append) RVC_SCREEN(true, 1, 32); else RVC_SCREEN(false, 1, 32); }
+#undef RVC_SCREEN
+    };
+    launch(false, blocks);
     RVC_LAUNCH_CHECK();
     hipLaunchKernelGGL(knn_select_kernel, dim3((unsigned)ceil_div(n_queries, 4)), dim3(256), 0, stream, mins, p.n_slots, qstat,
                        (const unsigned *)(ab + aux.stats), n_queries, thr);
@@ -586,7 +800,7 @@ int knn_screened_search(const float *index, const void *aux_dev, int64_t n_rows,
     // main pass over every row
     p.n_stripes = s.n_stripes; p.tiles_per_block = s.tiles_per_block; p.tile_step = 1;
     blocks = (unsigned)(ceil_div(p.n_stripes, 8) * 8 * p.n_qtiles);
-    hipLaunchKernelGGL(knn_screen_kernel<true>, dim3(blocks), dim3(KS_THREADS), KS_LDS_BYTES, stream, p);
+    launch(true, blocks);
     RVC_LAUNCH_CHECK();
     return knn_finalize_launch(index, n_rows, dim, queries, n_queries, cand, cnt, nullptr, aux_dev, s.cap, out_d2, out_ids,
                                cnt + n_queries, stream);
