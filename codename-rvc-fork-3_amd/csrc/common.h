@@ -45,6 +45,12 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 __device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a release + acquire fence over ALL address spaces:
+// hipcc lowers it to s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier, which drains the global prefetch a pipelined loop has just
+// issued for a later chunk -- the loop then eats a full memory latency per chunk.  Use this one where the data exchanged
+// between the waves went through LDS (ds_write, or LDS-DMA already retired with an explicit vmcnt wait).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
 }  // namespace rvc

@@ -1,6 +1,8 @@
 // fp32 implicit-GEMM conv1d on the gfx950 matrix cores: shared by the decoder and the exported
 // rvc_conv1d_forward unit-test entry point.
 #pragma once
+#include <vector>
+
 #include "common.h"
 
 namespace rvc {
@@ -34,6 +36,8 @@ struct ConvParams {
     int up_stride = 0, up_pad = 0;
     float out_scale = 1.f;
     int batch = 1;
+    const float *w_wino = nullptr;   // the same taps in wino.hip's layout: launch_conv may take the fast (Winograd) form for
+                                     // plain 3 / 7 / 11-tap layers where it is the faster one
     int debug = 0;   // experiments only (RVC_CONV_DEBUG): 1 = skip x loads, 2 = skip y stores, 4 = skip res loads
 };
 
@@ -60,6 +64,15 @@ static inline uint16_t bf16_rne(float f) {
     if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
     return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
+
+// fast (Winograd F(4,3), grouped) form of the 3 / 7 / 11-tap dilated convs (wino.hip): y = out_scale * (conv(act(x)) + bias + res + accin)
+bool wino_supported(int k, int dil);
+bool wino_fits(int c_in, int c_out, int64_t L);
+int launch_wino_conv(const float *x, const float *u, const float *bias, const float *res, const float *accin, float *y, int batch,
+                     int c_in, int c_out, int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream);
+// regular conv weight [c_out][c_in][k] -> [3 ceil(k/3)][c_in / 2][c_out][2] (zero taps appended, channel pairs interleaved)
+void wino_pack_host(const float *w_host, int c_out, int c_in, int k, std::vector<float> *out);
+int wino_pack_weight(const float *w_host, int c_out, int c_in, int k, float **out_dev);
 
 // host-side repacks (return freshly hipMalloc'ed device buffers)
 // regular conv weight [c_out][c_in][k] -> [k][c_in][c_out]

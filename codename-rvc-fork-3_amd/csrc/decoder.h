@@ -42,6 +42,7 @@ struct DevBuf16 {
 struct ConvW {
     DevBuf w, b;
     DevBuf16 w16;                 // set instead of w when the handle stores its ResBlock weights as bf16
+    DevBuf wu;                    // square 3 / 7 / 11-tap layers: the taps again in wino.hip's layout
     int c_in = 0, c_out = 0, k = 0;
 };
 

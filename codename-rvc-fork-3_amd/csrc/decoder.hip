@@ -381,6 +381,10 @@ int build_conv(const rvc_decoder *d, const std::string &prefix, int c_out, int c
     } else if (out->w.upload(packed)) {
         return 1;
     }
+    if (!as_bf16 && c_in == c_out && c_out % 32 == 0 && wino_supported(k, 1)) {   // ResBlock layers: second copy for the fast form
+        wino_pack_host(w->data.data(), c_out, c_in, k, &packed);
+        if (out->wu.upload(packed)) return 1;
+    }
     if (bias) {
         if (need(d, prefix + ".bias", &b, {c_out})) return 1;
         if (out->b.upload(b->data)) return 1;
@@ -728,13 +732,13 @@ extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const flo
                 const int dil = c.res_dilations[j];
                 ConvParams p;
                 p.x1 = xin; p.c1 = s.c_out; p.slope1 = 0.1f; p.x1_bstride = bs; p.l_in = len;
-                p.w = s.c1[m * nd + j].w.p; p.w16 = s.c1[m * nd + j].w16.p; p.bias = s.c1[m * nd + j].b.p;
+                p.w = s.c1[m * nd + j].w.p; p.w16 = s.c1[m * nd + j].w16.p; p.bias = s.c1[m * nd + j].b.p; p.w_wino = s.c1[m * nd + j].wu.p;
                 p.y = T1; p.y_bstride = bs; p.m_total = s.c_out; p.c_out = s.c_out; p.n_cols = len; p.l_out = len;
                 p.kw = k; p.dil = dil; p.padl = (k - 1) / 2 * dil; p.batch = batch;
                 if (launch_conv(p, stream)) return 1;
                 ConvParams q;
                 q.x1 = T1; q.c1 = s.c_out; q.slope1 = 0.1f; q.x1_bstride = bs; q.l_in = len;
-                q.w = s.c2[m * nd + j].w.p; q.w16 = s.c2[m * nd + j].w16.p; q.bias = s.c2[m * nd + j].b.p;
+                q.w = s.c2[m * nd + j].w.p; q.w16 = s.c2[m * nd + j].w16.p; q.bias = s.c2[m * nd + j].b.p; q.w_wino = s.c2[m * nd + j].wu.p;
                 q.res = xin;
                 q.y_bstride = bs; q.m_total = s.c_out; q.c_out = s.c_out; q.n_cols = len; q.l_out = len;
                 q.kw = k; q.dil = 1; q.padl = (k - 1) / 2; q.batch = batch;

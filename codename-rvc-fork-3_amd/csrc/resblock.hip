@@ -160,7 +160,7 @@ resblock_layer_kernel(const float *__restrict__ x, const float *__restrict__ w1,
             if (c + 1 < NCH) {
                 store_w(buf ^ 1);
                 if (c + 2 < NCH) load_w(w, c + 2);
-                __syncthreads();
+                lds_barrier();   // slab c + 2's loads stay in flight (conv.hip)
             }
         }
     };

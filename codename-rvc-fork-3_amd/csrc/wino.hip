@@ -1,0 +1,452 @@
+// K3w -- the ResBlock convolutions as a fast (Winograd / Toom-Cook) convolution on the fp32 matrix cores.
+//
+// 98 % of the vocoder's 3.5 TFLOP per utterance are 3-, 7- and 11-tap dilated conv1d layers (residuals.py:75-86).  The
+// direct implicit GEMM (conv.hip) is within ~20 % of the fp32 MFMA peak on them, so the remaining lever is arithmetic:
+// F(4,3) computes 4 outputs of a 3-tap correlation with 6 multiplications instead of 12, and a K-tap kernel is the sum of
+// G = ceil(K / 3) three-tap kernels applied to shifted inputs:
+//
+//   y[t0 + i d] = sum_g sum_kk w[3g + kk] x[t0 + (i + 3g + kk - c) d]            c = (K - 1) / 2, i = 0..3, dilation d
+//               = sum_p AT[i][p] * sum_g sum_ci U[p][g][ci][co] * X[p][g][ci][tile]
+//   U[p][g]  = G3 w[3g .. 3g + 2]                (6 x 3 transform of the taps, per lane at fragment-load time)
+//   X[p][g]  = BT (x[t0 + (n + 3g - c) d])_{n = 0..5}   (6 x 6 transform of the input window, at fragment-load time)
+//
+// The sum over groups commutes with the output transform, so each of the 6 transform points is ONE GEMM with
+// K = G * C_in: 6 G multiply-adds per 4 outputs per (c_in, c_out) instead of 4 K -- 2.0x / 1.56x / 1.83x fewer for
+// K = 3 / 7 / 11, 1.75x over a ResBlock.  Everything stays fp32; the transforms have small integer / dyadic entries
+// (|BT| <= 5, |AT| <= 8) and the measured error of one layer is 4-7e-7 relative RMS against float64 (the direct fp32 form:
+// 1.4-2.4e-7), three orders below the 1e-3 waveform gate.
+//
+// A dilated conv touches every d-th sample, so a tile is 4 outputs d apart: time t = sb * 4d + i * d + phi (super-block sb,
+// i = 0..3, phase phi < d) belongs to tile tau = sb * d + phi, output i.  In LDS the input chunk is stored de-interleaved,
+// X[ci / 2][i][tau][ci % 2], so that the 32 lanes of an MFMA "B" operand (consecutive tiles) read consecutive addresses
+// whatever d is.
+//
+// Block = 4 waves (2 x 2: 64 channels x 64 tiles), two blocks per CU; wave (wm, wn) owns 32 output channels x 32 tiles
+// (128 outputs) and keeps one accumulator per transform point (6 x 16 registers).  K is walked in chunks of CIC input
+// channels, double-buffered in LDS, one barrier per chunk.  The epilogue applies AT, bias, residual, running sum and scale
+// like conv.hip's.  What shaped the loop is written at the kernel.
+#include <stdlib.h>
+
+#include <mutex>
+#include <vector>
+
+#include "conv.h"
+
+namespace rvc {
+
+struct WinoParams {
+    const float *x = nullptr;        // [batch][c_in][L]
+    const float *u = nullptr;        // [3 G][c_in / 2][c_out][2]: the taps (zero-padded to a multiple of three), channel pairs interleaved
+    const float *bias = nullptr;     // [c_out]
+    const float *res = nullptr;      // [batch][c_out][L] or null
+    const float *accin = nullptr;    // [batch][c_out][L] or null
+    float *y = nullptr;              // [batch][c_out][L]
+    int c_in = 0, c_out = 0;
+    int64_t L = 0;
+    int dil = 1;
+    int sb_per_block = 0;            // super-blocks (of d tiles) per block
+    int64_t n_sb = 0;                // super-blocks in the sequence: ceil(L / 4d)
+    float slope = 1.f, out_scale = 1.f;
+    int batch = 1;
+};
+
+constexpr int WINO_MAX_DIL = 5;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef const void __attribute__((address_space(1))) *wino_gptr_t;
+typedef void __attribute__((address_space(3))) *wino_lptr_t;
+
+__device__ __forceinline__ f32x2 fma2(float a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(f32x2{a, a}, b, c); }
+// leaky ReLU for 0 <= slope <= 1 as max(v, slope * v): one packed multiply + two v_max (fmaxf would add a canonicalising
+// v_max per operand; NaN in gives NaN out either way)
+__device__ __forceinline__ f32x2 lrelu2(f32x2 v, float slope) {
+    const f32x2 sv = v * slope;
+    float a, b;
+    asm("v_max_f32 %0, %1, %2" : "=v"(a) : "v"(v.x), "v"(sv.x));
+    asm("v_max_f32 %0, %1, %2" : "=v"(b) : "v"(v.y), "v"(sv.y));
+    return f32x2{a, b};
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
+}
+constexpr int WINO_RSRC_FLAGS = 0x00020000;   // raw buffer, 32-bit data format
+
+// KW taps; WM x WN waves (each 32 channels x 32 tiles); CIC input channels per chunk.
+//
+// The fp32 matrix instruction runs on the SIMD's own fp32 lanes: measured, matrix-busy + VALU-busy add up to ~1 on this
+// kernel and on conv.hip's, and every ablation of non-matrix work (transforms, staging, index arithmetic) came off the
+// run time one for one (tools/ablate_wino.sh).  So the loop is written for the FEWEST vector instructions, not for overlap:
+//   * two k-steps are transformed at once in packed fp32 (v_pk_fma / v_pk_add): LDS holds channel PAIRS interleaved, one
+//     ds_read_b64 brings the operands of k-steps 2P and 2P + 1 and the 18 packed operations of the two transforms serve 12
+//     matrix instructions (the scalar version: 48);
+//   * the transforms carry no scale factors -- the rows of G are scaled by (1/4, -1/6, -1/6, 1/24, 1/24, 1) in the
+//     epilogue instead, once per accumulator;
+//   * the weight taps go HBM/L2 -> LDS by LDS-DMA (global_load_lds, 16 B per lane): no registers, no vector instructions;
+//   * the input rows are staged with two fixed per-thread offsets (one division set per block, not per element) and only
+//     the first / last block of a row masks for the conv's zero padding.
+template <int KW, int WM, int WN, int CIC, int DBG = 0>
+__global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2)))
+wino_conv_kernel(const WinoParams p) {
+    constexpr int G = (KW + 2) / 3;
+    constexpr int C0 = (KW - 1) / 2;
+    constexpr int BM = 32 * WM;
+    constexpr int BNT = 32 * WN;                         // tile columns per block
+    constexpr int NW = WM * WN;
+    constexpr int NTH = 64 * NW;
+    constexpr int CP = CIC / 2;                          // channel pairs per chunk
+    static_assert(CIC % 4 == 0, "k-steps are processed in pairs of channel pairs");
+    // window offsets (n + 3g - c) / 4 range over [MLO, MHI] super-block steps
+    constexpr int SMIN = -C0, SMAX = 5 + 3 * (G - 1) - C0;
+    constexpr int MLO = SMIN >= 0 ? SMIN / 4 : -((-SMIN + 3) / 4);
+    constexpr int MHI = SMAX / 4;
+    constexpr int XT = BNT + (MHI - MLO) * WINO_MAX_DIL;  // staged tiles per row (enough for d <= 5)
+    constexpr int XTS = ((XT + 31) / 32) * 32 + 8;        // row stride in float2: == 8 mod 32, the 4 de-interleaved rows of a ds_write_b64 land in 4 bank groups
+    constexpr int XTOT = CP * 4 * XTS;                    // float2 per input buffer
+    constexpr int UROWS = 3 * G * CP;                     // weight rows of BM float2
+    constexpr int UTOT = UROWS * BM;                      // float2 per weight buffer
+    constexpr int UINSTR = UTOT * 8 / 1024;               // LDS-DMA wave-instructions (1 KiB each) per chunk
+    static_assert((UTOT * 8) % 1024 == 0, "weight chunk is a whole number of DMA pieces");
+    constexpr int UPW = (UINSTR + NW - 1) / NW;           // per wave
+    constexpr int NJ = (4 * XT + NTH - 1) / NTH;          // staged samples per thread per channel
+
+    extern __shared__ __attribute__((aligned(16))) float wino_smem[];
+    f32x2 *us = reinterpret_cast<f32x2 *>(wino_smem);     // [2][UTOT]
+    f32x2 *xs = us + 2 * UTOT;                            // [2][XTOT]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z;
+    const int m0 = blockIdx.y * BM;
+    const int d = p.dil;
+    const int64_t sb0 = (int64_t)blockIdx.x * p.sb_per_block;     // first super-block of this block
+    const int n_tiles_blk = p.sb_per_block * d;                     // valid tile columns (<= BNT)
+    const int64_t L = p.L;
+    const float *const px = p.x + (int64_t)b * p.c_in * L;
+    const int c_in = p.c_in, c_out = p.c_out;
+    const float slope = p.slope;
+    const int n_chunks = c_in / CIC;
+    // staged time range: super-blocks [sb0 + MLO, sb0 + sb_per_block + MHI), i.e. xt_used tiles
+    const int xt_used = (p.sb_per_block + MHI - MLO) * d;
+    const int64_t t_start = (sb0 + MLO) * 4 * d;
+    const int span = 4 * xt_used;                                   // samples per input row in the staged range
+    const bool edge = t_start < 0 || t_start + span > L;            // block-uniform: some staged samples are conv padding
+
+    // ---- staging plan, once per block ----------------------------------------------------------------------------
+    // Both streams use buffer instructions: a scalar row / chunk offset plus a per-lane 32-bit offset fixed for the whole
+    // block, so staging costs no address arithmetic on the vector pipe.
+    __builtin_assume(wave >= 0 && wave < NW);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)px, 0, (int)((int64_t)c_in * L * 4), WINO_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t urs =
+        __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, (int)((int64_t)3 * G * c_in * c_out * 4), WINO_RSRC_FLAGS);
+    const int L4 = (int)(L * 4);
+    unsigned goff[NJ];    // byte offset of the sample inside a channel row (clamped into [0, L))
+    int loff[NJ];         // float2 offset inside a channel pair's 4 rows: ii * XTS + tile (lanes with nothing to stage: a pad column)
+    unsigned inb = 0;     // bit j: the sample lies inside [0, L)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int tl = tid + j * NTH;
+        const bool have = tl < span;
+        const int tlc = have ? tl : 0;
+        const int64_t t = t_start + tlc;
+        const int64_t tc = t < 0 ? 0 : (t >= L ? L - 1 : t);
+        goff[j] = (unsigned)tc * 4u;
+        // t_start is a multiple of 4d: tl = sbl * 4d + ii * d + phi  ->  row ii, tile sbl * d + phi
+        const int sbl = tlc / (4 * d);
+        const int r = tlc - sbl * 4 * d;
+        const int ii = r / d;
+        const int phi = r - ii * d;
+        loff[j] = have ? ii * XTS + sbl * d + phi : XT + (lane & 7);   // columns >= XT of a row are never read
+        if (t >= 0 && t < L) inb |= 1u << j;
+    }
+    unsigned woff[UPW];   // byte offset of this lane's 16 bytes of DMA piece (wave + NW * i) from the chunk's weight base
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) {
+        const int o = (wave + NW * i) * 1024 + 16 * lane;
+        const int row = o / (BM * 8), within = o - row * (BM * 8);
+        const int tap = row / CP, cp = row - tap * CP;
+        woff[i] = (unsigned)(((tap * (c_in / 2) + cp) * c_out) * 8 + within);
+    }
+
+    f32x2 xr[CP * NJ];
+    auto load_x = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int cp = 0; cp < CP; ++cp) {
+            const int s0 = (c * CIC + 2 * cp) * L4;       // wave-uniform byte offset of the pair's first row
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) xr[cp * NJ + j] = f32x2{buf_load(xrs, goff[j], s0), buf_load(xrs, goff[j], s0 + L4)};
+        }
+    };
+    auto store_x = [&](int buf) __attribute__((always_inline)) {
+        f32x2 *dst = xs + buf * XTOT;
+        if (edge) {   // first / last blocks of a row: staged samples outside [0, L) are the conv's zero padding
+#pragma unroll
+            for (int cp = 0; cp < CP; ++cp)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const f32x2 v = lrelu2(xr[cp * NJ + j], slope);
+                    dst[cp * 4 * XTS + loff[j]] = ((inb >> j) & 1) ? v : f32x2{0.f, 0.f};
+                }
+        } else {
+#pragma unroll
+            for (int cp = 0; cp < CP; ++cp)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) dst[cp * 4 * XTS + loff[j]] = lrelu2(xr[cp * NJ + j], slope);
+        }
+    };
+    auto dma_u = [&](int buf, int c) __attribute__((always_inline)) {
+        const int s0 = (c * CP * c_out + m0) * 8;         // byte offset of the chunk's first weight row, this block's channels
+        char *dst = reinterpret_cast<char *>(us + buf * UTOT);
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const int n = wave + NW * i;
+            if (n < UINSTR) __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, (wino_lptr_t)(dst + n * 1024), 16, (int)woff[i], s0, 0, 0);
+        }
+    };
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    load_x(0);
+    dma_u(0, 0);
+    store_x(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (n_chunks > 1) load_x(1);
+    lds_barrier();
+    const int col = wn * 32 + l31;                       // this lane's tile column inside the block
+    for (int c = 0; c < n_chunks; ++c) {
+        const int buf = c & 1;
+        // buffer buf ^ 1 was last read in iteration c - 1 and every wave has passed that iteration's barrier
+        if (!(DBG & 4) && c + 1 < n_chunks) dma_u(buf ^ 1, c + 1);
+        const f32x2 *ua = us + buf * UTOT + wm * 32 + l31;
+        const f32x2 *xb = xs + buf * XTOT + col - MLO * d;
+        // software pipeline over the S = G * CIC / 4 double k-steps: the 6 input pairs and 3 tap pairs of step s + 1 are
+        // read from LDS before the transforms + 12 matrix instructions of step s are issued
+        constexpr int S = G * (CIC / 4);
+        f32x2 dv[2][6], wv[2][3];
+        auto fetch = [&](int st, f32x2 (&dd)[6], f32x2 (&ww)[3]) __attribute__((always_inline)) {
+            const int g = st / (CIC / 4), P = st - g * (CIC / 4);
+            const int cpi = 2 * P + half;               // this lane's channel pair: k-step 2P takes .x, k-step 2P + 1 takes .y
+#pragma unroll
+            for (int n = 0; n < 6; ++n) {
+                const int sh = n + 3 * g - C0;           // window offset in units of d
+                dd[n] = xb[(cpi * 4 + (sh & 3)) * XTS + (sh >> 2) * d];
+            }
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) ww[kt] = ua[((3 * g + kt) * CP + cpi) * BM];
+        };
+        fetch(0, dv[0], wv[0]);
+#pragma unroll
+        for (int st = 0; st < S; ++st) {
+            if (st + 1 < S) fetch(st + 1, dv[(st + 1) & 1], wv[(st + 1) & 1]);   // reads only: nothing here depends on them yet
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x2(&dq)[6] = dv[st & 1];
+            const f32x2 w0 = wv[st & 1][0], w1 = wv[st & 1][1], w2 = wv[st & 1][2];
+            f32x2 aq[6], xq[6];
+            if (DBG & 1) {
+                aq[0] = w0; aq[1] = w1; aq[2] = w2; aq[3] = w0; aq[4] = w1; aq[5] = w2;
+            } else {   // rows of G3 without their scale factors (applied in the epilogue)
+                const f32x2 ts = w0 + w2, tv = fma2(4.f, w2, w0);
+                aq[0] = w0;
+                aq[1] = ts + w1;
+                aq[2] = ts - w1;
+                aq[3] = fma2(2.f, w1, tv);
+                aq[4] = fma2(-2.f, w1, tv);
+                aq[5] = w2;
+            }
+            if (DBG & 2) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) xq[q] = dq[q];
+            } else {   // BT d
+                xq[0] = fma2(4.f, dq[0], fma2(-5.f, dq[2], dq[4]));
+                const f32x2 t1 = fma2(-4.f, dq[2], dq[4]);
+                const f32x2 t2 = fma2(-4.f, dq[1], dq[3]);
+                xq[1] = t1 + t2;
+                xq[2] = t1 - t2;
+                const f32x2 t3 = dq[4] - dq[2];
+                const f32x2 t4 = dq[3] - dq[1];
+                xq[3] = fma2(2.f, t4, t3);
+                xq[4] = fma2(-2.f, t4, t3);
+                xq[5] = fma2(4.f, dq[1], fma2(-5.f, dq[3], dq[5]));
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) acc[q] = mfma32(aq[q].x, xq[q].x, acc[q]);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) acc[q] = mfma32(aq[q].y, xq[q].y, acc[q]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c + 1 < n_chunks) {
+            if (!(DBG & 4)) {
+                store_x(buf ^ 1);                                   // chunk c + 1's rows, loaded a whole chunk ago
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's DMA pieces of chunk c + 1 have landed
+                if (c + 2 < n_chunks) load_x(c + 2);
+            }
+            if (!(DBG & 8)) lds_barrier();   // chunk c + 2's rows stay in flight across it
+        }
+    }
+
+    // ---- epilogue: y_i = AT diag(s) D, + bias, + residual, + running sum, * scale ----------------------------------
+    const bool col_ok = col < n_tiles_blk;
+    const int sbl = col / d;
+    const int phi = col - sbl * d;
+    const int64_t t0 = (sb0 + sbl) * 4 * d + phi;
+    const float *bias = p.bias;
+    const float *res = p.res ? p.res + (int64_t)b * c_out * L : nullptr;
+    const float *accin = p.accin ? p.accin + (int64_t)b * c_out * L : nullptr;
+    float *y = p.y + (int64_t)b * c_out * L;
+    const float out_scale = p.out_scale;
+    const int row0 = m0 + wm * 32 + 4 * half;
+    const bool vec = d == 1 && (L & 3) == 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = row0 + (r & 3) + 8 * (r >> 2);
+        const float bv = bias ? bias[co] : 0.f;
+        const float d0 = acc[0][r], d1 = acc[1][r], d2 = acc[2][r], d3 = acc[3][r], d4 = acc[4][r], d5 = acc[5][r];
+        const float s12 = (d1 + d2) * (-1.f / 6.f), m12 = (d1 - d2) * (-1.f / 6.f), s34 = (d3 + d4) * (1.f / 24.f), m34 = (d3 - d4) * (1.f / 24.f);
+        float o[4];
+        o[0] = fmaf(0.25f, d0, s12 + s34) + bv;
+        o[1] = fmaf(2.f, m34, m12) + bv;
+        o[2] = fmaf(4.f, s34, s12) + bv;
+        o[3] = fmaf(8.f, m34, m12) + d5 + bv;
+        if (!col_ok) continue;
+        if ((DBG & 32) && o[0] + o[1] + o[2] + o[3] != 12345.678f) continue;
+        const int64_t base = (int64_t)co * L + t0;
+        if (vec && t0 + 3 < L) {
+            f32x4 ov = {o[0], o[1], o[2], o[3]};
+            if (res) ov += *reinterpret_cast<const f32x4 *>(res + base);
+            if (accin) ov += *reinterpret_cast<const f32x4 *>(accin + base);
+            *reinterpret_cast<f32x4 *>(y + base) = ov * out_scale;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t t = t0 + (int64_t)i * d;
+                if (t < L) {
+                    float v = o[i];
+                    if (res) v += res[base + (int64_t)i * d];
+                    if (accin) v += accin[base + (int64_t)i * d];
+                    y[base + (int64_t)i * d] = v * out_scale;
+                }
+            }
+        }
+    }
+}
+
+template <int KW, int WM, int WN, int CIC>
+static size_t wino_lds_bytes() {
+    constexpr int G = (KW + 2) / 3, C0 = (KW - 1) / 2;
+    constexpr int SMIN = -C0, SMAX = 5 + 3 * (G - 1) - C0;
+    constexpr int MLO = SMIN >= 0 ? SMIN / 4 : -((-SMIN + 3) / 4), MHI = SMAX / 4;
+    constexpr int XT = 32 * WN + (MHI - MLO) * WINO_MAX_DIL;
+    constexpr int XTS = ((XT + 31) / 32) * 32 + 8;
+    return (size_t)2 * (3 * G * (CIC / 2) * 32 * WM + (CIC / 2) * 4 * XTS) * 2 * sizeof(float);
+}
+
+template <int KW, int WM, int WN, int CIC, int DBG = 0>
+static int wino_launch_cfg(WinoParams p, hipStream_t stream) {
+    constexpr int BNT = 32 * WN;
+    p.sb_per_block = BNT / p.dil;
+    p.n_sb = ceil_div(p.L, (int64_t)4 * p.dil);
+    const size_t lds = wino_lds_bytes<KW, WM, WN, CIC>();
+    static std::once_flag once;
+    static hipError_t err = hipSuccess;
+    std::call_once(once, [lds] {
+        err = hipFuncSetAttribute((const void *)wino_conv_kernel<KW, WM, WN, CIC, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    if (err != hipSuccess) return fail("wino conv: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(err));
+    dim3 grid((unsigned)ceil_div(p.n_sb, p.sb_per_block), (unsigned)(p.c_out / (32 * WM)), (unsigned)p.batch);
+    hipLaunchKernelGGL((wino_conv_kernel<KW, WM, WN, CIC, DBG>), grid, dim3(64 * WM * WN), lds, stream, p);
+    RVC_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int KW>
+static int wino_launch_kw(const WinoParams &p, hipStream_t stream) {
+    constexpr int CIC = 8;
+    if (p.c_in % CIC) return fail("wino conv: c_in %d is not a multiple of %d", p.c_in, CIC);
+    if (KW == 11 && p.c_out % 64 == 0) {   // ablations (wrong results): where does the time go (tools/ablate_wino.sh)
+        static const int dbg = getenv("RVC_WINO_DBG") ? atoi(getenv("RVC_WINO_DBG")) : 0;
+        switch (dbg) {
+            case 1: return wino_launch_cfg<11, 2, 2, 8, 1>(p, stream);
+            case 2: return wino_launch_cfg<11, 2, 2, 8, 2>(p, stream);
+            case 3: return wino_launch_cfg<11, 2, 2, 8, 3>(p, stream);
+            case 7: return wino_launch_cfg<11, 2, 2, 8, 7>(p, stream);
+            case 15: return wino_launch_cfg<11, 2, 2, 8, 15>(p, stream);
+            case 32: return wino_launch_cfg<11, 2, 2, 8, 32>(p, stream);
+            case 47: return wino_launch_cfg<11, 2, 2, 8, 47>(p, stream);
+            default: break;
+        }
+    }
+    if (p.c_out % 64 == 0) return wino_launch_cfg<KW, 2, 2, CIC>(p, stream);
+    if (p.c_out % 32 == 0) return wino_launch_cfg<KW, 1, 4, CIC>(p, stream);
+    return fail("wino conv: c_out %d is not a multiple of 32", p.c_out);
+}
+
+// the staging streams address one batch item's input and the weight slab with 32-bit byte offsets
+bool wino_fits(int c_in, int c_out, int64_t L) { return (int64_t)c_in * L < ((int64_t)1 << 29) && (int64_t)12 * c_in * c_out < ((int64_t)1 << 29); }
+
+bool wino_supported(int k, int dil) { return (k == 3 || k == 7 || k == 11) && dil >= 1 && dil <= WINO_MAX_DIL; }
+
+int launch_wino_conv(const float *x, const float *u, const float *bias, const float *res, const float *accin, float *y, int batch,
+                     int c_in, int c_out, int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream) {
+    if (!wino_supported(k, dil)) return fail("wino conv: unsupported kernel size %d / dilation %d", k, dil);
+    if (!(slope >= 0.f && slope <= 1.f)) return fail("wino conv: leaky slope %g outside [0, 1]", (double)slope);
+    if (c_in % 8 || c_out % 32) return fail("wino conv: %d -> %d channels unsupported (multiples of 8 / 32)", c_in, c_out);
+    if (!wino_fits(c_in, c_out, L)) return fail("wino conv: %d x %lld samples exceed the 2 GiB buffer addressing of the fast form", c_in, (long long)L);
+    if (L <= 0 || batch <= 0) return 0;
+    WinoParams p;
+    p.x = x; p.u = u; p.bias = bias; p.res = res; p.accin = accin; p.y = y;
+    p.c_in = c_in; p.c_out = c_out; p.L = L; p.dil = dil; p.slope = slope; p.out_scale = out_scale; p.batch = batch;
+    switch (k) {
+        case 3: return wino_launch_kw<3>(p, stream);
+        case 7: return wino_launch_kw<7>(p, stream);
+        default: return wino_launch_kw<11>(p, stream);
+    }
+}
+
+// w_host [c_out][c_in][k] -> [3 G][c_in / 2][c_out][2] (taps zero-padded to a multiple of three, channel pairs interleaved)
+void wino_pack_host(const float *w_host, int c_out, int c_in, int k, std::vector<float> *out) {
+    const int G = (k + 2) / 3;
+    out->assign((size_t)3 * G * c_in * c_out, 0.f);
+    for (int tap = 0; tap < k; ++tap)
+        for (int ci = 0; ci < c_in; ++ci)
+            for (int co = 0; co < c_out; ++co)
+                (*out)[(((size_t)tap * (c_in / 2) + ci / 2) * c_out + co) * 2 + (ci & 1)] = w_host[((size_t)co * c_in + ci) * k + tap];
+}
+
+int wino_pack_weight(const float *w_host, int c_out, int c_in, int k, float **out_dev) {
+    if (c_in % 2) return fail("wino_pack_weight: odd c_in %d", c_in);
+    std::vector<float> u;
+    wino_pack_host(w_host, c_out, c_in, k, &u);
+    hipError_t e = hipMalloc((void **)out_dev, u.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(*out_dev, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail("wino_pack_weight: %s", hipGetErrorString(e));
+    return 0;
+}
+
+}  // namespace rvc
+
+using namespace rvc;
+
+extern "C" int rvc_conv1d_wino_pack_weight(const float *w_host, int c_out, int c_in, int k, float *u_dev, void *stream) {
+    if (!w_host || !u_dev || c_out <= 0 || c_in <= 0 || !(k == 3 || k == 7 || k == 11)) return fail("rvc_conv1d_wino_pack_weight: bad argument");
+    float *tmp = nullptr;
+    if (wino_pack_weight(w_host, c_out, c_in, k, &tmp)) return 1;
+    const size_t bytes = (size_t)3 * ((k + 2) / 3) * c_in * c_out * sizeof(float);
+    hipError_t e = hipMemcpyAsync(u_dev, tmp, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail("rvc_conv1d_wino_pack_weight: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int rvc_conv1d_wino_forward(const float *x_dev, const float *u_dev, const float *bias_dev, const float *res_dev,
+                                       const float *acc_dev, float *y_dev, int batch, int c_in, int c_out, int64_t length, int k,
+                                       int dilation, float slope_in, float out_scale, void *stream) {
+    if (!x_dev || !u_dev || !y_dev) return fail("rvc_conv1d_wino_forward: null pointer");
+    return launch_wino_conv(x_dev, u_dev, bias_dev, res_dev, acc_dev, y_dev, batch, c_in, c_out, length, k, dilation, slope_in,
+                            out_scale, (hipStream_t)stream);
+}

@@ -90,6 +90,40 @@ def _reflect_pad(x: torch.Tensor, pad: int) -> torch.Tensor:
     return x[torch.where(m < n, m, period - m)]
 
 
+class _PinnedIO:
+    """Page-locked staging buffers for the host boundary of ``Pipeline.pipeline`` (NumPy in, NumPy out, pipeline.py:509-528),
+    one pair per HIP stream (utterances in flight on different streams must not share them), grow-only.  The upload is an
+    asynchronous copy on the utterance's own stream; the download is one copy + one stream synchronise."""
+
+    def __init__(self):
+        self._buf = {}
+        self._lock = threading.Lock()
+
+    def _get(self, kind, n, dtype):
+        key = (kind, torch.cuda.current_stream().cuda_stream)
+        with self._lock:
+            b = self._buf.get(key)
+            if b is None or b.numel() < n or b.dtype != dtype:
+                b = torch.empty(max(n, 1 << 16), dtype=dtype, pin_memory=True)
+                self._buf[key] = b
+        return b
+
+    def upload(self, audio: np.ndarray, device) -> torch.Tensor:
+        stage = self._get("in", audio.shape[0], torch.float64)[:audio.shape[0]]
+        # the previous upload from this buffer ran on this same stream and has long completed (its utterance was downloaded)
+        stage.numpy()[:] = audio
+        return stage.to(device, non_blocking=True)
+
+    def download(self, out: torch.Tensor) -> np.ndarray:
+        stage = self._get("out", out.shape[0], out.dtype)[:out.shape[0]]
+        stage.copy_(out, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return stage.numpy().copy()
+
+
+_pinned = _PinnedIO()
+
+
 class FeatureIndex:
     """Device-resident replacement of the faiss index + ``big_npy`` pair (pipeline.py:553-556).
 
@@ -337,7 +371,8 @@ class Pipeline:
         if as_tensor:
             audio = audio.to(device=self.device, dtype=torch.float64)
         else:
-            audio = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float64)).to(self.device)
+            with torch.cuda.device(self.device):
+                audio = _pinned.upload(np.ascontiguousarray(audio, dtype=np.float64), self.device)
         if audio.shape[0] + self.window > self.t_max:
             # long inputs are cut at arg-min positions of a 160-tap box sum of the filtered signal (below); this
             # direct-form high-pass amplifies 1-ulp differences to ~2e-8, enough to move such an arg-min, so the split
@@ -433,4 +468,7 @@ class Pipeline:
             out = AudioProcessor.change_rms(audio, self.sample_rate, out, self.sample_rate, volume_envelope)
         audio_max = out.abs().max() / 0.99  # pipeline.py:686-688
         out = torch.where(audio_max > 1, out / audio_max, out)
-        return out if as_tensor else out.cpu().numpy()
+        if as_tensor:
+            return out
+        with torch.cuda.device(self.device):
+            return _pinned.download(out.contiguous())

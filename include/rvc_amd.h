@@ -296,6 +296,17 @@ int rvc_index_broadcast(rvc_comm *comm, void *buf_dev, size_t bytes, int root, v
  * (a trailing 1-3 bytes are zero-extended into a last word).  Computed in HBM: the index never crosses PCIe. */
 int rvc_checksum64(const void *buf_dev, size_t bytes, uint64_t *out2_dev, void *stream);
 
+/* ---- the same conv in its fast form (unit-test entry of what the decoder uses for its ResBlock layers) ---------------- *
+ * Winograd / Toom-Cook F(4,3) over groups of three taps: identical mathematics, 1.5 G multiply-adds per output instead
+ * of K (G = ceil(K / 3)); fp32 throughout, one layer agrees with float64 to ~5e-7 relative RMS (direct fp32 form: ~2e-7).
+ * K in {3, 7, 11}, dilation 1..5, C_in a multiple of 8, C_out a multiple of 32, leaky slope in [0, 1], C_in * L < 2^29.
+ * u_dev: 3 G * C_in * C_out floats laid out [3 G][C_in / 2][C_out][2] (the taps, zero-padded to a multiple of three, input
+ * channel pairs interleaved) filled by rvc_conv1d_wino_pack_weight from the [C_out][C_in][K] host weights. */
+int rvc_conv1d_wino_pack_weight(const float *w_host, int c_out, int c_in, int k, float *u_dev, void *stream);
+int rvc_conv1d_wino_forward(const float *x_dev, const float *u_dev, const float *bias_dev, const float *res_dev,
+                            const float *acc_dev, float *y_dev, int batch, int c_in, int c_out, int64_t length, int k,
+                            int dilation, float slope_in, float out_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

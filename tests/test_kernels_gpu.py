@@ -51,6 +51,34 @@ def test_conv1d_matches_torch_fp32(native, dev, c_in, c_out, k, dil, length, bat
     assert (y2.cpu().double() - ref2).abs().max().item() <= 2e-5
 
 
+@pytest.mark.parametrize("c_in,c_out,k,dil,length,batch", [
+    (32, 32, 3, 1, 1000, 1), (32, 32, 11, 5, 1537, 2), (64, 64, 7, 3, 700, 1), (128, 128, 11, 5, 513, 1), (128, 128, 11, 1, 4096, 1),
+    (256, 256, 3, 3, 300, 2), (64, 64, 3, 5, 31, 1), (128, 128, 7, 1, 4097, 1), (256, 256, 11, 3, 2051, 1), (32, 32, 7, 5, 9999, 1),
+    (64, 128, 3, 1, 777, 1), (128, 64, 11, 1, 1234, 2),
+])
+def test_conv1d_winograd_matches_float64(native, dev, c_in, c_out, k, dil, length, batch):
+    """The fast form of the ResBlock convs (wino.hip: grouped F(4,3), residuals.py:75-86 layers) against F.conv1d in
+    float64, with the fused input activation, bias, residual, running sum and scale; lengths that are not multiples of a
+    tile (4 d), every dilation, the 32-channel (1 x 4 waves) and 64+-channel (2 x 2) block shapes."""
+    g = torch.Generator().manual_seed(c_in * 1000 + k * 10 + dil)
+    x = torch.randn(batch, c_in, length, generator=g)
+    w = torch.randn(c_out, c_in, k, generator=g) / (c_in * k) ** 0.5
+    b = torch.randn(c_out, generator=g)
+    res = torch.randn(batch, c_out, length, generator=g)
+    acc = torch.randn(batch, c_out, length, generator=g)
+    ref = (F.conv1d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), padding=(k - 1) // 2 * dil, dilation=dil) + res.double()
+           + acc.double()) / 3
+    u = native.conv1d_wino_pack_weight(w, dev)
+    got = native.conv1d_wino_forward(x.to(dev), u, b.to(dev), c_out, k, dil, 0.1, res=res.to(dev), acc=acc.to(dev), out_scale=1 / 3).cpu()
+    err = (got.double() - ref).abs().max().item()
+    assert err <= 6e-5, err                         # |y| ~ 1, up to 2816 terms: a few fp32 ulps through the transforms
+    plain = native.conv1d_wino_forward(x.to(dev), u, None, c_out, k, dil, 1.0).cpu()
+    ref2 = F.conv1d(x.double(), w.double(), None, padding=(k - 1) // 2 * dil, dilation=dil)
+    assert (plain.double() - ref2).abs().max().item() <= 6e-5
+    direct = native.conv1d_forward(x.to(dev), native.conv1d_pack_weight(w, dev), None, c_out, k, dil, 1.0).cpu()
+    assert (plain - direct).abs().max().item() <= 6e-5
+
+
 # ---- K1 kNN ------------------------------------------------------------------------------------------
 def _knn_case(native, dev, n_rows, n_q, seed):
     from oracle import rvc_oracle as O

@@ -5,7 +5,7 @@ python3 - <<'PY'
 import csv, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list)); dur = collections.defaultdict(list)
 for r in csv.DictReader(open("/tmp/pg/g_counter_collection.csv")):
-    if "conv_mfma_kernel" in r["Kernel_Name"] or "resblock_layer" in r["Kernel_Name"]:
+    if "conv_mfma_kernel" in r["Kernel_Name"] or "resblock_layer" in r["Kernel_Name"] or "wino_conv" in r["Kernel_Name"]:
         k = r["Kernel_Name"].split("(")[0][-44:]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"])); dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 for k, d in agg.items():

@@ -6,7 +6,7 @@ import csv, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for r in csv.DictReader(open("/tmp/pc/c_counter_collection.csv")):
-    if "conv_mfma_kernel" in r["Kernel_Name"]:
+    if "conv_mfma_kernel" in r["Kernel_Name"] or "wino_conv_kernel" in r["Kernel_Name"]:
         k = r["Kernel_Name"].split("(")[0][-44:]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
