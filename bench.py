@@ -47,9 +47,10 @@ PEAK_F16_MFMA_TFLOPS = 2500.0   # dense fp16/bf16 MFMA
 PEAK_HBM_GBS = 8000.0           # HBM3E spec
 # average HBM bytes per launch of the roofline kernel symbol at the cfg-2 shape, from the PMC passes committed under
 # profiles/ (cannot be collected inside bench.py: it needs rocprofv3)
-PMC_TRAFFIC_BYTES = 641.0e6
-PMC_TRAFFIC_SOURCE = ("profiles/r01_pmc_conv.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
-                      "tools/pmc_conv.py (this same launch mix); FETCH_SIZE calibrated on the same kernel at K=1 with known bytes")
+PMC_TRAFFIC_BYTES = 611.6e6
+PMC_TRAFFIC_SOURCE = ("profiles/r02_pmc_wino.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
+                      "tools/pmc_conv.py (this same launch mix, tools/pmc_wino.sh); FETCH_SIZE calibrated per access width on "
+                      "launches with known byte counts (4 B/lane loads 0.566, 16 B/lane 0.5)")
 
 CONFIGS = {
     1: dict(seconds=10.0, sr=40000, vocoder="HiFi-GAN", index_rows=0, index_rate=0.0, weights="f32",
@@ -95,31 +96,33 @@ def cpu_model_string():
 
 # ---- roofline legs ----------------------------------------------------------------------------------------------------
 def roofline_mix(torch, native, dev, T, rates, k=11):
-    """The launches of conv_mfma_kernel<11,2,2,2,2,4,false> in one utterance's vocoder forward: the 11-tap ResBlock of
-    stage 1 (C = 128; the 38k-column stage 0 takes the 128x64-tile symbol), for each dilation d: conv1 (dilation d) then
-    conv2 (dilation 1, + residual; the last one also + running sum, x 1/3).
-    Returns (callable, flops per call, launches per call, algorithmic HBM bytes per call)."""
+    """The launches of the dominant kernel symbol, wino_conv_kernel<11,2,2,8,0>, in one utterance's vocoder forward that
+    belong to stage 1 (C = 128): the 11-tap ResBlock, for each dilation d: conv1 (dilation d) then conv2 (dilation 1,
+    + residual; the last one also + running sum, x 1/3).  (The same symbol also runs stages 0 and 2.)
+    Returns (callable, algorithmic flops per call, launches per call, algorithmic HBM bytes per call, executed flops)."""
     C, L = 128, T * rates[0] * rates[1]
     gen = torch.Generator().manual_seed(1)
     x = torch.randn(1, C, L, device=dev)
     t1 = torch.empty_like(x)
     y = torch.randn(1, C, L, device=dev)
     acc = torch.randn(1, C, L, device=dev)
-    w1 = native.conv1d_pack_weight(torch.randn(C, C, k, generator=gen) * 0.02, dev)
-    w2 = native.conv1d_pack_weight(torch.randn(C, C, k, generator=gen) * 0.02, dev)
+    w1 = native.conv1d_wino_pack_weight(torch.randn(C, C, k, generator=gen) * 0.02, dev)
+    w2 = native.conv1d_wino_pack_weight(torch.randn(C, C, k, generator=gen) * 0.02, dev)
     bias = torch.zeros(C, device=dev)
-    flops = 6 * 2.0 * C * C * k * L
+    flops = 6 * 2.0 * C * C * k * L                          # SURVEY 8d: 2 x MACs of the conv as the reference computes it
+    groups = (k + 2) // 3
+    executed = 6 * 2.0 * C * C * (6 * groups) * (L / 4.0)    # F(4,3): 6 multiply-adds per group per 4 outputs
     tensor = C * L * 4.0
     alg_bytes = 3 * (2 * tensor) + 2 * (3 * tensor) + 1 * (4 * tensor)   # conv1: r+w; conv2: r+res+w (+acc)
 
     def run():
         for j, d in enumerate((1, 3, 5)):
-            native.conv1d_forward_into(x, w1, bias, C, k, d, 0.1, out=t1)
+            native.conv1d_wino_forward(x, w1, bias, C, k, d, 0.1, out=t1)
             if j < 2:
-                native.conv1d_forward_into(t1, w2, bias, C, k, 1, 0.1, res=x, out=y)
+                native.conv1d_wino_forward(t1, w2, bias, C, k, 1, 0.1, res=x, out=y)
             else:
-                native.conv1d_forward_into(t1, w2, bias, C, k, 1, 0.1, res=x, acc=acc, out_scale=1 / 3, out=y)
-    return run, flops, 6, alg_bytes
+                native.conv1d_wino_forward(t1, w2, bias, C, k, 1, 0.1, res=x, acc=acc, out_scale=1 / 3, out=y)
+    return run, flops, 6, alg_bytes, executed
 
 
 def decoder_flops(T, rates, ksizes, c0=512, cin=192, res_k=(3, 7, 11), n_dil=3):
@@ -354,8 +357,8 @@ def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev):
     T = min(n_pad // 160, 2 * F_)                     # synth frames (pipeline.py:467)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    # ---- dominant kernel symbol: conv_mfma_kernel<11,2,2,2,2,4,false> (stage-1 11-tap ResBlock convs) ----
-    run_mix, mix_flops, mix_launches, mix_alg_bytes = roofline_mix(torch, _native, dev, T, rates)
+    # ---- dominant kernel symbol: wino_conv_kernel<11,2,2,8,0> (11-tap ResBlock convs; stage 1 is its largest share) ----
+    run_mix, mix_flops, mix_launches, mix_alg_bytes, mix_executed = roofline_mix(torch, _native, dev, T, rates)
     for _ in range(2):
         run_mix()
     reps = 5
@@ -367,16 +370,23 @@ def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev):
     t_launch = e0.elapsed_time(e1) / (reps * mix_launches) * 1e-3
     flops_launch = mix_flops / mix_launches
     cfg2 = T == 3198 and list(rates[:2]) == [12, 10]
+    exe_launch = mix_executed / mix_launches
     res["roofline"] = {
-        "kernel": f"rvc::conv_mfma_kernel<11,2,2,2,2,4,false>: the 6 launches per utterance of the 11-tap ResBlock convs of "
-                  f"vocoder stage 1 (C=128, {T * rates[0] * rates[1]} columns), in the decoder's own mix (dilations 1/3/5, "
-                  "residual on every second one)",
+        "kernel": f"rvc::wino_conv_kernel<11,2,2,8,0>: the 6 launches per utterance of the 11-tap ResBlock convs of vocoder "
+                  f"stage 1 (C=128, {T * rates[0] * rates[1]} columns), in the decoder's own mix (dilations 1/3/5, residual "
+                  "on every second one)",
         "bound": "mfma", "achieved": round(flops_launch / t_launch / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
         "unit": "TFLOP/s", "frac": round(flops_launch / t_launch / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+        "achieved_is": "ALGORITHMIC flops (2 x MACs of the 11-tap conv, SURVEY 8d) / launch time.  The kernel is a Winograd "
+                       "F(4,3) form and EXECUTES 6*4/(4*11) = 0.545 of them on the matrix pipe, so frac can pass 1; the "
+                       "pipe's own occupancy is executed_frac",
+        "executed_tflops": round(exe_launch / t_launch / 1e12, 2),
+        "executed_frac": round(exe_launch / t_launch / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
         "traffic": PMC_TRAFFIC_BYTES if cfg2 else None,
         "traffic_source": PMC_TRAFFIC_SOURCE if cfg2 else None,
         "algorithmic_bytes_per_launch": round(mix_alg_bytes / mix_launches),
-        "flops_per_launch": flops_launch, "avg_launch_ms": round(t_launch * 1e3, 4), "launches_per_utterance": mix_launches,
+        "flops_per_launch": flops_launch, "executed_flops_per_launch": exe_launch, "avg_launch_ms": round(t_launch * 1e3, 4),
+        "launches_per_utterance": mix_launches,
         "timing": "HIP events around the isolated launch mix on the launch stream (nothing else running); rocprofv3 "
                   "--stats agrees for a sequential run (profiles/); with two utterances in flight a kernel's traced "
                   "duration also contains the time it shares the chip"}

@@ -66,6 +66,7 @@ static inline uint16_t bf16_rne(float f) {
 }
 
 // fast (Winograd F(4,3), grouped) form of the 3 / 7 / 11-tap dilated convs (wino.hip): y = out_scale * (conv(act(x)) + bias + res + accin)
+bool wino_enabled();   // RVC_WINO != 0 (conv.hip)
 bool wino_supported(int k, int dil);
 bool wino_fits(int c_in, int c_out, int64_t L);
 int launch_wino_conv(const float *x, const float *u, const float *bias, const float *res, const float *accin, float *y, int batch,

@@ -394,24 +394,19 @@ static int launch_kw(const ConvParams &p, hipStream_t stream) {
     return fail("conv: GEMM rows (%d) must be a multiple of 32", p.m_total);
 }
 
-// Which ResBlock layers take the fast (Winograd) form: where it measured faster than the direct implicit GEMM on MI355X
-// (tools/bench_conv.py; ratios direct / fast): 11 taps 1.23-1.36 at C >= 128 (any dilation), 1.1-1.25 at C = 64 / 32 for
-// dilation 1; 7 taps 1.06-1.22 for dilation 1 at C >= 64; 3 taps 1.16 for dilation 1 at C >= 128.  Dilated layers pay for
-// their strided epilogue (a tile is 4 outputs d apart), narrow ones for the per-lane transforms.
-static bool wino_wins(int k, int dil, int c) {
-    static const int mode = env_int("RVC_WINO", 1);   // 0: never; 2: wherever supported
-    if (mode == 0 || !wino_supported(k, dil)) return false;
-    if (mode == 2) return true;
-    if (k == 11) return c >= 128 || dil == 1;
-    if (k == 7) return dil == 1 && c >= 64;
-    return dil == 1 && c >= 128;
+// The ResBlock layers take the fast (Winograd) form wherever wino.hip supports the shape: on MI355X it is 1.11-1.62x the
+// direct implicit GEMM on every one of the 24 (C, K, dilation) shapes of the 48 kHz vocoders (tools/bench_conv.py,
+// profiles/r02_conv_shapes.txt).  RVC_WINO=0 switches it off (A/B runs, and the direct form's own tests).
+bool wino_enabled() {
+    static const int mode = env_int("RVC_WINO", 1);
+    return mode != 0;
 }
 
 int launch_conv(const ConvParams &p_in, hipStream_t stream) {
     if (p_in.w_wino && !p_in.x2 && !p_in.w16 && p_in.up_stride == 0 && p_in.c1 == p_in.m_total && p_in.bias_bstride == 0 &&
         p_in.l_in == p_in.l_out && p_in.n_cols == p_in.l_out && p_in.x1_bstride == (int64_t)p_in.c1 * p_in.l_in &&
         p_in.y_bstride == (int64_t)p_in.m_total * p_in.l_out && p_in.c1 % 32 == 0 && p_in.slope1 >= 0.f && p_in.slope1 <= 1.f && p_in.padl == (p_in.kw - 1) / 2 * p_in.dil &&
-        wino_fits(p_in.c1, p_in.m_total, p_in.l_in) && wino_wins(p_in.kw, p_in.dil, p_in.c1))
+        wino_enabled() && wino_supported(p_in.kw, p_in.dil) && wino_fits(p_in.c1, p_in.m_total, p_in.l_in))
         return launch_wino_conv(p_in.x1, p_in.w_wino, p_in.bias, p_in.res, p_in.accin, p_in.y, p_in.batch, p_in.c1, p_in.m_total, p_in.l_out,
                                 p_in.kw, p_in.dil, p_in.slope1, p_in.out_scale, stream);
     static const int dbg = env_int("RVC_CONV_DEBUG", 0);

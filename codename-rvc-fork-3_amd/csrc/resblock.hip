@@ -256,7 +256,10 @@ bool resblock_layer_supported(int c, int k) {
     // measured on MI355X (profiles/r01_decoder_kernels.txt): fused beats two launches for every k at C = 32 (238 vs 2 x 187 us at
     // k = 3, 453 vs 2 x 272 at k = 7, 676 vs 2 x 356 at k = 11); at C = 64 the wider unfused tiles win (k = 3: 464 vs 2 x 211 us)
     static const int c64 = getenv("RVC_FUSED_C64") ? atoi(getenv("RVC_FUSED_C64")) : 0;
-    return !off && ((c == 32 && (k == 3 || k == 7 || k == 11)) || (c64 && c == 64 && k == 3));
+    // Against the fast (Winograd) form of the unfused convs (wino.hip) the fusion only still pays at k = 3: 238 us vs 128 + 139;
+    // k = 7: 453 vs 181 + 186, k = 11: 676 vs 214 + 231.
+    const bool fast = wino_enabled();
+    return !off && ((c == 32 && (k == 3 || (!fast && (k == 7 || k == 11)))) || (c64 && c == 64 && k == 3));
 }
 
 // x, y: [batch][c][L] (must NOT alias: blocks read their neighbours' columns); w1/w2 packed [k][c][c]

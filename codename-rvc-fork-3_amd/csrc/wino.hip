@@ -46,6 +46,7 @@ struct WinoParams {
     int dil = 1;
     int sb_per_block = 0;            // super-blocks (of d tiles) per block
     int64_t n_sb = 0;                // super-blocks in the sequence: ceil(L / 4d)
+    int n_tile_blocks = 0;           // blocks along time: ceil(n_sb / sb_per_block)
     float slope = 1.f, out_scale = 1.f;
     int batch = 1;
 };
@@ -118,9 +119,16 @@ wino_conv_kernel(const WinoParams p) {
     const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.z;
-    const int m0 = blockIdx.y * BM;
+    // Blocks go round-robin over the 8 XCDs (each with its own L2).  The n_m channel blocks of one time tile read the same
+    // input rows, so they are given ids 8 apart: same XCD, dispatched together, the rows come from HBM once (measured
+    // before this mapping: 2.27x the input's bytes at the L2's memory side with two channel blocks, profiles/r02_pmc_wino.txt).
+    const int n_m = p.c_out / BM;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int tile_blk = (seq / n_m) * 8 + xcd;
+    if (tile_blk >= p.n_tile_blocks) return;
+    const int m0 = (seq % n_m) * BM;
     const int d = p.dil;
-    const int64_t sb0 = (int64_t)blockIdx.x * p.sb_per_block;     // first super-block of this block
+    const int64_t sb0 = (int64_t)tile_blk * p.sb_per_block;       // first super-block of this block
     const int n_tiles_blk = p.sb_per_block * d;                     // valid tile columns (<= BNT)
     const int64_t L = p.L;
     const float *const px = p.x + (int64_t)b * p.c_in * L;
@@ -290,47 +298,110 @@ wino_conv_kernel(const WinoParams p) {
     }
 
     // ---- epilogue: y_i = AT diag(s) D, + bias, + residual, + running sum, * scale ----------------------------------
-    const bool col_ok = col < n_tiles_blk;
-    const int sbl = col / d;
-    const int phi = col - sbl * d;
-    const int64_t t0 = (sb0 + sbl) * 4 * d + phi;
     const float *bias = p.bias;
     const float *res = p.res ? p.res + (int64_t)b * c_out * L : nullptr;
     const float *accin = p.accin ? p.accin + (int64_t)b * c_out * L : nullptr;
     float *y = p.y + (int64_t)b * c_out * L;
     const float out_scale = p.out_scale;
-    const int row0 = m0 + wm * 32 + 4 * half;
-    const bool vec = d == 1 && (L & 3) == 0;
+    const int row_l = wm * 32 + 4 * half;                // + (r & 3) + 8 (r >> 2): this lane's rows inside the block
+    f32x4 o[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int co = row0 + (r & 3) + 8 * (r >> 2);
-        const float bv = bias ? bias[co] : 0.f;
+        const float bv = bias ? bias[m0 + row_l + (r & 3) + 8 * (r >> 2)] : 0.f;
         const float d0 = acc[0][r], d1 = acc[1][r], d2 = acc[2][r], d3 = acc[3][r], d4 = acc[4][r], d5 = acc[5][r];
         const float s12 = (d1 + d2) * (-1.f / 6.f), m12 = (d1 - d2) * (-1.f / 6.f), s34 = (d3 + d4) * (1.f / 24.f), m34 = (d3 - d4) * (1.f / 24.f);
-        float o[4];
-        o[0] = fmaf(0.25f, d0, s12 + s34) + bv;
-        o[1] = fmaf(2.f, m34, m12) + bv;
-        o[2] = fmaf(4.f, s34, s12) + bv;
-        o[3] = fmaf(8.f, m34, m12) + d5 + bv;
-        if (!col_ok) continue;
-        if ((DBG & 32) && o[0] + o[1] + o[2] + o[3] != 12345.678f) continue;
-        const int64_t base = (int64_t)co * L + t0;
-        if (vec && t0 + 3 < L) {
-            f32x4 ov = {o[0], o[1], o[2], o[3]};
-            if (res) ov += *reinterpret_cast<const f32x4 *>(res + base);
-            if (accin) ov += *reinterpret_cast<const f32x4 *>(accin + base);
-            *reinterpret_cast<f32x4 *>(y + base) = ov * out_scale;
-        } else {
+        o[r].x = fmaf(0.25f, d0, s12 + s34) + bv;
+        o[r].y = fmaf(2.f, m34, m12) + bv;
+        o[r].z = fmaf(4.f, s34, s12) + bv;
+        o[r].w = fmaf(8.f, m34, m12) + d5 + bv;
+    }
+    if (DBG & 32) {
+        float sum = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int64_t t = t0 + (int64_t)i * d;
-                if (t < L) {
-                    float v = o[i];
-                    if (res) v += res[base + (int64_t)i * d];
-                    if (accin) v += accin[base + (int64_t)i * d];
-                    y[base + (int64_t)i * d] = v * out_scale;
-                }
+        for (int r = 0; r < 16; ++r) sum += o[r].x + o[r].y + o[r].z + o[r].w;
+        if (sum != 12345.678f) return;
+    }
+    const bool l4 = (L & 3) == 0;
+    if (d == 1 && l4) {
+        // a lane's 4 outputs are 16 contiguous bytes: straight from the registers.  All residual / running-sum loads are
+        // issued before the first is used (one memory latency per block, not one per row).
+        const int64_t t0 = (sb0 + col) * 4;
+        if (col < n_tiles_blk && t0 < L) {
+            const int64_t base = (int64_t)(m0 + row_l) * L + t0;
+            if (res) {
+                f32x4 rv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = *reinterpret_cast<const f32x4 *>(res + base + (int64_t)((r & 3) + 8 * (r >> 2)) * L);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] += rv[r];
             }
+            if (accin) {
+                f32x4 av[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) av[r] = *reinterpret_cast<const f32x4 *>(accin + base + (int64_t)((r & 3) + 8 * (r >> 2)) * L);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] += av[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) *reinterpret_cast<f32x4 *>(y + base + (int64_t)((r & 3) + 8 * (r >> 2)) * L) = o[r] * out_scale;
+        }
+        return;
+    }
+    // Dilated (a lane's outputs are d apart) or ragged rows: through LDS, so that HBM sees whole contiguous rows.
+    // yt[row][t - t_blk0], row stride YS floats; the chunk buffers are dead once every wave has left the main loop.
+    constexpr int YS = 4 * BNT + 4;
+    // (the launch reserves max(chunk buffers, BM * YS floats): wino_lds_bytes)
+    float *yt = wino_smem;
+    lds_barrier();
+    {
+        const int sbl = col / d;
+        const int tl0 = sbl * 4 * d + (col - sbl * d);
+        if (col < n_tiles_blk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float *dst = yt + (row_l + (r & 3) + 8 * (r >> 2)) * YS + tl0;
+                dst[0] = o[r].x; dst[d] = o[r].y; dst[2 * d] = o[r].z; dst[3 * d] = o[r].w;
+            }
+        }
+    }
+    lds_barrier();
+    const int64_t t_blk0 = sb0 * 4 * d;                             // a multiple of 4
+    const int64_t left = L - t_blk0;
+    const int n_t = (int)(left < 4 * n_tiles_blk ? left : 4 * n_tiles_blk);   // valid outputs per row in this block
+    if (l4) {   // 16-byte pieces: BNT threads per row, NTH / BNT rows per pass
+        constexpr int RPP = NTH / BNT, PASSES = BM / RPP;
+        const int tq = (tid % BNT) * 4, rq = tid / BNT;
+        if (tq < n_t) {
+            const int64_t base = (int64_t)(m0 + rq) * L + t_blk0 + tq;
+            f32x4 v[PASSES];
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) v[k] = *reinterpret_cast<const f32x4 *>(yt + (rq + k * RPP) * YS + tq);
+            if (res) {
+                f32x4 rv[PASSES];
+#pragma unroll
+                for (int k = 0; k < PASSES; ++k) rv[k] = *reinterpret_cast<const f32x4 *>(res + base + (int64_t)k * RPP * L);
+#pragma unroll
+                for (int k = 0; k < PASSES; ++k) v[k] += rv[k];
+            }
+            if (accin) {
+                f32x4 av[PASSES];
+#pragma unroll
+                for (int k = 0; k < PASSES; ++k) av[k] = *reinterpret_cast<const f32x4 *>(accin + base + (int64_t)k * RPP * L);
+#pragma unroll
+                for (int k = 0; k < PASSES; ++k) v[k] += av[k];
+            }
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) *reinterpret_cast<f32x4 *>(y + base + (int64_t)k * RPP * L) = v[k] * out_scale;
+        }
+    } else {    // row length not a multiple of 4: single samples
+        for (int e = tid; e < BM * 4 * BNT; e += NTH) {
+            const int rq = e / (4 * BNT), tq = e - rq * (4 * BNT);
+            if (tq >= n_t) continue;
+            const int64_t at = (int64_t)(m0 + rq) * L + t_blk0 + tq;
+            float v = yt[rq * YS + tq];
+            if (res) v += res[at];
+            if (accin) v += accin[at];
+            y[at] = v * out_scale;
         }
     }
 }
@@ -342,7 +413,9 @@ static size_t wino_lds_bytes() {
     constexpr int MLO = SMIN >= 0 ? SMIN / 4 : -((-SMIN + 3) / 4), MHI = SMAX / 4;
     constexpr int XT = 32 * WN + (MHI - MLO) * WINO_MAX_DIL;
     constexpr int XTS = ((XT + 31) / 32) * 32 + 8;
-    return (size_t)2 * (3 * G * (CIC / 2) * 32 * WM + (CIC / 2) * 4 * XTS) * 2 * sizeof(float);
+    const size_t chunks = (size_t)2 * (3 * G * (CIC / 2) * 32 * WM + (CIC / 2) * 4 * XTS) * 2 * sizeof(float);
+    const size_t out_tile = (size_t)32 * WM * (4 * 32 * WN + 4) * sizeof(float);   // the dilated epilogue's transposed tile
+    return chunks > out_tile ? chunks : out_tile;
 }
 
 template <int KW, int WM, int WN, int CIC, int DBG = 0>
@@ -357,7 +430,9 @@ static int wino_launch_cfg(WinoParams p, hipStream_t stream) {
         err = hipFuncSetAttribute((const void *)wino_conv_kernel<KW, WM, WN, CIC, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
     if (err != hipSuccess) return fail("wino conv: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(err));
-    dim3 grid((unsigned)ceil_div(p.n_sb, p.sb_per_block), (unsigned)(p.c_out / (32 * WM)), (unsigned)p.batch);
+    p.n_tile_blocks = (int)ceil_div(p.n_sb, p.sb_per_block);
+    const int n_m = p.c_out / (32 * WM);
+    dim3 grid((unsigned)(ceil_div(p.n_tile_blocks, 8) * 8 * n_m), 1, (unsigned)p.batch);
     hipLaunchKernelGGL((wino_conv_kernel<KW, WM, WN, CIC, DBG>), grid, dim3(64 * WM * WN), lds, stream, p);
     RVC_LAUNCH_CHECK();
     return 0;
