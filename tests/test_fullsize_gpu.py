@@ -45,6 +45,7 @@ def _converter(S, sr, voc, hubert, config=None):
     return vc
 
 
+PLAIN_GATE = 5e-3  # waveform RMS with each side on its OWN f0 contour (fp32-noise-level f0 differences through the phase integral)
 SAL_TIE = 2.5e-4   # salience near-tie bound: ~4x the largest GPU-vs-CPU salience difference measured (6e-5, tools/diag_rmvpe.py)
 F0_NOISE = 2e-5    # relative f0 difference that identical arg-max bins produce (measured ~1e-6: the 9-bin weighted mean
                    # moves with the salience's 1e-5-level differences)
@@ -89,13 +90,33 @@ def _run_pair(S, sds, vc, hubert, cpt, audio, big, rate, seed, **okw):
     vc.vc.debug_taps = None
     differ = _f0_tie_report(f0_p, sal_p, taps["f0_raw"], taps["salience"])
     plain_err = rms(got - want) if got.shape == want.shape else float("nan")
-    if len(differ):
+    # The coarse pitch (integer 1..255, the pitch-embedding index; pipeline.py:401-408) rounds a mel-scaled f0: contours equal
+    # to fp noise can still land on either side of a .5 boundary.  One such frame changes the embedding of 10 ms of a 45 s
+    # clip -- 1.3e-3 whole-clip RMS when it happens (seen on about one run in three of the 45 s case; the GPU contour itself
+    # moves by ~1e-7 relative from run to run).  Each flip must be a certified rounding near-tie; the oracle then follows
+    # the product's contour like for the arg-max ties.
+    n_f = min(len(f0_p), len(taps["f0_raw"]))
+    keep = np.ones(n_f, bool)
+    keep[differ[differ < n_f]] = False
+    c_p, c_o = O.f0_to_coarse(f0_p[:n_f].astype(np.float64))[0], O.f0_to_coarse(taps["f0_raw"][:n_f].astype(np.float64))[0]
+    flips = np.nonzero((c_p != c_o) & keep)[0]
+    for t in flips:
+        f = float(taps["f0_raw"][t])
+        mel = (1127 * np.log(1 + f / 700) - O.F0_MEL_MIN) * 254 / (O.F0_MEL_MAX - O.F0_MEL_MIN) + 1
+        assert abs(abs(mel - np.floor(mel)) - 0.5) <= 2e-3 and abs(int(c_p[t]) - int(c_o[t])) == 1, (t, f, mel, c_p[t], c_o[t])
+    # Even with NO differing frame the two contours are only equal to fp32 noise (<= F0_NOISE relative, asserted above), and
+    # the NSF source integrates f0 into phase over the whole segment: a 2e-7 relative offset is 2 pi * 200 Hz * 45 s * 2e-7
+    # = 0.011 rad at the end of a 45 s clip, i.e. ~1e-3 waveform RMS (measured 1.35e-3 at 45 s, 4e-4 at 30 s).  So when the
+    # plain comparison is within a factor of a few of the gate, the oracle is re-run ON THE PRODUCT'S CONTOUR: the f0 stage
+    # has been checked on its own just above, this checks everything downstream of it at full length.  The plain error is
+    # reported and bounded by the callers (PLAIN_GATE).
+    if len(differ) or len(flips) or plain_err > 3e-4:
         torch.manual_seed(seed)
         want = O.pipeline(sds[0], sds[1], cpt, audio.copy(), sid=0, pitch=0, big_npy=big, index_rate=rate, protect=0.5,
                           f0_override=f0_p, **okw)
     rel = np.abs(f0_p[:len(taps["f0_raw"])] - taps["f0_raw"]) / np.maximum(taps["f0_raw"], 1.0)
     rel[differ] = 0
-    return got, want, dict(tie_frames=len(differ), n_frames=len(f0_p), plain_err=plain_err, t_oracle=t_oracle,
+    return got, want, dict(tie_frames=len(differ), coarse_flips=len(flips), n_frames=len(f0_p), plain_err=plain_err, t_oracle=t_oracle,
                            f0_rel_max=float(rel.max()), opt_ts=taps.get("opt_ts"))
 
 
@@ -122,9 +143,13 @@ def test_baseline_config_full_length_vs_oracle(S, hubert, sds, cfg):
     err = rms(got - want)
     print(f"cfg {cfg} full length: rms err {err:.3e} (oracle rms {rms(want):.3f}, oracle {info['t_oracle']:.0f} s); "
           f"f0: {info['tie_frames']} of {info['n_frames']} frames are certified salience near-ties, the rest agree to "
-          f"{info['f0_rel_max']:.1e} relative; waveform error before following the product on those frames: {info['plain_err']:.3e}")
+          f"{info['f0_rel_max']:.1e} relative, {info['coarse_flips']} coarse-bin rounding flips; waveform error before following "
+          f"the product on those frames: {info['plain_err']:.3e}")
     assert err <= 1e-3, err
     assert info["tie_frames"] <= 0.002 * info["n_frames"], info   # a handful per 30 s at most
+    assert info["coarse_flips"] <= 0.002 * info["n_frames"], info
+    if info["tie_frames"] == 0:
+        assert info["plain_err"] <= PLAIN_GATE, info
 
 
 def test_multi_segment_matches_reference_golden(S, hubert):
@@ -155,9 +180,13 @@ def test_45s_two_segments_vs_oracle(S, hubert, sds):
     assert len(info["opt_ts"]) == 1 and got.shape == want.shape == (int(load_golden("segmentation")["outlen_45"]),)
     err = rms(got - want)
     print(f"45 s, 2 segments: rms err {err:.3e} (oracle rms {rms(want):.3f}); f0 near-tie frames {info['tie_frames']} of "
-          f"{info['n_frames']}; before following the product on them: {info['plain_err']:.3e}")
+          f"{info['n_frames']}, coarse-bin rounding flips {info['coarse_flips']}; before following the product on them: "
+          f"{info['plain_err']:.3e}")
     assert err <= 1e-3, err
     assert info["tie_frames"] <= 0.002 * info["n_frames"], info
+    assert info["coarse_flips"] <= 0.002 * info["n_frames"], info
+    if info["tie_frames"] == 0:
+        assert info["plain_err"] <= PLAIN_GATE, info
 
 
 @pytest.mark.parametrize("hint", [1, 2])
