@@ -94,6 +94,11 @@ SYMBOLS = {
     "rvc_conv1d_wino_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rvc_conv1d_wino_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                         c_int64, c_int, c_int, c_float, c_float, c_void_p]),
+    "rvc_conv2d_packed_floats": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
+    "rvc_conv2d_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rvc_conv2d_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
+    "rvc_conv2d_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "rvc_comm_unique_id": (c_int, [c_void_p]),
     "rvc_comm_create": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
     "rvc_comm_destroy": (c_int, [c_void_p]),
@@ -515,6 +520,37 @@ def conv1d_wino_forward(x, u_packed, bias, c_out, k, dilation=1, slope_in=1.0, r
                                         res.data_ptr() if res is not None else None,
                                         acc.data_ptr() if acc is not None else None, y.data_ptr(), b, c_in, c_out, length, k,
                                         dilation, float(slope_in), float(out_scale), _stream()), "rvc_conv1d_wino_forward")
+    return y
+
+
+# ---- K9: conv2d 3x3 / 1x1 of the RMVPE U-Net -------------------------------------------------------------
+def conv2d_pack_weight(w: torch.Tensor, device) -> torch.Tensor:
+    """torch conv2d weight [C_out, C_in, kh, kw] (3x3 or 1x1) -> packed taps in HBM."""
+    w = w.detach().float().cpu().contiguous()
+    c_out, c_in, kh, kw = w.shape
+    n = c_size_t()
+    _check(_lib.rvc_conv2d_packed_floats(c_out, c_in, kh, kw, ctypes.byref(n)), "rvc_conv2d_packed_floats")
+    out = torch.empty(n.value, dtype=torch.float32, device=device)
+    _check(_lib.rvc_conv2d_pack_weight(w.data_ptr(), c_out, c_in, kh, kw, out.data_ptr(), _stream()), "rvc_conv2d_pack_weight")
+    return out
+
+
+def conv2d_supported(c_in: int, width: int) -> bool:
+    return c_in % 8 == 0 and 4 <= width <= 128 and width & (width - 1) == 0
+
+
+def conv2d_forward(x, w_packed, bias, c_out, ksize=3, relu=False, res=None, out=None):
+    """y = act(conv2d(x, w, padding=ksize // 2) + bias) + res  (x [B, C_in, H, W] float32 on the device)."""
+    x = _dev_f32(x, "x")
+    b, c_in, h, wd = x.shape
+    y = out if out is not None else torch.empty((b, c_out, h, wd), dtype=torch.float32, device=x.device)
+    need = c_size_t()
+    _check(_lib.rvc_conv2d_workspace_bytes(b, c_in, c_out, h, wd, ksize, ksize, ctypes.byref(need)), "rvc_conv2d_workspace_bytes")
+    ws = _ws.get("conv2d", need.value, x.device) if need.value else None
+    _check(_lib.rvc_conv2d_forward(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                   res.data_ptr() if res is not None else None, y.data_ptr(), b, c_in, c_out, h, wd, ksize, ksize,
+                                   1 if relu else 0, ws.data_ptr() if ws is not None else None, need.value, _stream()),
+           "rvc_conv2d_forward")
     return y
 
 

@@ -7,6 +7,7 @@
 """
 from __future__ import annotations
 
+import os
 from typing import Dict
 
 import numpy as np
@@ -66,6 +67,13 @@ class RMVPE0Predictor:
                 w["gru." + n + sfx] = sd["fc.0.gru." + n + sfx]
         w["fc.w"], w["fc.b"] = sd["fc.1.weight"], sd["fc.1.bias"]
         self.w = {k: v.to(self.device).contiguous() for k, v in w.items()}
+        # K9 (conv2d.hip) taps of every 3x3 / 1x1 block conv whose input channel count the kernel takes (all but the 1 -> 16 one)
+        self.wp = {}
+        if self.device.type == "cuda" and os.environ.get("RVC_NATIVE_UNET", "1") != "0":
+            from rvc_amd import _native
+            for k, v in w.items():
+                if k.endswith((".c1.w", ".c2.w", ".sc.w")) and v.shape[1] % 8 == 0:
+                    self.wp[k] = _native.conv2d_pack_weight(v, self.device)
         # BiGRU: one GEMM for the input projections of both directions, recurrence in librvc_amd (gru.hip)
         self.w["gru.wih"] = torch.cat([self.w["gru.weight_ih_l0"], self.w["gru.weight_ih_l0_reverse"]], 0).contiguous()
         self.w["gru.bih"] = torch.cat([self.w["gru.bias_ih_l0"], self.w["gru.bias_ih_l0_reverse"]], 0).contiguous()
@@ -75,6 +83,14 @@ class RMVPE0Predictor:
 
     def _block(self, x, p):
         w = self.w
+        if x.is_cuda and p + ".c1.w" in self.wp and x.shape[-1] in (4, 8, 16, 32, 64, 128):
+            # the whole block in librvc_amd: conv + folded-BN bias + ReLU (+ skip path) per launch (conv2d.hip)
+            from rvc_amd import _native
+            c_mid, c_out = w[p + ".c1.w"].shape[0], w[p + ".c2.w"].shape[0]
+            x = x.contiguous()
+            y = _native.conv2d_forward(x, self.wp[p + ".c1.w"], w[p + ".c1.b"], c_mid, 3, relu=True)
+            res = _native.conv2d_forward(x, self.wp[p + ".sc.w"], w[p + ".sc.b"], c_out, 1) if p + ".sc.w" in self.wp else x
+            return _native.conv2d_forward(y, self.wp[p + ".c2.w"], w[p + ".c2.b"], c_out, 3, relu=True, res=res)
         if x.is_cuda and x.shape[-1] * x.shape[-2] % 4 == 0:
             # conv by MIOpen; bias + ReLU (+ residual) as ONE pass of librvc_amd K8 instead of three PyTorch launches
             from rvc_amd import _native

@@ -296,6 +296,21 @@ int rvc_index_broadcast(rvc_comm *comm, void *buf_dev, size_t bytes, int root, v
  * (a trailing 1-3 bytes are zero-extended into a last word).  Computed in HBM: the index never crosses PCIe. */
 int rvc_checksum64(const void *buf_dev, size_t bytes, uint64_t *out2_dev, void *stream);
 
+/* ---- K9: conv2d 3x3 (padding 1) / 1x1, stride 1, of RMVPE's U-Net blocks (RMVPE.py:13-287) ---------------------------- *
+ * y = act(conv(x) + bias) + res  with act = ReLU when relu != 0 -- ConvBlockRes with its BatchNorms folded into the weights
+ * (eval mode): conv -> BN -> ReLU, then the skip path added after the activation.  fp32 on the matrix cores, k-ordered
+ * accumulation; deep levels split K over several workgroups and sum the partials in a fixed order (bit-reproducible).
+ * x [batch][C_in][H][W], y / res [batch][C_out][H][W]; C_in a multiple of 8, W a power of two in 4..128.
+ * w_packed: rvc_conv2d_packed_floats() floats filled by rvc_conv2d_pack_weight from torch's [C_out][C_in][kh][kw].
+ * workspace: rvc_conv2d_workspace_bytes() bytes (0 for shapes that do not split), caller-owned, reusable across calls on one
+ * stream. */
+int rvc_conv2d_packed_floats(int c_out, int c_in, int kh, int kw, size_t *out);
+int rvc_conv2d_pack_weight(const float *w_host, int c_out, int c_in, int kh, int kw, float *w_dev, void *stream);
+int rvc_conv2d_workspace_bytes(int batch, int c_in, int c_out, int height, int width, int kh, int kw, size_t *out);
+int rvc_conv2d_forward(const float *x_dev, const float *w_packed_dev, const float *bias_dev, const float *res_dev,
+                       float *y_dev, int batch, int c_in, int c_out, int height, int width, int kh, int kw, int relu,
+                       void *workspace_dev, size_t workspace_bytes, void *stream);
+
 /* ---- the same conv in its fast form (unit-test entry of what the decoder uses for its ResBlock layers) ---------------- *
  * Winograd / Toom-Cook F(4,3) over groups of three taps: identical mathematics, 1.5 G multiply-adds per output instead
  * of K (G = ceil(K / 3)); fp32 throughout, one layer agrees with float64 to ~5e-7 relative RMS (direct fp32 form: ~2e-7).

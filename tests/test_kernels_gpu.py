@@ -79,6 +79,32 @@ def test_conv1d_winograd_matches_float64(native, dev, c_in, c_out, k, dil, lengt
     assert (plain - direct).abs().max().item() <= 6e-5
 
 
+@pytest.mark.parametrize("c_in,c_out,h,w,ks,batch", [
+    (32, 32, 50, 64, 3, 1), (64, 64, 37, 32, 3, 2), (128, 128, 101, 16, 3, 1), (256, 256, 51, 8, 3, 1), (512, 512, 26, 4, 3, 1),
+    (256, 512, 101, 4, 3, 1), (512, 256, 13, 8, 3, 1), (16, 16, 9, 128, 3, 1), (32, 16, 7, 128, 3, 1), (16, 3, 11, 128, 3, 1),
+    (16, 32, 20, 64, 1, 1), (256, 512, 17, 4, 1, 1), (64, 32, 33, 64, 3, 1),
+])
+def test_conv2d_matches_float64(native, dev, c_in, c_out, h, w, ks, batch):
+    """K9 (conv2d.hip), the conv of RMVPE's ConvBlockRes (RMVPE.py:13-60) with folded BatchNorm bias, ReLU and the skip path:
+    every level's (channels, row length) pair of the U-Net, heights that are not a multiple of the block's rows, the 16- and
+    3-channel outputs (padded to 32 rows), the K-split deep levels, 1x1 shortcuts -- against F.conv2d in float64."""
+    g = torch.Generator().manual_seed(c_in * 100 + c_out + h + w)
+    x = torch.randn(batch, c_in, h, w, generator=g)
+    wt = torch.randn(c_out, c_in, ks, ks, generator=g) / (c_in * ks * ks) ** 0.5
+    b = torch.randn(c_out, generator=g)
+    res = torch.randn(batch, c_out, h, w, generator=g)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=ks // 2)) + res.double()
+    wp = native.conv2d_pack_weight(wt, dev)
+    got = native.conv2d_forward(x.to(dev), wp, b.to(dev), c_out, ks, relu=True, res=res.to(dev)).cpu()
+    assert got.shape == ref.shape
+    err = (got.double() - ref).abs().max().item()
+    assert err <= 2e-5, err
+    plain = native.conv2d_forward(x.to(dev), wp, None, c_out, ks).cpu()
+    assert (plain.double() - F.conv2d(x.double(), wt.double(), None, padding=ks // 2)).abs().max().item() <= 2e-5
+    again = native.conv2d_forward(x.to(dev), wp, None, c_out, ks).cpu()
+    assert torch.equal(plain, again)                # split-K partials are summed in a fixed order
+
+
 # ---- K1 kNN ------------------------------------------------------------------------------------------
 def _knn_case(native, dev, n_rows, n_q, seed):
     from oracle import rvc_oracle as O

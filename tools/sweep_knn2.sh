@@ -1,0 +1,6 @@
+#!/bin/bash
+# screened kNN at the cfg-2 shape (1599 x 100000 x 768): block count of the main pass x sampled tiles
+cd $GRAFT_REPO_ROOT
+for b in 252 504 1024 2800; do for s in 36 63 73; do
+  echo -n "blocks=$b sample_tiles=$s: "; QS=1599 RVC_KNN_SCREEN_BLOCKS=$b RVC_KNN_SAMPLE_TILES=$s python tools/bench_knn.py 2>/dev/null | sed 's/.*screened *//; s/(.*identical/ identical/'
+done; done
