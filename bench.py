@@ -423,7 +423,7 @@ def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev):
         n_rows = int(index_dev.shape[0])
         q = index_dev[torch.randint(0, n_rows, (F_,), device=dev)] + 0.03 * torch.randn(F_, 768, device=dev)
         idx.search_device(q)
-        reps = 5 if n_rows <= 200_000 else 2
+        reps = 20 if n_rows <= 200_000 else 3
         e0.record()
         for _ in range(reps):
             idx.search_device(q)

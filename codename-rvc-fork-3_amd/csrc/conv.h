@@ -36,6 +36,7 @@ struct ConvParams {
     int up_stride = 0, up_pad = 0;
     float out_scale = 1.f;
     int batch = 1;
+    const uint32_t *w_wino16 = nullptr;   // ... stored as bf16 pairs (with w16)
     const float *w_wino = nullptr;   // the same taps in wino.hip's layout: launch_conv may take the fast (Winograd) form for
                                      // plain 3 / 7 / 11-tap layers where it is the faster one
     int debug = 0;   // experiments only (RVC_CONV_DEBUG): 1 = skip x loads, 2 = skip y stores, 4 = skip res loads
@@ -69,10 +70,11 @@ static inline uint16_t bf16_rne(float f) {
 bool wino_enabled();   // RVC_WINO != 0 (conv.hip)
 bool wino_supported(int k, int dil);
 bool wino_fits(int c_in, int c_out, int64_t L);
-int launch_wino_conv(const float *x, const float *u, const float *bias, const float *res, const float *accin, float *y, int batch,
-                     int c_in, int c_out, int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream);
+int launch_wino_conv(const float *x, const void *u, bool u_bf16, const float *bias, const float *res, const float *accin, float *y,
+                     int batch, int c_in, int c_out, int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream);
 // regular conv weight [c_out][c_in][k] -> [3 ceil(k/3)][c_in / 2][c_out][2] (zero taps appended, channel pairs interleaved)
 void wino_pack_host(const float *w_host, int c_out, int c_in, int k, std::vector<float> *out);
+void wino_pack_host_bf16(const float *w_host, int c_out, int c_in, int k, std::vector<uint32_t> *out);   // one word per channel pair
 int wino_pack_weight(const float *w_host, int c_out, int c_in, int k, float **out_dev);
 
 // host-side repacks (return freshly hipMalloc'ed device buffers)

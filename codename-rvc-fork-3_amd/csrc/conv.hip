@@ -403,11 +403,11 @@ bool wino_enabled() {
 }
 
 int launch_conv(const ConvParams &p_in, hipStream_t stream) {
-    if (p_in.w_wino && !p_in.x2 && !p_in.w16 && p_in.up_stride == 0 && p_in.c1 == p_in.m_total && p_in.bias_bstride == 0 &&
+    if ((p_in.w_wino || p_in.w_wino16) && !p_in.x2 && p_in.up_stride == 0 && p_in.c1 == p_in.m_total && p_in.bias_bstride == 0 &&
         p_in.l_in == p_in.l_out && p_in.n_cols == p_in.l_out && p_in.x1_bstride == (int64_t)p_in.c1 * p_in.l_in &&
         p_in.y_bstride == (int64_t)p_in.m_total * p_in.l_out && p_in.c1 % 32 == 0 && p_in.slope1 >= 0.f && p_in.slope1 <= 1.f && p_in.padl == (p_in.kw - 1) / 2 * p_in.dil &&
         wino_enabled() && wino_supported(p_in.kw, p_in.dil) && wino_fits(p_in.c1, p_in.m_total, p_in.l_in))
-        return launch_wino_conv(p_in.x1, p_in.w_wino, p_in.bias, p_in.res, p_in.accin, p_in.y, p_in.batch, p_in.c1, p_in.m_total, p_in.l_out,
+        return launch_wino_conv(p_in.x1, p_in.w_wino16 ? (const void *)p_in.w_wino16 : (const void *)p_in.w_wino, p_in.w_wino16 != nullptr, p_in.bias, p_in.res, p_in.accin, p_in.y, p_in.batch, p_in.c1, p_in.m_total, p_in.l_out,
                                 p_in.kw, p_in.dil, p_in.slope1, p_in.out_scale, stream);
     static const int dbg = env_int("RVC_CONV_DEBUG", 0);
     ConvParams p = p_in;

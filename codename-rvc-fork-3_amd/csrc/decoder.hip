@@ -381,9 +381,17 @@ int build_conv(const rvc_decoder *d, const std::string &prefix, int c_out, int c
     } else if (out->w.upload(packed)) {
         return 1;
     }
-    if (!as_bf16 && c_in == c_out && c_out % 32 == 0 && wino_supported(k, 1)) {   // ResBlock layers: second copy for the fast form
-        wino_pack_host(w->data.data(), c_out, c_in, k, &packed);
-        if (out->wu.upload(packed)) return 1;
+    if (c_in == c_out && c_out % 32 == 0 && wino_supported(k, 1)) {   // ResBlock layers: second copy for the fast form
+        if (as_bf16) {
+            std::vector<uint32_t> words;
+            wino_pack_host_bf16(w->data.data(), c_out, c_in, k, &words);
+            std::vector<uint16_t> halves(words.size() * 2);
+            memcpy(halves.data(), words.data(), words.size() * 4);
+            if (out->wu16.upload(halves)) return 1;
+        } else {
+            wino_pack_host(w->data.data(), c_out, c_in, k, &packed);
+            if (out->wu.upload(packed)) return 1;
+        }
     }
     if (bias) {
         if (need(d, prefix + ".bias", &b, {c_out})) return 1;
@@ -733,12 +741,14 @@ extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const flo
                 ConvParams p;
                 p.x1 = xin; p.c1 = s.c_out; p.slope1 = 0.1f; p.x1_bstride = bs; p.l_in = len;
                 p.w = s.c1[m * nd + j].w.p; p.w16 = s.c1[m * nd + j].w16.p; p.bias = s.c1[m * nd + j].b.p; p.w_wino = s.c1[m * nd + j].wu.p;
+                p.w_wino16 = reinterpret_cast<const uint32_t *>(s.c1[m * nd + j].wu16.p);
                 p.y = T1; p.y_bstride = bs; p.m_total = s.c_out; p.c_out = s.c_out; p.n_cols = len; p.l_out = len;
                 p.kw = k; p.dil = dil; p.padl = (k - 1) / 2 * dil; p.batch = batch;
                 if (launch_conv(p, stream)) return 1;
                 ConvParams q;
                 q.x1 = T1; q.c1 = s.c_out; q.slope1 = 0.1f; q.x1_bstride = bs; q.l_in = len;
                 q.w = s.c2[m * nd + j].w.p; q.w16 = s.c2[m * nd + j].w16.p; q.bias = s.c2[m * nd + j].b.p; q.w_wino = s.c2[m * nd + j].wu.p;
+                q.w_wino16 = reinterpret_cast<const uint32_t *>(s.c2[m * nd + j].wu16.p);
                 q.res = xin;
                 q.y_bstride = bs; q.m_total = s.c_out; q.c_out = s.c_out; q.n_cols = len; q.l_out = len;
                 q.kw = k; q.dil = 1; q.padl = (k - 1) / 2; q.batch = batch;

@@ -69,10 +69,19 @@ struct ScreenTile {
 // atomicMax on the integer view orders them): [0] max sum x^2, [1] max residual^2, [2] max |x|.
 __global__ void __launch_bounds__(256)
 knn_to_half_kernel(const float *__restrict__ x, int64_t n_rows, int dim, _Float16 *__restrict__ xh, float *__restrict__ norms,
-                   f32x4 *__restrict__ rowstat, unsigned *__restrict__ stats) {
+                   f32x4 *__restrict__ rowstat, unsigned *__restrict__ stats, float *__restrict__ mins = nullptr, int n_slots = 0,
+                   int *__restrict__ cnt = nullptr) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_rows) return;
+    // a search's per-query scratch is reset here (the query conversion is its first launch): the sample pass's minima to
+    // +inf, the candidate counters to 0 -- two fill launches less per search
+    if (mins)
+        for (int i = lane; i < n_slots; i += 64) mins[row * n_slots + i] = INFINITY;
+    if (cnt && lane == 0) {
+        cnt[row] = 0;
+        if (row == 0) cnt[n_rows] = 0;       // the exact-scan counter behind the per-query ones
+    }
     const f32x4 *p = reinterpret_cast<const f32x4 *>(x + row * dim);
     _Float16 *o = xh + row * dim;
     float s = 0.f, r2 = 0.f, h2 = 0.f, mx = 0.f;
@@ -764,10 +773,8 @@ int knn_screened_search(const float *index, const void *aux_dev, int64_t n_rows,
     });
     if (lds_err != hipSuccess) return fail("knn screen: cannot reserve LDS: %s", hipGetErrorString(lds_err));
 
-    RVC_HIP(hipMemsetAsync(cnt, 0, (size_t)(n_queries + 1) * sizeof(int), stream));
-    RVC_HIP(hipMemsetD32Async((hipDeviceptr_t)mins, 0x7f800000, (size_t)n_queries * s.sample_tiles * s.slots_per_tile, stream));   // +inf
     hipLaunchKernelGGL(knn_to_half_kernel, dim3((unsigned)ceil_div(n_queries, 4)), dim3(256), 0, stream, queries, n_queries, dim, qh,
-                       (float *)nullptr, qstat, (unsigned *)nullptr);
+                       (float *)nullptr, qstat, (unsigned *)nullptr, mins, s.sample_tiles * s.slots_per_tile, cnt);
     RVC_LAUNCH_CHECK();
 
     ScreenParams p;
@@ -823,7 +830,8 @@ extern "C" int rvc_knn_index_build(const float *index_dev, int64_t n_rows, int d
     char *ab = (char *)aux_dev;
     RVC_HIP(hipMemsetAsync(ab + a.stats, 0, 256, (hipStream_t)stream));
     hipLaunchKernelGGL(knn_to_half_kernel, dim3((unsigned)ceil_div(n_rows, 4)), dim3(256), 0, (hipStream_t)stream, index_dev, n_rows,
-                       dim, (_Float16 *)(ab + a.half), (float *)(ab + a.norms), (f32x4 *)nullptr, (unsigned *)(ab + a.stats));
+                       dim, (_Float16 *)(ab + a.half), (float *)(ab + a.norms), (f32x4 *)nullptr, (unsigned *)(ab + a.stats),
+                       (float *)nullptr, 0, (int *)nullptr);
     RVC_LAUNCH_CHECK();
     return 0;
 }

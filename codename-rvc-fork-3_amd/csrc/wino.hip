@@ -36,7 +36,9 @@ namespace rvc {
 
 struct WinoParams {
     const float *x = nullptr;        // [batch][c_in][L]
-    const float *u = nullptr;        // [3 G][c_in / 2][c_out][2]: the taps (zero-padded to a multiple of three), channel pairs interleaved
+    const void *u = nullptr;         // [3 G][c_in / 2][c_out][2]: the taps (zero-padded to a multiple of three), channel pairs interleaved;
+                                     // fp32, or (u_bf16) one 32-bit word per pair: even channel in the low half
+    bool u_bf16 = false;
     const float *bias = nullptr;     // [c_out]
     const float *res = nullptr;      // [batch][c_out][L] or null
     const float *accin = nullptr;    // [batch][c_out][L] or null
@@ -85,7 +87,9 @@ constexpr int WINO_RSRC_FLAGS = 0x00020000;   // raw buffer, 32-bit data format
 //   * the weight taps go HBM/L2 -> LDS by LDS-DMA (global_load_lds, 16 B per lane): no registers, no vector instructions;
 //   * the input rows are staged with two fixed per-thread offsets (one division set per block, not per element) and only
 //     the first / last block of a row masks for the conv's zero padding.
-template <int KW, int WM, int WN, int CIC, int DBG = 0>
+// WB16: the taps are stored as bf16 (BASELINE cfg 4), one 32-bit word per input-channel pair; they stay bf16 in LDS and are
+// widened (two shifts / masks per tap pair) when the fragment is read -- half the tap stream and LDS footprint.
+template <int KW, int WM, int WN, int CIC, int DBG = 0, bool WB16 = false>
 __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wino_conv_kernel(const WinoParams p) {
     constexpr int G = (KW + 2) / 3;
@@ -103,10 +107,10 @@ wino_conv_kernel(const WinoParams p) {
     constexpr int XT = BNT + (MHI - MLO) * WINO_MAX_DIL;  // staged tiles per row (enough for d <= 5)
     constexpr int XTS = ((XT + 31) / 32) * 32 + 8;        // row stride in float2: == 8 mod 32, the 4 de-interleaved rows of a ds_write_b64 land in 4 bank groups
     constexpr int XTOT = CP * 4 * XTS;                    // float2 per input buffer
-    constexpr int UROWS = 3 * G * CP;                     // weight rows of BM float2
-    constexpr int UTOT = UROWS * BM;                      // float2 per weight buffer
-    constexpr int UINSTR = UTOT * 8 / 1024;               // LDS-DMA wave-instructions (1 KiB each) per chunk
-    static_assert((UTOT * 8) % 1024 == 0, "weight chunk is a whole number of DMA pieces");
+    constexpr int UROWS = 3 * G * CP;                     // weight rows of BM channel pairs
+    constexpr int UPAIR = WB16 ? 4 : 8;                   // bytes per stored pair
+    constexpr int UINSTR = (UROWS * BM * UPAIR + 1023) / 1024;   // LDS-DMA wave-instructions (1 KiB each) per chunk
+    constexpr int UTOT = UINSTR * 1024 / 8;               // float2-sized slots reserved per weight buffer
     constexpr int UPW = (UINSTR + NW - 1) / NW;           // per wave
     constexpr int NJ = (4 * XT + NTH - 1) / NTH;          // staged samples per thread per channel
 
@@ -147,7 +151,7 @@ wino_conv_kernel(const WinoParams p) {
     __builtin_assume(wave >= 0 && wave < NW);
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)px, 0, (int)((int64_t)c_in * L * 4), WINO_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t urs =
-        __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, (int)((int64_t)3 * G * c_in * c_out * 4), WINO_RSRC_FLAGS);
+        __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, (int)((int64_t)3 * G * (c_in / 2) * c_out * UPAIR), WINO_RSRC_FLAGS);
     const int L4 = (int)(L * 4);
     unsigned goff[NJ];    // byte offset of the sample inside a channel row (clamped into [0, L))
     int loff[NJ];         // float2 offset inside a channel pair's 4 rows: ii * XTS + tile (lanes with nothing to stage: a pad column)
@@ -172,9 +176,11 @@ wino_conv_kernel(const WinoParams p) {
 #pragma unroll
     for (int i = 0; i < UPW; ++i) {
         const int o = (wave + NW * i) * 1024 + 16 * lane;
-        const int row = o / (BM * 8), within = o - row * (BM * 8);
+        int row = o / (BM * UPAIR);
+        const int within = o - row * (BM * UPAIR);
+        if (row >= UROWS) row = UROWS - 1;             // overhang of the last piece (bf16, odd row counts): a harmless repeat
         const int tap = row / CP, cp = row - tap * CP;
-        woff[i] = (unsigned)(((tap * (c_in / 2) + cp) * c_out) * 8 + within);
+        woff[i] = (unsigned)(((tap * (c_in / 2) + cp) * c_out) * UPAIR + within);
     }
 
     f32x2 xr[CP * NJ];
@@ -204,7 +210,7 @@ wino_conv_kernel(const WinoParams p) {
         }
     };
     auto dma_u = [&](int buf, int c) __attribute__((always_inline)) {
-        const int s0 = (c * CP * c_out + m0) * 8;         // byte offset of the chunk's first weight row, this block's channels
+        const int s0 = (c * CP * c_out + m0) * UPAIR;     // byte offset of the chunk's first weight row, this block's channels
         char *dst = reinterpret_cast<char *>(us + buf * UTOT);
 #pragma unroll
         for (int i = 0; i < UPW; ++i) {
@@ -231,6 +237,7 @@ wino_conv_kernel(const WinoParams p) {
         // buffer buf ^ 1 was last read in iteration c - 1 and every wave has passed that iteration's barrier
         if (!(DBG & 4) && c + 1 < n_chunks) dma_u(buf ^ 1, c + 1);
         const f32x2 *ua = us + buf * UTOT + wm * 32 + l31;
+        const unsigned *ua16 = reinterpret_cast<const unsigned *>(us + buf * UTOT) + wm * 32 + l31;
         const f32x2 *xb = xs + buf * XTOT + col - MLO * d;
         // software pipeline over the S = G * CIC / 4 double k-steps: the 6 input pairs and 3 tap pairs of step s + 1 are
         // read from LDS before the transforms + 12 matrix instructions of step s are issued
@@ -245,7 +252,14 @@ wino_conv_kernel(const WinoParams p) {
                 dd[n] = xb[(cpi * 4 + (sh & 3)) * XTS + (sh >> 2) * d];
             }
 #pragma unroll
-            for (int kt = 0; kt < 3; ++kt) ww[kt] = ua[((3 * g + kt) * CP + cpi) * BM];
+            for (int kt = 0; kt < 3; ++kt) {
+                if constexpr (WB16) {
+                    const unsigned bits = ua16[((3 * g + kt) * CP + cpi) * BM];
+                    ww[kt] = f32x2{__uint_as_float(bits << 16), __uint_as_float(bits & 0xffff0000u)};
+                } else {
+                    ww[kt] = ua[((3 * g + kt) * CP + cpi) * BM];
+                }
+            }
         };
         fetch(0, dv[0], wv[0]);
 #pragma unroll
@@ -406,34 +420,35 @@ wino_conv_kernel(const WinoParams p) {
     }
 }
 
-template <int KW, int WM, int WN, int CIC>
+template <int KW, int WM, int WN, int CIC, bool WB16 = false>
 static size_t wino_lds_bytes() {
     constexpr int G = (KW + 2) / 3, C0 = (KW - 1) / 2;
     constexpr int SMIN = -C0, SMAX = 5 + 3 * (G - 1) - C0;
     constexpr int MLO = SMIN >= 0 ? SMIN / 4 : -((-SMIN + 3) / 4), MHI = SMAX / 4;
     constexpr int XT = 32 * WN + (MHI - MLO) * WINO_MAX_DIL;
     constexpr int XTS = ((XT + 31) / 32) * 32 + 8;
-    const size_t chunks = (size_t)2 * (3 * G * (CIC / 2) * 32 * WM + (CIC / 2) * 4 * XTS) * 2 * sizeof(float);
+    const size_t upieces = ((size_t)3 * G * (CIC / 2) * 32 * WM * (WB16 ? 4 : 8) + 1023) / 1024;
+    const size_t chunks = 2 * (upieces * 1024 + (size_t)(CIC / 2) * 4 * XTS * 2 * sizeof(float));
     const size_t out_tile = (size_t)32 * WM * (4 * 32 * WN + 4) * sizeof(float);   // the dilated epilogue's transposed tile
     return chunks > out_tile ? chunks : out_tile;
 }
 
-template <int KW, int WM, int WN, int CIC, int DBG = 0>
+template <int KW, int WM, int WN, int CIC, int DBG = 0, bool WB16 = false>
 static int wino_launch_cfg(WinoParams p, hipStream_t stream) {
     constexpr int BNT = 32 * WN;
     p.sb_per_block = BNT / p.dil;
     p.n_sb = ceil_div(p.L, (int64_t)4 * p.dil);
-    const size_t lds = wino_lds_bytes<KW, WM, WN, CIC>();
+    const size_t lds = wino_lds_bytes<KW, WM, WN, CIC, WB16>();
     static std::once_flag once;
     static hipError_t err = hipSuccess;
     std::call_once(once, [lds] {
-        err = hipFuncSetAttribute((const void *)wino_conv_kernel<KW, WM, WN, CIC, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        err = hipFuncSetAttribute((const void *)wino_conv_kernel<KW, WM, WN, CIC, DBG, WB16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
     if (err != hipSuccess) return fail("wino conv: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(err));
     p.n_tile_blocks = (int)ceil_div(p.n_sb, p.sb_per_block);
     const int n_m = p.c_out / (32 * WM);
     dim3 grid((unsigned)(ceil_div(p.n_tile_blocks, 8) * 8 * n_m), 1, (unsigned)p.batch);
-    hipLaunchKernelGGL((wino_conv_kernel<KW, WM, WN, CIC, DBG>), grid, dim3(64 * WM * WN), lds, stream, p);
+    hipLaunchKernelGGL((wino_conv_kernel<KW, WM, WN, CIC, DBG, WB16>), grid, dim3(64 * WM * WN), lds, stream, p);
     RVC_LAUNCH_CHECK();
     return 0;
 }
@@ -455,6 +470,10 @@ static int wino_launch_kw(const WinoParams &p, hipStream_t stream) {
             default: break;
         }
     }
+    if (p.u_bf16) {
+        if (p.c_out % 64 == 0) return wino_launch_cfg<KW, 2, 2, CIC, 0, true>(p, stream);
+        if (p.c_out % 32 == 0) return wino_launch_cfg<KW, 1, 4, CIC, 0, true>(p, stream);
+    }
     if (p.c_out % 64 == 0) return wino_launch_cfg<KW, 2, 2, CIC>(p, stream);
     if (p.c_out % 32 == 0) return wino_launch_cfg<KW, 1, 4, CIC>(p, stream);
     return fail("wino conv: c_out %d is not a multiple of 32", p.c_out);
@@ -465,15 +484,15 @@ bool wino_fits(int c_in, int c_out, int64_t L) { return (int64_t)c_in * L < ((in
 
 bool wino_supported(int k, int dil) { return (k == 3 || k == 7 || k == 11) && dil >= 1 && dil <= WINO_MAX_DIL; }
 
-int launch_wino_conv(const float *x, const float *u, const float *bias, const float *res, const float *accin, float *y, int batch,
-                     int c_in, int c_out, int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream) {
+int launch_wino_conv(const float *x, const void *u, bool u_bf16, const float *bias, const float *res, const float *accin, float *y,
+                     int batch, int c_in, int c_out, int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream) {
     if (!wino_supported(k, dil)) return fail("wino conv: unsupported kernel size %d / dilation %d", k, dil);
     if (!(slope >= 0.f && slope <= 1.f)) return fail("wino conv: leaky slope %g outside [0, 1]", (double)slope);
     if (c_in % 8 || c_out % 32) return fail("wino conv: %d -> %d channels unsupported (multiples of 8 / 32)", c_in, c_out);
     if (!wino_fits(c_in, c_out, L)) return fail("wino conv: %d x %lld samples exceed the 2 GiB buffer addressing of the fast form", c_in, (long long)L);
     if (L <= 0 || batch <= 0) return 0;
     WinoParams p;
-    p.x = x; p.u = u; p.bias = bias; p.res = res; p.accin = accin; p.y = y;
+    p.x = x; p.u = u; p.u_bf16 = u_bf16; p.bias = bias; p.res = res; p.accin = accin; p.y = y;
     p.c_in = c_in; p.c_out = c_out; p.L = L; p.dil = dil; p.slope = slope; p.out_scale = out_scale; p.batch = batch;
     switch (k) {
         case 3: return wino_launch_kw<3>(p, stream);
@@ -490,6 +509,14 @@ void wino_pack_host(const float *w_host, int c_out, int c_in, int k, std::vector
         for (int ci = 0; ci < c_in; ++ci)
             for (int co = 0; co < c_out; ++co)
                 (*out)[(((size_t)tap * (c_in / 2) + ci / 2) * c_out + co) * 2 + (ci & 1)] = w_host[((size_t)co * c_in + ci) * k + tap];
+}
+
+// the same slab with each channel pair as one word of two bf16 (round to nearest even; exact for bf16-valued weights)
+void wino_pack_host_bf16(const float *w_host, int c_out, int c_in, int k, std::vector<uint32_t> *out) {
+    std::vector<float> f;
+    wino_pack_host(w_host, c_out, c_in, k, &f);
+    out->resize(f.size() / 2);
+    for (size_t i = 0; i < out->size(); ++i) (*out)[i] = (uint32_t)bf16_rne(f[2 * i]) | ((uint32_t)bf16_rne(f[2 * i + 1]) << 16);
 }
 
 int wino_pack_weight(const float *w_host, int c_out, int c_in, int k, float **out_dev) {
@@ -522,6 +549,6 @@ extern "C" int rvc_conv1d_wino_forward(const float *x_dev, const float *u_dev, c
                                        const float *acc_dev, float *y_dev, int batch, int c_in, int c_out, int64_t length, int k,
                                        int dilation, float slope_in, float out_scale, void *stream) {
     if (!x_dev || !u_dev || !y_dev) return fail("rvc_conv1d_wino_forward: null pointer");
-    return launch_wino_conv(x_dev, u_dev, bias_dev, res_dev, acc_dev, y_dev, batch, c_in, c_out, length, k, dilation, slope_in,
+    return launch_wino_conv(x_dev, u_dev, false, bias_dev, res_dev, acc_dev, y_dev, batch, c_in, c_out, length, k, dilation, slope_in,
                             out_scale, (hipStream_t)stream);
 }

@@ -11,6 +11,9 @@ cp /tmp/pb1/b_kernel_stats.csv $O/bench_kernel_stats_inflight1.csv
 rocprofv3 --kernel-trace --output-format csv -d /tmp/pp -o t -- python3 $R/tools/profile_pipeline.py > $O/profile_pipeline.log 2>&1
 python3 $R/tools/summarize_trace.py /tmp/pp/t_kernel_trace.csv 0 all lastgap > $O/pipeline_kernels.txt
 rocprofv3 --kernel-trace --output-format csv -d /tmp/d1 -o t -- python3 $R/tools/profile_decoder.py >/dev/null 2>&1; python3 $R/tools/summarize_trace.py /tmp/d1/t_kernel_trace.csv > $O/decoder_kernels_nsf.txt
+python3 $R/tools/bench_conv.py > $O/conv_shapes.txt 2>&1
+python3 $R/tools/bench_conv2d.py 2>&1 | grep -- "->" > $O/conv2d_shapes.txt
+(cd $R && DBGS="0 1 2 3 7 15 32 47" bash tools/ablate_wino.sh) > $O/wino_ablation.txt 2>&1
 for c in 2 1 4 5; do python3 - <<PY
 import json
 d = json.loads([l for l in open("$O/bench_cfg$c.json") if l.startswith("{")][-1])
