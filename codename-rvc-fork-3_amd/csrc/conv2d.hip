@@ -1,4 +1,4 @@
-// K9 -- 3x3 / 1x1 conv2d of RMVPE's U-Net (RMVPE.py:13-287: ConvBlockRes and the shortcut convs) as an fp32 implicit GEMM
+// K10 -- 3x3 / 1x1 conv2d of RMVPE's U-Net (RMVPE.py:13-287: ConvBlockRes and the shortcut convs) as an fp32 implicit GEMM
 // on the matrix cores, with the folded BatchNorm bias, the ReLU and the block's residual in the epilogue.
 //
 // The U-Net runs ~117 3x3 convs of 1.77 GFLOP each over [C][T][128 >> level] maps whose channel count doubles as the map

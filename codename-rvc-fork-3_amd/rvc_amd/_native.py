@@ -523,7 +523,7 @@ def conv1d_wino_forward(x, u_packed, bias, c_out, k, dilation=1, slope_in=1.0, r
     return y
 
 
-# ---- K9: conv2d 3x3 / 1x1 of the RMVPE U-Net -------------------------------------------------------------
+# ---- K10: conv2d 3x3 / 1x1 of the RMVPE U-Net -------------------------------------------------------------
 def conv2d_pack_weight(w: torch.Tensor, device) -> torch.Tensor:
     """torch conv2d weight [C_out, C_in, kh, kw] (3x3 or 1x1) -> packed taps in HBM."""
     w = w.detach().float().cpu().contiguous()

@@ -67,7 +67,7 @@ class RMVPE0Predictor:
                 w["gru." + n + sfx] = sd["fc.0.gru." + n + sfx]
         w["fc.w"], w["fc.b"] = sd["fc.1.weight"], sd["fc.1.bias"]
         self.w = {k: v.to(self.device).contiguous() for k, v in w.items()}
-        # K9 (conv2d.hip) taps of every 3x3 / 1x1 block conv whose input channel count the kernel takes (all but the 1 -> 16 one)
+        # K10 (conv2d.hip) taps of every 3x3 / 1x1 block conv whose input channel count the kernel takes (all but the 1 -> 16 one)
         self.wp = {}
         if self.device.type == "cuda" and os.environ.get("RVC_NATIVE_UNET", "1") != "0":
             from rvc_amd import _native

@@ -296,7 +296,7 @@ int rvc_index_broadcast(rvc_comm *comm, void *buf_dev, size_t bytes, int root, v
  * (a trailing 1-3 bytes are zero-extended into a last word).  Computed in HBM: the index never crosses PCIe. */
 int rvc_checksum64(const void *buf_dev, size_t bytes, uint64_t *out2_dev, void *stream);
 
-/* ---- K9: conv2d 3x3 (padding 1) / 1x1, stride 1, of RMVPE's U-Net blocks (RMVPE.py:13-287) ---------------------------- *
+/* ---- K10: conv2d 3x3 (padding 1) / 1x1, stride 1, of RMVPE's U-Net blocks (RMVPE.py:13-287) ---------------------------- *
  * y = act(conv(x) + bias) + res  with act = ReLU when relu != 0 -- ConvBlockRes with its BatchNorms folded into the weights
  * (eval mode): conv -> BN -> ReLU, then the skip path added after the activation.  fp32 on the matrix cores, k-ordered
  * accumulation; deep levels split K over several workgroups and sum the partials in a fixed order (bit-reproducible).

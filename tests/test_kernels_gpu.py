@@ -85,7 +85,7 @@ def test_conv1d_winograd_matches_float64(native, dev, c_in, c_out, k, dil, lengt
     (16, 32, 20, 64, 1, 1), (256, 512, 17, 4, 1, 1), (64, 32, 33, 64, 3, 1),
 ])
 def test_conv2d_matches_float64(native, dev, c_in, c_out, h, w, ks, batch):
-    """K9 (conv2d.hip), the conv of RMVPE's ConvBlockRes (RMVPE.py:13-60) with folded BatchNorm bias, ReLU and the skip path:
+    """K10 (conv2d.hip), the conv of RMVPE's ConvBlockRes (RMVPE.py:13-60) with folded BatchNorm bias, ReLU and the skip path:
     every level's (channels, row length) pair of the U-Net, heights that are not a multiple of the block's rows, the 16- and
     3-channel outputs (padded to 32 rows), the K-split deep levels, 1x1 shortcuts -- against F.conv2d in float64."""
     g = torch.Generator().manual_seed(c_in * 100 + c_out + h + w)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""RMVPE U-Net conv shapes at the cfg-2 length (3232 frames): native conv2d (K9) vs torch / MIOpen, median batch."""
+"""RMVPE U-Net conv shapes at the cfg-2 length (3232 frames): native conv2d (K10) vs torch / MIOpen, median batch."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "codename-rvc-fork-3_amd")]
