@@ -340,11 +340,15 @@ def main():
     else:
         line["cpu_baseline"] = None
 
-    print(json.dumps(line), flush=True)
+    # tear down first, report last: the JSON line is the LAST thing on stdout (RCCL / the runtime may print on C stdout while
+    # communicators go down; distributed._c_stdout_to_stderr keeps that off this stream)
     barrier()
-    D.destroy_native_comm()
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    with D._c_stdout_to_stderr():
+        D.destroy_native_comm()
+        if world > 1:
+            torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev):

@@ -14,6 +14,8 @@ that branch is chosen by where the caller's tensor lives, never as a fallback fo
 """
 from __future__ import annotations
 
+import contextlib
+import ctypes
 import os
 import socket
 import subprocess
@@ -67,6 +69,24 @@ _comm = None          # librvc_amd RCCL communicator of this process (one per jo
 _last_broadcast = {}  # facts of the last broadcast_index call, for the bench report
 
 
+@contextlib.contextmanager
+def _c_stdout_to_stderr():
+    """RCCL prints a version banner on C stdout when its first communicator comes up (RCCL 2.26: always).  A report line
+    on stdout -- bench.py's one JSON line -- must not share the stream with it, and being C-buffered the banner would even
+    land AFTER a later Python print.  While the communicator is created, file descriptor 1 points at stderr."""
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush()
+    libc.fflush(None)
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        libc.fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def native_comm():
     """The job-wide RCCL communicator behind the C ABI, created on first use: rank 0 draws the id, torch.distributed
     hands its 128 bytes round, every rank joins on its own GPU."""
@@ -86,7 +106,8 @@ def native_comm():
             ident_dev = ident.cuda()
             dist.broadcast(ident_dev, 0)
             ident = ident_dev.cpu()
-    _comm = _native.Comm(bytes(ident.numpy().tobytes()), world, rank)
+    with _c_stdout_to_stderr():
+        _comm = _native.Comm(bytes(ident.numpy().tobytes()), world, rank)
     return _comm
 
 
