@@ -310,7 +310,7 @@ def main():
     }
 
     if not args.no_rooflines:
-        line.update(rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev))
+        line.update(rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev, audios[0]))
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample, 1 warm-up + median of 3 ----
     if world == 1 and not args.no_cpu_baseline:
@@ -351,7 +351,7 @@ def main():
         print(json.dumps(line), flush=True)
 
 
-def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev):
+def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev, utterance):
     """Per-kernel legs (rank 0, after the timed region): dominant conv symbol, whole vocoder, kNN."""
     res = {}
     sr = cfg["sr"]
@@ -425,7 +425,12 @@ def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev):
     if index_dev is not None:
         idx = vc.vc._preset_index
         n_rows = int(index_dev.shape[0])
-        q = index_dev[torch.randint(0, n_rows, (F_,), device=dev)] + 0.03 * torch.randn(F_, 768, device=dev)
+        # the queries of one of the timed utterances (HuBERT features of the synthetic clip), not a synthetic stand-in
+        vc.vc.debug_taps = {}
+        vc.convert_batch([utterance], inflight=1, index_path="", index_rate=cfg["index_rate"], protect=0.5, sid=0)
+        q = vc.vc.debug_taps["knn_queries"].clone()
+        vc.vc.debug_taps = None
+        assert q.shape == (F_, 768), q.shape
         idx.search_device(q)
         reps = 20 if n_rows <= 200_000 else 3
         e0.record()

@@ -349,6 +349,8 @@ class Pipeline:
         if not isinstance(index, FeatureIndex):  # a foreign index object with the faiss API: wrap its vectors once
             index = FeatureIndex(big_npy, self.device)
         q = feats[0].contiguous()
+        if isinstance(getattr(self, "debug_taps", None), dict):   # tests / bench.py's kNN leg: the queries of this utterance
+            self.debug_taps["knn_queries"] = q
         d2, ids = index.search_device(q, 8)
         return _native.knn_blend(index.vectors, q, d2, ids, float(index_rate)).unsqueeze(0)
 
