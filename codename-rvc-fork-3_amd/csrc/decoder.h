@@ -54,6 +54,12 @@ struct Stage {
     int vk = 0, vk_rows = 0;      // folded noise-conv rows: valid, padded to a multiple of 8
     int64_t S = 0, P = 0;         // V[k][q] = har[q*S + k - P]
     DevBuf w, b;                  // [taps][c_in + vk_rows][rate * c_out], [c_out]
+    // nc_rows > 0: the noise conv is NOT folded into the upsampler's GEMM (w has c_in rows per tap) but added by its own
+    // launch, y += W_nc V2 with V2[k][t] = har[t * nc_stride + k - nc_pad].  Folding it costs (rate - 1) * nc_stride + nc_k
+    // GEMM rows per tap for nc_k useful ones: 520 against 512 real input channels in the first stage of the 48 k vocoder
+    // (half of that launch's matrix instructions multiplied zeros), 8-48 rows in the later stages.
+    int nc_rows = 0;              // nc_k padded to a multiple of 8
+    DevBuf nc_w;                  // [1][nc_rows][c_out]
     std::vector<ConvW> c1, c2;    // [n_res_kernels * n_res_dilations]
 };
 

@@ -7,6 +7,8 @@
 // NSF: hifigan_nsf.py:173-207 + hifigan.py:156-228;  MRF: hifigan_mrf.py:339-366, 129-175.
 // All dense contractions go through conv.hip (fp32 MFMA implicit GEMM); this file holds the small
 // element-wise kernels, the weight repacks and the schedule.
+#include <stdlib.h>
+
 #include "decoder.h"
 
 namespace rvc {
@@ -486,6 +488,13 @@ extern "C" int rvc_decoder_finalize(rvc_decoder *d) {
         s.vk_rows = (s.vk + 7) / 8 * 8;
         s.S = (int64_t)s.rate * s.nc_stride;
         s.P = (int64_t)s.pad * s.nc_stride + s.nc_pad;
+        static const int nc_sep_env = getenv("RVC_NC_SEPARATE") ? atoi(getenv("RVC_NC_SEPARATE")) : 1;
+        const bool nc_separate = nc_sep_env && s.vk_rows * 2 >= s.c_in;   // folding would at least 1.5x the upsampler's GEMM
+        if (nc_separate) {
+            s.nc_rows = (s.nc_k + 7) / 8 * 8;
+            s.vk = 0;
+            s.vk_rows = 0;
+        }
 
         const std::string up = (mrf ? "upsamples." : "ups.") + std::to_string(i);
         const std::string nc = "noise_convs." + std::to_string(i);
@@ -519,6 +528,12 @@ extern "C" int rvc_decoder_finalize(rvc_decoder *d) {
                     packed[((size_t)tp0 * ctot + s.c_in + kq) * m_total + ph * s.c_out + co] = nw->data[(size_t)co * s.nc_k + k];
             }
         if (s.w.upload(packed)) return 1;
+        if (s.nc_rows) {
+            std::vector<float> ncw((size_t)s.nc_rows * s.c_out, 0.f);
+            for (int k = 0; k < s.nc_k; ++k)
+                for (int co = 0; co < s.c_out; ++co) ncw[(size_t)k * s.c_out + co] = nw->data[(size_t)co * s.nc_k + k];
+            if (s.nc_w.upload(ncw)) return 1;
+        }
         std::vector<float> bias(s.c_out);
         for (int co = 0; co < s.c_out; ++co) bias[co] = ub->data[co] + nb->data[co];
         if (s.b.upload(bias)) return 1;
@@ -586,6 +601,7 @@ Layout make_layout(const rvc_decoder *d, int batch, int64_t T) {
         const int64_t nq = len + 1;
         max_v = std::max<int64_t>(max_v, (int64_t)s.vk_rows * nq);
         len = (len - 1) * s.rate - 2 * s.pad + s.ksize + s.opad;
+        max_v = std::max<int64_t>(max_v, (int64_t)s.nc_rows * len);
         max_cl = std::max<int64_t>(max_cl, (int64_t)s.c_out * len);
     }
     l.V = c.take((size_t)batch * max_v * 4);
@@ -696,14 +712,16 @@ extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const flo
         Stage &s = d->stages[i];
         const int64_t nq = len + 1;
         const int64_t len_out = (len - 1) * s.rate - 2 * s.pad + s.ksize + s.opad;
-        hipLaunchKernelGGL(unfold_src_kernel, dim3((unsigned)ceil_div(nq, 256), s.vk_rows, batch), dim3(256), 0, stream, har, L,
-                           s.S, s.P, s.vk, s.vk_rows, nq, V);
-        RVC_LAUNCH_CHECK();
+        if (s.vk_rows) {
+            hipLaunchKernelGGL(unfold_src_kernel, dim3((unsigned)ceil_div(nq, 256), s.vk_rows, batch), dim3(256), 0, stream, har, L,
+                               s.S, s.P, s.vk, s.vk_rows, nq, V);
+            RVC_LAUNCH_CHECK();
+        }
         float *X = buf[1], *Y = buf[2], *T1 = buf[3];
         {
             ConvParams p;
             p.x1 = cur; p.c1 = s.c_in; p.slope1 = 0.1f; p.x1_bstride = (int64_t)s.c_in * len;
-            p.x2 = V; p.c2 = s.vk_rows; p.slope2 = 1.f; p.x2_bstride = (int64_t)s.vk_rows * nq;
+            if (s.vk_rows) { p.x2 = V; p.c2 = s.vk_rows; p.slope2 = 1.f; p.x2_bstride = (int64_t)s.vk_rows * nq; }
             // both sources are indexed by the GEMM column q; x rows are valid on [0, len), V rows on [0, nq):
             // V is stored with row length nq, x with row length len -> give x its own staging length
             p.l_in = len;
@@ -713,6 +731,17 @@ extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const flo
             p.kw = s.taps; p.dil = 1; p.padl = s.taps - 1;
             p.up_stride = s.rate; p.up_pad = s.pad; p.batch = batch;
             p.l_in2 = nq;
+            if (launch_conv(p, stream)) return 1;
+        }
+        if (s.nc_rows) {   // the noise conv on its own: y += W_nc V2 (hifigan_nsf.py:190-191), bias already in the upsampler's
+            hipLaunchKernelGGL(unfold_src_kernel, dim3((unsigned)ceil_div(len_out, 256), s.nc_rows, batch), dim3(256), 0, stream, har,
+                               L, (int64_t)s.nc_stride, (int64_t)s.nc_pad, s.nc_k, s.nc_rows, len_out, V);
+            RVC_LAUNCH_CHECK();
+            ConvParams p;
+            p.x1 = V; p.c1 = s.nc_rows; p.slope1 = 1.f; p.x1_bstride = (int64_t)s.nc_rows * len_out; p.l_in = len_out;
+            p.w = s.nc_w.p; p.accin = X; p.y = X; p.y_bstride = (int64_t)s.c_out * len_out;
+            p.m_total = s.c_out; p.c_out = s.c_out; p.n_cols = len_out; p.l_out = len_out;
+            p.kw = 1; p.dil = 1; p.padl = 0; p.batch = batch;
             if (launch_conv(p, stream)) return 1;
         }
         len = len_out;
