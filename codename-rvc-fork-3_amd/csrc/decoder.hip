@@ -2,10 +2,10 @@
 //   source module (sine + noise excitation)  -> har_source [B, L]
 //   conv_pre (+ speaker conditioning folded into a per-utterance bias)
 //   per stage: leaky -> ConvTranspose1d (polyphase GEMM) with noise_conv(har_source) folded in as extra
-//              input rows -> three parallel dilated ResBlocks, mean
+//              input rows (first stage: as its own launch, see Stage::nc_rows) -> three parallel dilated ResBlocks, mean
 //   leaky(0.01) -> conv_post -> tanh
 // NSF: hifigan_nsf.py:173-207 + hifigan.py:156-228;  MRF: hifigan_mrf.py:339-366, 129-175.
-// All dense contractions go through conv.hip (fp32 MFMA implicit GEMM); this file holds the small
+// All dense contractions go through conv.hip / wino.hip (fp32 MFMA; the ResBlock layers in Winograd form); this file holds the small
 // element-wise kernels, the weight repacks and the schedule.
 #include <stdlib.h>
 
