@@ -110,8 +110,12 @@ class Synthesizer:
             shapes += [(b, ch, length)] * (2 * len(self.resblock_kernel_sizes))
         return shapes
 
-    def _draw(self, noise, b, t):
-        L = t * self.upp
+    def _draw(self, noise, b, t, t_dec=None):
+        """Every random tensor of one infer call, in the reference's order.  ``t_dec``: frames the vocoder sees when
+        ``rate`` cuts the head off (synthesizers.py:247-251) -- z is drawn for all ``t`` frames BEFORE the cut, the
+        vocoder's draws happen after it, at the shorter length."""
+        t_dec = t if t_dec is None else t_dec
+        L = t_dec * self.upp
         dim = 9 if self.vocoder == "MRF HiFi-GAN" else 1
         refine = self.vocoder == "RefineGAN"
         dev = self.device
@@ -127,13 +131,13 @@ class Synthesizer:
                 src_randn = torch.randn(b, L, dim)                            # hifigan_mrf.py:172 / refinegan.py:258
             out = {"z": z.to(dev), "src_rand": src_rand.to(dev), "src_randn": src_randn.to(dev)}
             if refine:
-                out["adain_randn"] = torch.cat([torch.randn(*sh).reshape(-1) for sh in self._adain_shapes(b, t)]).to(dev)
+                out["adain_randn"] = torch.cat([torch.randn(*sh).reshape(-1) for sh in self._adain_shapes(b, t_dec)]).to(dev)
             return out
         out = {"z": torch.randn(b, self.inter_channels, t, device=dev),
                "src_rand": torch.rand(b, dim, device=dev),
                "src_randn": torch.randn(b, L, dim, device=dev)}
         if refine:
-            out["adain_randn"] = torch.randn(sum(int(np.prod(sh)) for sh in self._adain_shapes(b, t)), device=dev)
+            out["adain_randn"] = torch.randn(sum(int(np.prod(sh)) for sh in self._adain_shapes(b, t_dec)), device=dev)
         return out
 
     @torch.no_grad()
@@ -148,13 +152,12 @@ class Synthesizer:
                                            n_layers=self.n_layers, kernel_size=self.kernel_size,
                                            lengths_host=phone_lengths_host)
         b, _, t = m_p.shape
-        nz = self._draw(noise, b, t)
+        head = int(t * (1.0 - rate.item())) if rate is not None else 0   # synthesizers.py:247-251
+        nz = self._draw(noise, b, t, t - head)
         z_p = (m_p + torch.exp(logs_p) * nz["z"] * 0.66666) * x_mask
-        if rate is not None:  # synthesizers.py:247-251
-            head = int(z_p.shape[2] * (1.0 - rate.item()))
+        if rate is not None:
             z_p, x_mask = z_p[:, :, head:], x_mask[:, :, head:]
             nsff0 = nsff0[:, head:]
-            nz["src_randn"] = nz["src_randn"][:, head * self.upp:]
         full = phone_lengths_host is not None and rate is None and all(int(n) == t for n in phone_lengths_host)
         z = flow_reverse(w, z_p, x_mask, g, half=self.inter_channels // 2, hidden=self.hidden_channels, full=full)
         o = self.dec.forward((z * x_mask).contiguous(), nsff0.float().contiguous(), g[:, :, 0].contiguous(),

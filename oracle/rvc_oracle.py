@@ -744,8 +744,9 @@ def decoder_refine(w, mel: Tensor, f0: Tensor, g: Tensor, rates, sr: int, noise,
 
 
 def synthesizer_infer(cpt: dict, phone: Tensor, phone_lengths: Tensor, pitch: Tensor, nsff0: Tensor, sid: Tensor,
-                      noise=None, w=None, taps=None):
-    """Synthesizer.infer, synthesizers.py:223-260 (rate=None).  Returns (o, x_mask, (z, z_p, m_p, logs_p))."""
+                      noise=None, w=None, taps=None, rate=None):
+    """Synthesizer.infer, synthesizers.py:223-260; `rate` (a float) drops the head of z_p / x_mask / nsff0 before the flow
+    and the vocoder (:247-251).  Returns (o, x_mask, (z, z_p, m_p, logs_p))."""
     noise = noise or TorchNoise()
     if w is None:
         w = fold_weight_norm(cpt["weight"])
@@ -756,6 +757,9 @@ def synthesizer_infer(cpt: dict, phone: Tensor, phone_lengths: Tensor, pitch: Te
         g = F.embedding(sid, w["emb_g.weight"]).unsqueeze(-1)
         m_p, logs_p, x_mask = text_encoder(w, phone, pitch, phone_lengths)
         z_p = (m_p + torch.exp(logs_p) * noise.randn(*m_p.shape) * 0.66666) * x_mask
+        if rate is not None:   # synthesizers.py:247-251
+            head = int(z_p.shape[2] * (1.0 - float(rate)))
+            z_p, x_mask, nsff0 = z_p[:, :, head:], x_mask[:, :, head:], nsff0[:, head:]
         z = flow_reverse(w, z_p, x_mask, g)
         if vocoder == "MRF HiFi-GAN":
             o = decoder_mrf(w, z * x_mask, nsff0, g, rates, ksizes, sr, noise, taps)

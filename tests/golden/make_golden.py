@@ -218,6 +218,28 @@ class CfgSmall:
     x_pad, x_query, x_center, x_max, device = 1, 1, 3, 4, "cpu"
 
 
+def rate_case():
+    """11. Synthesizer.infer with `rate` (synthesizers.py:247-251): the head of z_p / x_mask / nsff0 is cut off before the
+    flow and the vocoder -- the reference's partial-resynthesis argument.  NSF 48 k and 40 k, rate 0.6 and 0.25."""
+    ref_feats = np.load(os.path.join(HERE, "ref_feats.npy"))
+    ref_f0c = np.load(os.path.join(HERE, "ref_f0c.npy"))
+    ref_f0f = np.load(os.path.join(HERE, "ref_f0f.npy"))
+    T = 64
+    phone = torch.from_numpy(np.repeat(ref_feats, 2, axis=0)[:T]).unsqueeze(0)
+    pitch = torch.from_numpy(ref_f0c[:T].astype(np.int64)).unsqueeze(0)
+    pitchf = torch.from_numpy(ref_f0f[:T]).float().unsqueeze(0)
+    out = {}
+    for tag, sr, rate in (("nsf48", 48000, 0.6), ("nsf40", 40000, 0.25)):
+        net = build_net(S.make_synth_checkpoint(sr, "HiFi-GAN", seed=0))
+        torch.manual_seed(4321)
+        with torch.no_grad():
+            o, x_mask, (z, z_p, m_p, logs_p) = net.infer(phone, torch.tensor([T]), pitch, pitchf, torch.tensor([5]),
+                                                         rate=torch.tensor(rate))
+        out.update({f"o_{tag}": o[0, 0].numpy(), f"z_{tag}": z[0].numpy(), f"rate_{tag}": np.float64(rate)})
+        print(f"    rate {rate} {tag}: {z.shape[2]} of {T} frames kept, out rms {o.pow(2).mean().sqrt().item():.4f}")
+    save("synth_rate", seed=np.int64(4321), sid=np.int64(5), T=np.int64(T), **out)
+
+
 def multiseg(hub=None, big=None):
     """10. multi-segment Pipeline.pipeline: 3 segments cut at quiet points, per-segment HuBERT + Synthesizer noise draws
     from ONE seeded CPU generator stream, crops, concatenation (pipeline.py:563-577, 614-681)."""
@@ -254,6 +276,9 @@ def multiseg(hub=None, big=None):
 if __name__ == "__main__":
     if "--only-multiseg" in sys.argv:
         multiseg()
+    elif "--only-rate" in sys.argv:
+        rate_case()
     else:
         main()
+        rate_case()
     shutil.rmtree(scratch, ignore_errors=True)

@@ -143,6 +143,25 @@ def test_synthesizer_infer(tag, sr, voc, ref_inputs):
 
 
 @pytest.mark.parametrize("tag,sr", [("nsf48", 48000), ("nsf40", 40000)])
+def test_synthesizer_infer_rate(tag, sr, ref_inputs):
+    """`rate` (synthesizers.py:247-251) against the reference's own output (make_golden.py --only-rate)."""
+    g = load_golden("synth_rate")
+    feats, f0c, f0f = ref_inputs
+    T = int(g["T"])
+    phone = torch.from_numpy(np.repeat(feats, 2, axis=0)[:T]).unsqueeze(0)
+    pitch = torch.from_numpy(f0c[:T].astype(np.int64)).unsqueeze(0)
+    pitchf = torch.from_numpy(f0f[:T]).float().unsqueeze(0)
+    torch.manual_seed(int(g["seed"]))
+    o, _, (z, _, _, _) = O.synthesizer_infer(S.make_synth_checkpoint(sr, "HiFi-GAN", seed=0), phone, torch.tensor([T]), pitch, pitchf,
+                                             torch.tensor([int(g["sid"])]), rate=float(g["rate_" + tag]))
+    assert z.shape[2] == g["z_" + tag].shape[1] < T
+    assert np.abs(z[0].numpy() - g["z_" + tag]).max() <= 1e-4
+    out = o[0, 0].numpy()
+    assert out.shape == g["o_" + tag].shape
+    assert rms(out - g["o_" + tag]) <= 2e-5, rms(out - g["o_" + tag])
+
+
+@pytest.mark.parametrize("tag,sr", [("nsf48", 48000), ("nsf40", 40000)])
 def test_whole_pipeline(tag, sr):
     g = load_golden("pipeline_" + tag)
     cpt = S.make_synth_checkpoint(sr, "HiFi-GAN", seed=0)
