@@ -7,6 +7,8 @@
 // recurrent weights stream from L2 (786 KB, resident) as 16-byte loads, two barriers per step.
 //
 // thread (jq, kq), jq in [0,192), kq in [0,4): partial dot products of gate rows 4jq..4jq+3 over k in [64kq, 64kq+64)
+#include <stdlib.h>
+
 #include <atomic>
 
 #include "common.h"
@@ -115,8 +117,20 @@ bigru_mc_kernel(const float *__restrict__ gi, const float *__restrict__ whhT, co
     __shared__ float g_s[GRU_ROWS];
     __shared__ int dead_s;
     const int tid = threadIdx.x;
-    const int c = blockIdx.x % GRU_CUS;
-    const int dir = blockIdx.x / GRU_CUS;
+    // Workgroups go round-robin over the 8 XCDs.  The four workgroups of one direction exchange h every step, so they are
+    // given ids 8 apart -- the same XCD -- and the 24 ids in between exit at once (grid.x = 32: id % 8 = direction,
+    // id / 8 = slice): 1.37-1.52 us per step against 1.6-1.8 with one workgroup per XCD (RVC_GRU_SPREAD=1).  The granules
+    // still need agent-scope accesses: group-scope ones (sc0, with or without an L1 invalidate) are served from the CU's
+    // L1 and never see the partner's store.
+    int c, dir;
+    if (gridDim.x == 8 * GRU_CUS) {
+        if ((blockIdx.x & 7) >= 2) return;
+        dir = blockIdx.x & 7;
+        c = blockIdx.x >> 3;
+    } else {
+        c = blockIdx.x % GRU_CUS;
+        dir = blockIdx.x / GRU_CUS;
+    }
     const int b = blockIdx.y;
     const int q = tid & 3;            // k quarter
     const int r = tid >> 2;           // local gate row 0..191
@@ -257,7 +271,8 @@ extern "C" int rvc_bigru_forward(const float *gi_dev, const float *whhT_dev, con
     if (batch * 2 * GRU_CUS > 128) return fail("rvc_bigru_forward: batch %d needs %d co-resident workgroups (max 128)", batch, batch * 2 * GRU_CUS);
     RVC_HIP(hipMemsetAsync(workspace_dev, 0, need, (hipStream_t)stream));  // tags must start below epoch 1 on every call; status = 0
     int *status = (int *)((char *)workspace_dev + bigru_xchg_bytes(batch));
-    hipLaunchKernelGGL(bigru_mc_kernel, dim3(2 * GRU_CUS, batch), dim3(GRU_THREADS), 0, (hipStream_t)stream, gi_dev, whhT_dev,
+    static const int spread = getenv("RVC_GRU_SPREAD") ? atoi(getenv("RVC_GRU_SPREAD")) : 0;
+    hipLaunchKernelGGL(bigru_mc_kernel, dim3(spread ? 2 * GRU_CUS : 8 * GRU_CUS, batch), dim3(GRU_THREADS), 0, (hipStream_t)stream, gi_dev, whhT_dev,
                        bhh_dev, out_dev, (u64 *)workspace_dev, status, (int)n_steps, g_spin_limit.load(std::memory_order_relaxed));
     RVC_LAUNCH_CHECK();
     // 2 x batch workgroups that return at once unless their sequence's rendezvous timed out (see bigru_mc_kernel)
