@@ -47,10 +47,10 @@ PEAK_F16_MFMA_TFLOPS = 2500.0   # dense fp16/bf16 MFMA
 PEAK_HBM_GBS = 8000.0           # HBM3E spec
 # average HBM bytes per launch of the roofline kernel symbol at the cfg-2 shape, from the PMC passes committed under
 # profiles/ (cannot be collected inside bench.py: it needs rocprofv3)
-PMC_TRAFFIC_BYTES = 611.6e6
+PMC_TRAFFIC_BYTES = 446.9e6
 PMC_TRAFFIC_SOURCE = ("profiles/r02_pmc_wino.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
-                      "tools/pmc_conv.py (this same launch mix, tools/pmc_wino.sh); FETCH_SIZE calibrated per access width on "
-                      "launches with known byte counts (4 B/lane loads 0.566, 16 B/lane 0.5)")
+                      "tools/pmc_conv.py (this same 18-launch mix, tools/pmc_wino.sh), average per launch; FETCH_SIZE calibrated "
+                      "per access width on launches with known byte counts (4 B/lane loads 0.566, 16 B/lane 0.5)")
 
 CONFIGS = {
     1: dict(seconds=10.0, sr=40000, vocoder="HiFi-GAN", index_rows=0, index_rate=0.0, weights="f32",
@@ -96,33 +96,39 @@ def cpu_model_string():
 
 # ---- roofline legs ----------------------------------------------------------------------------------------------------
 def roofline_mix(torch, native, dev, T, rates, k=11):
-    """The launches of the dominant kernel symbol, wino_conv_kernel<11,2,2,8,0>, in one utterance's vocoder forward that
-    belong to stage 1 (C = 128): the 11-tap ResBlock, for each dilation d: conv1 (dilation d) then conv2 (dilation 1,
-    + residual; the last one also + running sum, x 1/3).  (The same symbol also runs stages 0 and 2.)
+    """Every launch of the dominant kernel symbol, wino_conv_kernel<11,2,2,8,0>, in one utterance's vocoder forward: the
+    11-tap ResBlock of stages 0-2 (C = 256, 128, 64; the C = 32 stage takes the 1 x 4-wave symbol), per stage and for each
+    dilation d: conv1 (dilation d) then conv2 (dilation 1, + residual; the last one also + running sum, x 1/3) -- 18 launches,
+    the same population rocprofv3 --stats averages over for that symbol.
     Returns (callable, algorithmic flops per call, launches per call, algorithmic HBM bytes per call, executed flops)."""
-    C, L = 128, T * rates[0] * rates[1]
     gen = torch.Generator().manual_seed(1)
-    x = torch.randn(1, C, L, device=dev)
-    t1 = torch.empty_like(x)
-    y = torch.randn(1, C, L, device=dev)
-    acc = torch.randn(1, C, L, device=dev)
-    w1 = native.conv1d_wino_pack_weight(torch.randn(C, C, k, generator=gen) * 0.02, dev)
-    w2 = native.conv1d_wino_pack_weight(torch.randn(C, C, k, generator=gen) * 0.02, dev)
-    bias = torch.zeros(C, device=dev)
-    flops = 6 * 2.0 * C * C * k * L                          # SURVEY 8d: 2 x MACs of the conv as the reference computes it
+    stages, flops, executed, alg_bytes = [], 0.0, 0.0, 0.0
     groups = (k + 2) // 3
-    executed = 6 * 2.0 * C * C * (6 * groups) * (L / 4.0)    # F(4,3): 6 multiply-adds per group per 4 outputs
-    tensor = C * L * 4.0
-    alg_bytes = 3 * (2 * tensor) + 2 * (3 * tensor) + 1 * (4 * tensor)   # conv1: r+w; conv2: r+res+w (+acc)
+    L = T
+    for i in range(3):
+        C, L = 512 >> (i + 1), L * rates[i]
+        x = torch.randn(1, C, L, device=dev)
+        st = dict(C=C, x=x, t1=torch.empty_like(x), y=torch.randn(1, C, L, device=dev), acc=torch.randn(1, C, L, device=dev),
+                  w1=native.conv1d_wino_pack_weight(torch.randn(C, C, k, generator=gen) * 0.02, dev),
+                  w2=native.conv1d_wino_pack_weight(torch.randn(C, C, k, generator=gen) * 0.02, dev),
+                  bias=torch.zeros(C, device=dev))
+        stages.append(st)
+        flops += 6 * 2.0 * C * C * k * L                          # SURVEY 8d: 2 x MACs of the conv as the reference computes it
+        executed += 6 * 2.0 * C * C * (6 * groups) * (L / 4.0)    # F(4,3): 6 multiply-adds per group per 4 outputs
+        tensor = C * L * 4.0
+        alg_bytes += 3 * (2 * tensor) + 2 * (3 * tensor) + 1 * (4 * tensor)   # conv1: r+w; conv2: r+res+w (+acc)
 
     def run():
-        for j, d in enumerate((1, 3, 5)):
-            native.conv1d_wino_forward(x, w1, bias, C, k, d, 0.1, out=t1)
-            if j < 2:
-                native.conv1d_wino_forward(t1, w2, bias, C, k, 1, 0.1, res=x, out=y)
-            else:
-                native.conv1d_wino_forward(t1, w2, bias, C, k, 1, 0.1, res=x, acc=acc, out_scale=1 / 3, out=y)
-    return run, flops, 6, alg_bytes, executed
+        for st in stages:
+            C = st["C"]
+            for j, d in enumerate((1, 3, 5)):
+                native.conv1d_wino_forward(st["x"], st["w1"], st["bias"], C, k, d, 0.1, out=st["t1"])
+                if j < 2:
+                    native.conv1d_wino_forward(st["t1"], st["w2"], st["bias"], C, k, 1, 0.1, res=st["x"], out=st["y"])
+                else:
+                    native.conv1d_wino_forward(st["t1"], st["w2"], st["bias"], C, k, 1, 0.1, res=st["x"], acc=st["acc"],
+                                               out_scale=1 / 3, out=st["y"])
+    return run, flops, 18, alg_bytes, executed
 
 
 def decoder_flops(T, rates, ksizes, c0=512, cin=192, res_k=(3, 7, 11), n_dil=3):
@@ -361,7 +367,7 @@ def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev, utterance):
     T = min(n_pad // 160, 2 * F_)                     # synth frames (pipeline.py:467)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    # ---- dominant kernel symbol: wino_conv_kernel<11,2,2,8,0> (11-tap ResBlock convs; stage 1 is its largest share) ----
+    # ---- dominant kernel symbol: wino_conv_kernel<11,2,2,8,0> (the 11-tap ResBlock convs of stages 0-2) ----
     run_mix, mix_flops, mix_launches, mix_alg_bytes, mix_executed = roofline_mix(torch, _native, dev, T, rates)
     for _ in range(2):
         run_mix()
@@ -373,12 +379,13 @@ def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev, utterance):
     torch.cuda.synchronize()
     t_launch = e0.elapsed_time(e1) / (reps * mix_launches) * 1e-3
     flops_launch = mix_flops / mix_launches
-    cfg2 = T == 3198 and list(rates[:2]) == [12, 10]
+    cfg2 = T == 3198 and list(rates[:3]) == [12, 10, 2]
     exe_launch = mix_executed / mix_launches
     res["roofline"] = {
-        "kernel": f"rvc::wino_conv_kernel<11,2,2,8,0>: the 6 launches per utterance of the 11-tap ResBlock convs of vocoder "
-                  f"stage 1 (C=128, {T * rates[0] * rates[1]} columns), in the decoder's own mix (dilations 1/3/5, residual "
-                  "on every second one)",
+        "kernel": f"rvc::wino_conv_kernel<11,2,2,8,0>: ALL 18 launches per utterance of this symbol -- the 11-tap ResBlock "
+                  f"convs of vocoder stages 0-2 (C=256/128/64 at {T * rates[0]}/{T * rates[0] * rates[1]}/"
+                  f"{T * rates[0] * rates[1] * rates[2]} columns), in the decoder's own mix (dilations 1/3/5, residual on every "
+                  "second one); per-launch figures are averages over the 18",
         "bound": "mfma", "achieved": round(flops_launch / t_launch / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
         "unit": "TFLOP/s", "frac": round(flops_launch / t_launch / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
         "achieved_is": "ALGORITHMIC flops (2 x MACs of the 11-tap conv, SURVEY 8d) / launch time.  The kernel is a Winograd "

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Workload for the rocprofv3 --pmc passes: calibration launches with known byte counts, then the launch mix that
-bench.py's `roofline` object times (bench.roofline_mix: 6 launches of wino_conv_kernel<11,2,2,8,0> at C = 128)."""
+bench.py's `roofline` object times (bench.roofline_mix: the 18 launches of wino_conv_kernel<11,2,2,8,0> of one vocoder forward)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "codename-rvc-fork-3_amd")]

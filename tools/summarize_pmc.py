@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise the two rocprofv3 --pmc passes of tools/pmc_conv.py -> calibrated HBM bytes per launch of the roofline kernel
-(wino_conv_kernel<11,2,2,8,0>, the 6-launch stage-1 mix)."""
+(wino_conv_kernel<11,2,2,8,0>: the 18 launches per vocoder forward, stages 0-2 x (conv1 d, conv2) x d = 1, 3, 5)."""
 import csv, sys, statistics as st
 F, W = (list(csv.DictReader(open(p))) for p in sys.argv[1:3])
 KiB = 1024.0
@@ -14,30 +14,26 @@ grid = str(((L + 127) // 128) * (C // 128) * 256)
 k1 = lambda r: "conv_mfma_kernel<1," in r["Kernel_Name"] and r["Grid_Size"] == grid
 f1, w1 = st.median(vals(F, k1)), st.median(vals(W, k1))
 cal4 = f1 / (2 * tensor)
+cal16 = 0.5   # the guide's factor for 16 B/lane streaming reads (measured 0.500 on a tensor copy in round 1)
 out.append(f"calibration, 4 B/lane loads (direct conv, K=1, x + res): known reads {2*tensor/1e6:.1f} MB -> FETCH_SIZE {f1/1e6:.1f} MB "
-           f"(factor {cal4:.3f}); known writes {tensor/1e6:.1f} MB -> WRITE_SIZE {w1/1e6:.1f} MB (factor {w1/tensor:.3f})")
-# 16-byte-per-lane loads: torch's copy kernel
-cp = lambda r: "elementwise" in r["Kernel_Name"] and "copy" in r["Kernel_Name"].lower()
-fc = vals(F, cp)
-cal16 = 0.5
-if fc:
-    m = st.median(fc); cal16 = m / tensor
-    out.append(f"calibration, 16 B/lane loads (tensor copy): known reads {tensor/1e6:.1f} MB -> FETCH_SIZE {m/1e6:.1f} MB (factor {cal16:.3f})")
-wk = lambda r: "wino_conv_kernel<11, 2, 2, 8, 0>" in r["Kernel_Name"]
+           f"(factor {cal4:.3f}); known writes {tensor/1e6:.1f} MB -> WRITE_SIZE {w1/1e6:.1f} MB (factor {w1/tensor:.3f}); "
+           f"16 B/lane loads: factor {cal16}")
+wk = lambda r: "wino_conv_kernel<11, 2, 2, 8, 0" in r["Kernel_Name"]
 f, w = vals(F, wk), vals(W, wk)
-n = len(f) // 6
-pos_f = [st.mean(f[i::6][-n:]) for i in range(6)]
-pos_w = [st.mean(w[i::6][-n:]) for i in range(6)]
+n = len(f) // 18
+pos_f = [st.mean(f[i::18][-n:]) for i in range(18)]
+pos_w = [st.mean(w[i::18][-n:]) for i in range(18)]
 names = ["conv1 d=1", "conv2 (+res)", "conv1 d=3", "conv2 (+res)", "conv1 d=5", "conv2 (+res +sum)"]
 tot = 0.0
-for i in range(6):
+for i in range(18):
+    stage, j = divmod(i, 6)
     # conv1 launches: x through 4 B/lane buffer loads (+ the tap slab, 16 B/lane LDS-DMA, L2-resident after the first blocks);
-    # conv2 launches add the residual (and the running sum) through 16 B/lane loads: raw excess over the d = 1 conv1 launch
-    x_raw = pos_f[0] if i % 2 else pos_f[i]
-    extra_raw = pos_f[i] - x_raw if i % 2 else 0.0
+    # conv2 launches add the residual (and the running sum) through 16 B/lane loads: raw excess over the stage's d = 1 conv1
+    x_raw = pos_f[stage * 6] if j % 2 else pos_f[i]
+    extra_raw = pos_f[i] - x_raw if j % 2 else 0.0
     reads = x_raw / cal4 + extra_raw / cal16
     tot += reads + pos_w[i]
-    out.append(f"  launch {i} {names[i]:18s}: FETCH_SIZE raw {pos_f[i]/1e6:7.1f} MB -> reads {reads/1e6:7.1f} MB; WRITE_SIZE {pos_w[i]/1e6:7.1f} MB")
-out.append(f"roofline kernel wino_conv_kernel<11,2,2,8,0>: {len(f)} launches profiled ({n} runs of the 6-launch mix)")
-out.append(f"TRAFFIC_BYTES_PER_LAUNCH {tot / 6:.0f}")
+    out.append(f"  stage {stage} launch {j} {names[j]:18s}: FETCH_SIZE raw {pos_f[i]/1e6:7.1f} MB -> reads {reads/1e6:7.1f} MB; WRITE_SIZE {pos_w[i]/1e6:7.1f} MB")
+out.append(f"roofline kernel wino_conv_kernel<11,2,2,8,0>: {len(f)} launches profiled ({n} runs of the 18-launch mix)")
+out.append(f"TRAFFIC_BYTES_PER_LAUNCH {tot / 18:.0f}")
 print("\n".join(out))
