@@ -103,7 +103,10 @@ def roofline_mix(torch, native, dev, T, rates, k=11):
     Returns (callable, algorithmic flops per call, launches per call, algorithmic HBM bytes per call, executed flops)."""
     gen = torch.Generator().manual_seed(1)
     stages, flops, executed, alg_bytes = [], 0.0, 0.0, 0.0
-    groups = (k + 2) // 3
+    # multiply-adds the kernel executes per 4 outputs and (c_in, c_out) pair: F(4,4) -- 7 points per group of four taps -- for
+    # 7 / 11 taps unless RVC_WINO_R4 masks it out (wino.hip), else F(4,3) -- 6 points per group of three
+    r4 = int(os.environ.get("RVC_WINO_R4", "3")) & (1 if k == 7 else 2 if k == 11 else 0)
+    points = 7 * ((k + 3) // 4) if r4 else 6 * ((k + 2) // 3)
     L = T
     for i in range(3):
         C, L = 512 >> (i + 1), L * rates[i]
@@ -114,7 +117,7 @@ def roofline_mix(torch, native, dev, T, rates, k=11):
                   bias=torch.zeros(C, device=dev))
         stages.append(st)
         flops += 6 * 2.0 * C * C * k * L                          # 2 x MACs of the conv as the reference computes it
-        executed += 6 * 2.0 * C * C * (6 * groups) * (L / 4.0)    # F(4,3): 6 multiply-adds per group per 4 outputs
+        executed += 6 * 2.0 * C * C * points * (L / 4.0)
         tensor = C * L * 4.0
         alg_bytes += 3 * (2 * tensor) + 2 * (3 * tensor) + 1 * (4 * tensor)   # conv1: r+w; conv2: r+res+w (+acc)
 
@@ -389,8 +392,8 @@ def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev, utterance):
         "bound": "mfma", "achieved": round(flops_launch / t_launch / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
         "unit": "TFLOP/s", "frac": round(flops_launch / t_launch / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
         "achieved_is": "ALGORITHMIC flops (2 x MACs of the 11-tap conv, SURVEY 8d) / launch time.  The kernel is a Winograd "
-                       "F(4,3) form and EXECUTES 6*4/(4*11) = 0.545 of them on the matrix pipe, so frac can pass 1; the "
-                       "pipe's own occupancy is executed_frac",
+                       "F(4,4) form (7 products per 4 outputs per group of 4 taps) and EXECUTES 7*3/(4*11) = 0.477 of them on "
+                       "the matrix pipe, so frac can pass 1; the pipe's own occupancy is executed_frac",
         "executed_tflops": round(exe_launch / t_launch / 1e12, 2),
         "executed_frac": round(exe_launch / t_launch / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
         "traffic": PMC_TRAFFIC_BYTES if cfg2 else None,

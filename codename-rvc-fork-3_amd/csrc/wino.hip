@@ -1,4 +1,6 @@
 // K3w -- the ResBlock convolutions as a fast (Winograd / Toom-Cook) convolution on the fp32 matrix cores.
+// (The text below derives the F(4,3) form, used for 3 taps; 7 and 11 taps run the same scheme with F(4,4) groups of four
+// taps on seven points -- template parameter R of the kernel.)
 //
 // 98 % of the vocoder's 3.5 TFLOP per utterance are 3-, 7- and 11-tap dilated conv1d layers (residuals.py:75-86).  The
 // direct implicit GEMM (conv.hip) is within ~20 % of the fp32 MFMA peak on them, so the remaining lever is arithmetic:
@@ -89,10 +91,15 @@ constexpr int WINO_RSRC_FLAGS = 0x00020000;   // raw buffer, 32-bit data format
 //     the first / last block of a row masks for the conv's zero padding.
 // WB16: the taps are stored as bf16 (BASELINE cfg 4), one 32-bit word per input-channel pair; they stay bf16 in LDS and are
 // widened (two shifts / masks per tap pair) when the fragment is read -- half the tap stream and LDS footprint.
-template <int KW, int WM, int WN, int CIC, int DBG = 0, bool WB16 = false>
+// R: taps per group.  3: F(4,3), 6 transform points (above).  4: F(4,4) on the points {0, 1, -1, 1/2, -1/2, 2, inf}: 7 products
+// per 4 outputs per FOUR taps -- 14 instead of 18 for the 7-tap layers (2 groups instead of 3), 21 instead of 24 for 11 taps
+// -- for larger transforms (43 packed operations per two k-steps instead of 18) and a seventh accumulator.
+template <int KW, int WM, int WN, int CIC, int DBG = 0, bool WB16 = false, int R = 3>
 __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wino_conv_kernel(const WinoParams p) {
-    constexpr int G = (KW + 2) / 3;
+    constexpr int NP = R + 3;                            // transform points = window samples
+    constexpr int G = (KW + R - 1) / R;
+    constexpr int G3 = (KW + 2) / 3;                     // the tap slab in HBM always holds 3 ceil(K / 3) taps (>= R G)
     constexpr int C0 = (KW - 1) / 2;
     constexpr int BM = 32 * WM;
     constexpr int BNT = 32 * WN;                         // tile columns per block
@@ -101,13 +108,13 @@ wino_conv_kernel(const WinoParams p) {
     constexpr int CP = CIC / 2;                          // channel pairs per chunk
     static_assert(CIC % 4 == 0, "k-steps are processed in pairs of channel pairs");
     // window offsets (n + 3g - c) / 4 range over [MLO, MHI] super-block steps
-    constexpr int SMIN = -C0, SMAX = 5 + 3 * (G - 1) - C0;
+    constexpr int SMIN = -C0, SMAX = NP - 1 + R * (G - 1) - C0;
     constexpr int MLO = SMIN >= 0 ? SMIN / 4 : -((-SMIN + 3) / 4);
     constexpr int MHI = SMAX / 4;
     constexpr int XT = BNT + (MHI - MLO) * WINO_MAX_DIL;  // staged tiles per row (enough for d <= 5)
     constexpr int XTS = ((XT + 31) / 32) * 32 + 8;        // row stride in float2: == 8 mod 32, the 4 de-interleaved rows of a ds_write_b64 land in 4 bank groups
     constexpr int XTOT = CP * 4 * XTS;                    // float2 per input buffer
-    constexpr int UROWS = 3 * G * CP;                     // weight rows of BM channel pairs
+    constexpr int UROWS = R * G * CP;                     // weight rows of BM channel pairs
     constexpr int UPAIR = WB16 ? 4 : 8;                   // bytes per stored pair
     constexpr int UINSTR = (UROWS * BM * UPAIR + 1023) / 1024;   // LDS-DMA wave-instructions (1 KiB each) per chunk
     constexpr int UTOT = UINSTR * 1024 / 8;               // float2-sized slots reserved per weight buffer
@@ -151,7 +158,7 @@ wino_conv_kernel(const WinoParams p) {
     __builtin_assume(wave >= 0 && wave < NW);
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)px, 0, (int)((int64_t)c_in * L * 4), WINO_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t urs =
-        __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, (int)((int64_t)3 * G * (c_in / 2) * c_out * UPAIR), WINO_RSRC_FLAGS);
+        __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, (int)((int64_t)3 * G3 * (c_in / 2) * c_out * UPAIR), WINO_RSRC_FLAGS);
     const int L4 = (int)(L * 4);
     unsigned goff[NJ];    // byte offset of the sample inside a channel row (clamped into [0, L))
     int loff[NJ];         // float2 offset inside a channel pair's 4 rows: ii * XTS + tile (lanes with nothing to stage: a pad column)
@@ -219,9 +226,9 @@ wino_conv_kernel(const WinoParams p) {
         }
     };
 
-    f32x16 acc[6];
+    f32x16 acc[NP];
 #pragma unroll
-    for (int q = 0; q < 6; ++q)
+    for (int q = 0; q < NP; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
@@ -242,22 +249,22 @@ wino_conv_kernel(const WinoParams p) {
         // software pipeline over the S = G * CIC / 4 double k-steps: the 6 input pairs and 3 tap pairs of step s + 1 are
         // read from LDS before the transforms + 12 matrix instructions of step s are issued
         constexpr int S = G * (CIC / 4);
-        f32x2 dv[2][6], wv[2][3];
-        auto fetch = [&](int st, f32x2 (&dd)[6], f32x2 (&ww)[3]) __attribute__((always_inline)) {
+        f32x2 dv[2][NP], wv[2][R];
+        auto fetch = [&](int st, f32x2 (&dd)[NP], f32x2 (&ww)[R]) __attribute__((always_inline)) {
             const int g = st / (CIC / 4), P = st - g * (CIC / 4);
             const int cpi = 2 * P + half;               // this lane's channel pair: k-step 2P takes .x, k-step 2P + 1 takes .y
 #pragma unroll
-            for (int n = 0; n < 6; ++n) {
-                const int sh = n + 3 * g - C0;           // window offset in units of d
+            for (int n = 0; n < NP; ++n) {
+                const int sh = n + R * g - C0;           // window offset in units of d
                 dd[n] = xb[(cpi * 4 + (sh & 3)) * XTS + (sh >> 2) * d];
             }
 #pragma unroll
-            for (int kt = 0; kt < 3; ++kt) {
+            for (int kt = 0; kt < R; ++kt) {
                 if constexpr (WB16) {
-                    const unsigned bits = ua16[((3 * g + kt) * CP + cpi) * BM];
+                    const unsigned bits = ua16[((R * g + kt) * CP + cpi) * BM];
                     ww[kt] = f32x2{__uint_as_float(bits << 16), __uint_as_float(bits & 0xffff0000u)};
                 } else {
-                    ww[kt] = ua[((3 * g + kt) * CP + cpi) * BM];
+                    ww[kt] = ua[((R * g + kt) * CP + cpi) * BM];
                 }
             }
         };
@@ -266,39 +273,65 @@ wino_conv_kernel(const WinoParams p) {
         for (int st = 0; st < S; ++st) {
             if (st + 1 < S) fetch(st + 1, dv[(st + 1) & 1], wv[(st + 1) & 1]);   // reads only: nothing here depends on them yet
             __builtin_amdgcn_sched_barrier(0);
-            const f32x2(&dq)[6] = dv[st & 1];
-            const f32x2 w0 = wv[st & 1][0], w1 = wv[st & 1][1], w2 = wv[st & 1][2];
-            f32x2 aq[6], xq[6];
-            if (DBG & 1) {
-                aq[0] = w0; aq[1] = w1; aq[2] = w2; aq[3] = w0; aq[4] = w1; aq[5] = w2;
-            } else {   // rows of G3 without their scale factors (applied in the epilogue)
-                const f32x2 ts = w0 + w2, tv = fma2(4.f, w2, w0);
+            const f32x2(&dq)[NP] = dv[st & 1];
+            f32x2 aq[NP], xq[NP];
+            if constexpr (R == 3) {
+                const f32x2 w0 = wv[st & 1][0], w1 = wv[st & 1][1], w2 = wv[st & 1][2];
+                if (DBG & 1) {
+                    aq[0] = w0; aq[1] = w1; aq[2] = w2; aq[3] = w0; aq[4] = w1; aq[5] = w2;
+                } else {   // rows of G3 without their scale factors (applied in the epilogue)
+                    const f32x2 ts = w0 + w2, tv = fma2(4.f, w2, w0);
+                    aq[0] = w0;
+                    aq[1] = ts + w1;
+                    aq[2] = ts - w1;
+                    aq[3] = fma2(2.f, w1, tv);
+                    aq[4] = fma2(-2.f, w1, tv);
+                    aq[5] = w2;
+                }
+                if (DBG & 2) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) xq[q] = dq[q];
+                } else {   // BT d
+                    xq[0] = fma2(4.f, dq[0], fma2(-5.f, dq[2], dq[4]));
+                    const f32x2 t1 = fma2(-4.f, dq[2], dq[4]);
+                    const f32x2 t2 = fma2(-4.f, dq[1], dq[3]);
+                    xq[1] = t1 + t2;
+                    xq[2] = t1 - t2;
+                    const f32x2 t3 = dq[4] - dq[2];
+                    const f32x2 t4 = dq[3] - dq[1];
+                    xq[3] = fma2(2.f, t4, t3);
+                    xq[4] = fma2(-2.f, t4, t3);
+                    xq[5] = fma2(4.f, dq[1], fma2(-5.f, dq[3], dq[5]));
+                }
+            } else {
+                // F(4,4), points 0, 1, -1, 1/2, -1/2, 2, inf.  Taps: Vandermonde rows without their 1 / N_j (epilogue).
+                const f32x2 w0 = wv[st & 1][0], w1 = wv[st & 1][1], w2 = wv[st & 1][2], w3 = wv[st & 1][3];
+                const f32x2 e1 = w0 + w2, o1 = w1 + w3;
+                const f32x2 e2 = fma2(0.25f, w2, w0), o2 = fma2(0.125f, w3, w1 * 0.5f);
                 aq[0] = w0;
-                aq[1] = ts + w1;
-                aq[2] = ts - w1;
-                aq[3] = fma2(2.f, w1, tv);
-                aq[4] = fma2(-2.f, w1, tv);
-                aq[5] = w2;
-            }
-            if (DBG & 2) {
-#pragma unroll
-                for (int q = 0; q < 6; ++q) xq[q] = dq[q];
-            } else {   // BT d
-                xq[0] = fma2(4.f, dq[0], fma2(-5.f, dq[2], dq[4]));
-                const f32x2 t1 = fma2(-4.f, dq[2], dq[4]);
-                const f32x2 t2 = fma2(-4.f, dq[1], dq[3]);
-                xq[1] = t1 + t2;
-                xq[2] = t1 - t2;
-                const f32x2 t3 = dq[4] - dq[2];
-                const f32x2 t4 = dq[3] - dq[1];
-                xq[3] = fma2(2.f, t4, t3);
-                xq[4] = fma2(-2.f, t4, t3);
-                xq[5] = fma2(4.f, dq[1], fma2(-5.f, dq[3], dq[5]));
+                aq[1] = e1 + o1;
+                aq[2] = e1 - o1;
+                aq[3] = e2 + o2;
+                aq[4] = e2 - o2;
+                aq[5] = fma2(8.f, w3, fma2(4.f, w2, fma2(2.f, w1, w0)));
+                aq[6] = w3;
+                // input: row j holds the coefficients of prod_{l != j} (x - a_l); the +- pairs share their even / odd halves
+                xq[0] = fma2(-0.5f, dq[0], fma2(0.25f, dq[1], fma2(2.5f, dq[2], fma2(-1.25f, dq[3], fma2(-2.f, dq[4], dq[5])))));
+                const f32x2 A = fma2(0.5f, dq[2], fma2(-0.25f, dq[3], fma2(-2.f, dq[4], dq[5])));
+                const f32x2 B = fma2(0.5f, dq[1], fma2(-0.25f, dq[2], fma2(-2.f, dq[3], dq[4])));
+                xq[1] = A + B;
+                xq[2] = A - B;
+                const f32x2 A2 = fma2(2.f, dq[2], fma2(-2.f, dq[4], dq[5] - dq[3]));
+                const f32x2 B2 = fma2(-0.5f, dq[2], fma2(0.5f, dq[4], dq[1] - dq[3]));
+                xq[3] = A2 + B2;
+                xq[4] = A2 - B2;
+                xq[5] = fma2(0.25f, dq[1], fma2(-1.25f, dq[3], dq[5]));
+                xq[6] = fma2(-0.5f, dq[1], fma2(0.25f, dq[2], fma2(2.5f, dq[3], fma2(-1.25f, dq[4], fma2(-2.f, dq[5], dq[6])))));
             }
 #pragma unroll
-            for (int q = 0; q < 6; ++q) acc[q] = mfma32(aq[q].x, xq[q].x, acc[q]);
+            for (int q = 0; q < NP; ++q) acc[q] = mfma32(aq[q].x, xq[q].x, acc[q]);
 #pragma unroll
-            for (int q = 0; q < 6; ++q) acc[q] = mfma32(aq[q].y, xq[q].y, acc[q]);
+            for (int q = 0; q < NP; ++q) acc[q] = mfma32(aq[q].y, xq[q].y, acc[q]);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (c + 1 < n_chunks) {
@@ -322,12 +355,22 @@ wino_conv_kernel(const WinoParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const float bv = bias ? bias[m0 + row_l + (r & 3) + 8 * (r >> 2)] : 0.f;
-        const float d0 = acc[0][r], d1 = acc[1][r], d2 = acc[2][r], d3 = acc[3][r], d4 = acc[4][r], d5 = acc[5][r];
-        const float s12 = (d1 + d2) * (-1.f / 6.f), m12 = (d1 - d2) * (-1.f / 6.f), s34 = (d3 + d4) * (1.f / 24.f), m34 = (d3 - d4) * (1.f / 24.f);
-        o[r].x = fmaf(0.25f, d0, s12 + s34) + bv;
-        o[r].y = fmaf(2.f, m34, m12) + bv;
-        o[r].z = fmaf(4.f, s34, s12) + bv;
-        o[r].w = fmaf(8.f, m34, m12) + d5 + bv;
+        if constexpr (R == 3) {
+            const float d0 = acc[0][r], d1 = acc[1][r], d2 = acc[2][r], d3 = acc[3][r], d4 = acc[4][r], d5 = acc[5][r];
+            const float s12 = (d1 + d2) * (-1.f / 6.f), m12 = (d1 - d2) * (-1.f / 6.f), s34 = (d3 + d4) * (1.f / 24.f), m34 = (d3 - d4) * (1.f / 24.f);
+            o[r].x = fmaf(0.25f, d0, s12 + s34) + bv;
+            o[r].y = fmaf(2.f, m34, m12) + bv;
+            o[r].z = fmaf(4.f, s34, s12) + bv;
+            o[r].w = fmaf(8.f, m34, m12) + d5 + bv;
+        } else {   // AT diag(1 / N_j): N = (-1/2, -3/2, -9/2, 9/16, 15/16, 45/2, 1)
+            const float t0 = acc[0][r] * -2.f, t1 = acc[1][r] * (-2.f / 3.f), t2 = acc[2][r] * (-2.f / 9.f), t3 = acc[3][r] * (16.f / 9.f),
+                        t4 = acc[4][r] * (16.f / 15.f), t5 = acc[5][r] * (2.f / 45.f), t6 = acc[6][r];
+            const float s12 = t1 + t2, m12 = t1 - t2, s34 = t3 + t4, m34 = t3 - t4;
+            o[r].x = (t0 + s12) + (s34 + t5) + bv;
+            o[r].y = fmaf(0.5f, m34, m12) + fmaf(2.f, t5, bv);
+            o[r].z = fmaf(0.25f, s34, s12) + fmaf(4.f, t5, bv);
+            o[r].w = fmaf(0.125f, m34, m12) + fmaf(8.f, t5, t6) + bv;
+        }
     }
     if (DBG & 32) {
         float sum = 0.f;
@@ -420,35 +463,35 @@ wino_conv_kernel(const WinoParams p) {
     }
 }
 
-template <int KW, int WM, int WN, int CIC, bool WB16 = false>
+template <int KW, int WM, int WN, int CIC, bool WB16 = false, int R = 3>
 static size_t wino_lds_bytes() {
-    constexpr int G = (KW + 2) / 3, C0 = (KW - 1) / 2;
-    constexpr int SMIN = -C0, SMAX = 5 + 3 * (G - 1) - C0;
+    constexpr int G = (KW + R - 1) / R, C0 = (KW - 1) / 2;
+    constexpr int SMIN = -C0, SMAX = R + 2 + R * (G - 1) - C0;
     constexpr int MLO = SMIN >= 0 ? SMIN / 4 : -((-SMIN + 3) / 4), MHI = SMAX / 4;
     constexpr int XT = 32 * WN + (MHI - MLO) * WINO_MAX_DIL;
     constexpr int XTS = ((XT + 31) / 32) * 32 + 8;
-    const size_t upieces = ((size_t)3 * G * (CIC / 2) * 32 * WM * (WB16 ? 4 : 8) + 1023) / 1024;
+    const size_t upieces = ((size_t)R * G * (CIC / 2) * 32 * WM * (WB16 ? 4 : 8) + 1023) / 1024;
     const size_t chunks = 2 * (upieces * 1024 + (size_t)(CIC / 2) * 4 * XTS * 2 * sizeof(float));
     const size_t out_tile = (size_t)32 * WM * (4 * 32 * WN + 4) * sizeof(float);   // the dilated epilogue's transposed tile
     return chunks > out_tile ? chunks : out_tile;
 }
 
-template <int KW, int WM, int WN, int CIC, int DBG = 0, bool WB16 = false>
+template <int KW, int WM, int WN, int CIC, int DBG = 0, bool WB16 = false, int R = 3>
 static int wino_launch_cfg(WinoParams p, hipStream_t stream) {
     constexpr int BNT = 32 * WN;
     p.sb_per_block = BNT / p.dil;
     p.n_sb = ceil_div(p.L, (int64_t)4 * p.dil);
-    const size_t lds = wino_lds_bytes<KW, WM, WN, CIC, WB16>();
+    const size_t lds = wino_lds_bytes<KW, WM, WN, CIC, WB16, R>();
     static std::once_flag once;
     static hipError_t err = hipSuccess;
     std::call_once(once, [lds] {
-        err = hipFuncSetAttribute((const void *)wino_conv_kernel<KW, WM, WN, CIC, DBG, WB16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        err = hipFuncSetAttribute((const void *)wino_conv_kernel<KW, WM, WN, CIC, DBG, WB16, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
     if (err != hipSuccess) return fail("wino conv: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(err));
     p.n_tile_blocks = (int)ceil_div(p.n_sb, p.sb_per_block);
     const int n_m = p.c_out / (32 * WM);
     dim3 grid((unsigned)(ceil_div(p.n_tile_blocks, 8) * 8 * n_m), 1, (unsigned)p.batch);
-    hipLaunchKernelGGL((wino_conv_kernel<KW, WM, WN, CIC, DBG, WB16>), grid, dim3(64 * WM * WN), lds, stream, p);
+    hipLaunchKernelGGL((wino_conv_kernel<KW, WM, WN, CIC, DBG, WB16, R>), grid, dim3(64 * WM * WN), lds, stream, p);
     RVC_LAUNCH_CHECK();
     return 0;
 }
@@ -468,6 +511,20 @@ static int wino_launch_kw(const WinoParams &p, hipStream_t stream) {
             case 32: return wino_launch_cfg<11, 2, 2, 8, 32>(p, stream);
             case 47: return wino_launch_cfg<11, 2, 2, 8, 47>(p, stream);
             default: break;
+        }
+    }
+    // taps per group: F(4,4) for the kernel sizes in RVC_WINO_R4's mask (1: 7 taps, 2: 11 taps; default both).  Measured
+    // against F(4,3) (tools/bench_conv.py): 7 taps 0.86-0.93 of the time on every shape (530 -> 463 us at C = 128),
+    // 11 taps 0.94-0.98 (678 -> 641 us).
+    static const int r4_mask = getenv("RVC_WINO_R4") ? atoi(getenv("RVC_WINO_R4")) : 3;
+    if constexpr (KW == 7 || KW == 11) {
+        if (r4_mask & (KW == 7 ? 1 : 2)) {
+            if (p.u_bf16) {
+                if (p.c_out % 64 == 0) return wino_launch_cfg<KW, 2, 2, CIC, 0, true, 4>(p, stream);
+                if (p.c_out % 32 == 0) return wino_launch_cfg<KW, 1, 4, CIC, 0, true, 4>(p, stream);
+            }
+            if (p.c_out % 64 == 0) return wino_launch_cfg<KW, 2, 2, CIC, 0, false, 4>(p, stream);
+            if (p.c_out % 32 == 0) return wino_launch_cfg<KW, 1, 4, CIC, 0, false, 4>(p, stream);
         }
     }
     if (p.u_bf16) {

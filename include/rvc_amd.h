@@ -312,8 +312,9 @@ int rvc_conv2d_forward(const float *x_dev, const float *w_packed_dev, const floa
                        void *workspace_dev, size_t workspace_bytes, void *stream);
 
 /* ---- the same conv in its fast form (unit-test entry of what the decoder uses for its ResBlock layers) ---------------- *
- * Winograd / Toom-Cook F(4,3) over groups of three taps: identical mathematics, 1.5 G multiply-adds per output instead
- * of K (G = ceil(K / 3)); fp32 throughout, one layer agrees with float64 to ~5e-7 relative RMS (direct fp32 form: ~2e-7).
+ * Winograd / Toom-Cook over groups of taps -- F(4,3) for 3 taps, F(4,4) for 7 and 11: identical mathematics, 1.5 / 3.5 / 5.25
+ * multiply-adds per output instead of 3 / 7 / 11; fp32 throughout, one layer agrees with float64 to ~5e-7 relative RMS (direct
+ * fp32 form: ~2e-7).
  * K in {3, 7, 11}, dilation 1..5, C_in a multiple of 8, C_out a multiple of 32, leaky slope in [0, 1], C_in * L < 2^29.
  * u_dev: 3 G * C_in * C_out floats laid out [3 G][C_in / 2][C_out][2] (the taps, zero-padded to a multiple of three, input
  * channel pairs interleaved) filled by rvc_conv1d_wino_pack_weight from the [C_out][C_in][K] host weights. */
