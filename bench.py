@@ -96,7 +96,7 @@ def cpu_model_string():
 
 # ---- roofline legs ----------------------------------------------------------------------------------------------------
 def roofline_mix(torch, native, dev, T, rates, k=11):
-    """Every launch of the dominant kernel symbol, wino_conv_kernel<11,2,2,8,0>, in one utterance's vocoder forward: the
+    """Every launch of the dominant kernel symbol, wino_conv_kernel<11,2,2,8,0,false,4> (11 taps, F(4,4) groups), in one utterance's vocoder forward: the
     11-tap ResBlock of stages 0-2 (C = 256, 128, 64; the C = 32 stage takes the 1 x 4-wave symbol), per stage and for each
     dilation d: conv1 (dilation d) then conv2 (dilation 1, + residual; the last one also + running sum, x 1/3) -- 18 launches,
     the same population rocprofv3 --stats averages over for that symbol.
@@ -370,7 +370,7 @@ def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev, utterance):
     T = min(n_pad // 160, 2 * F_)                     # synth frames (pipeline.py:467)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    # ---- dominant kernel symbol: wino_conv_kernel<11,2,2,8,0> (the 11-tap ResBlock convs of stages 0-2) ----
+    # ---- dominant kernel symbol: wino_conv_kernel<11,2,2,8,0,false,4> (the 11-tap ResBlock convs of stages 0-2) ----
     run_mix, mix_flops, mix_launches, mix_alg_bytes, mix_executed = roofline_mix(torch, _native, dev, T, rates)
     for _ in range(2):
         run_mix()
@@ -385,7 +385,7 @@ def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev, utterance):
     cfg2 = T == 3198 and list(rates[:3]) == [12, 10, 2]
     exe_launch = mix_executed / mix_launches
     res["roofline"] = {
-        "kernel": f"rvc::wino_conv_kernel<11,2,2,8,0>: ALL 18 launches per utterance of this symbol -- the 11-tap ResBlock "
+        "kernel": f"rvc::wino_conv_kernel<11,2,2,8,0,false,4>: ALL 18 launches per utterance of this symbol -- the 11-tap ResBlock "
                   f"convs of vocoder stages 0-2 (C=256/128/64 at {T * rates[0]}/{T * rates[0] * rates[1]}/"
                   f"{T * rates[0] * rates[1] * rates[2]} columns), in the decoder's own mix (dilations 1/3/5, residual on every "
                   "second one); per-launch figures are averages over the 18",
