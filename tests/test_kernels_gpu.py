@@ -79,6 +79,21 @@ def test_conv1d_winograd_matches_float64(native, dev, c_in, c_out, k, dil, lengt
     assert (plain - direct).abs().max().item() <= 6e-5
 
 
+def test_conv1d_winograd_f43_groups_still_pass():
+    """7- and 11-tap layers default to F(4,4) groups; the F(4,3) form of the same kernel (RVC_WINO_R4=0, read once per
+    process) stays covered by re-running the Winograd test above in a child process."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("RVC_WINO_R4") == "0":
+        pytest.skip("already the child")
+    env = dict(os.environ, RVC_WINO_R4="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "test_conv1d_winograd_matches_float64",
+                        os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "12 passed" in r.stdout, r.stdout[-500:]
+
+
 @pytest.mark.parametrize("c_in,c_out,h,w,ks,batch", [
     (32, 32, 50, 64, 3, 1), (64, 64, 37, 32, 3, 2), (128, 128, 101, 16, 3, 1), (256, 256, 51, 8, 3, 1), (512, 512, 26, 4, 3, 1),
     (256, 512, 101, 4, 3, 1), (512, 256, 13, 8, 3, 1), (16, 16, 9, 128, 3, 1), (32, 16, 7, 128, 3, 1), (16, 3, 11, 128, 3, 1),
