@@ -72,7 +72,7 @@ class RMVPE0Predictor:
         if self.device.type == "cuda" and os.environ.get("RVC_NATIVE_UNET", "1") != "0":
             from rvc_amd import _native
             for k, v in w.items():
-                if k.endswith((".c1.w", ".c2.w", ".sc.w")) and v.shape[1] % 8 == 0:
+                if k.endswith((".c1.w", ".c2.w", ".sc.w", "cnn.w")) and v.shape[1] % 8 == 0:
                     self.wp[k] = _native.conv2d_pack_weight(v, self.device)
         # BiGRU: one GEMM for the input projections of both directions, recurrence in librvc_amd (gru.hip)
         self.w["gru.wih"] = torch.cat([self.w["gru.weight_ih_l0"], self.w["gru.weight_ih_l0_reverse"]], 0).contiguous()
@@ -135,7 +135,11 @@ class RMVPE0Predictor:
             x = torch.cat((x, skips[-1 - i]), dim=1)
             for m in range(4):
                 x = self._block(x, f"{p}.conv2.{m}")
-        x = F.conv2d(x, w["cnn.w"], w["cnn.b"], 1, 1)
+        if x.is_cuda and "cnn.w" in self.wp and x.shape[-1] in (4, 8, 16, 32, 64, 128):
+            from rvc_amd import _native
+            x = _native.conv2d_forward(x.contiguous(), self.wp["cnn.w"], w["cnn.b"], w["cnn.w"].shape[0], 3)
+        else:
+            x = F.conv2d(x, w["cnn.w"], w["cnn.b"], 1, 1)
         x = x.transpose(1, 2).flatten(-2)
         return F.linear(x, w["gru.wih"], w["gru.bih"]).view(x.shape[0], x.shape[1], 2, 768)
 
