@@ -163,9 +163,22 @@ class VoiceConverter:
         lock, cursor = threading.Lock(), [0]
 
         def work(tid):
+            # Host arrays (the reference's boundary, pipeline.py:509-528) cross PCIe through two page-locked slots per
+            # stream, both ways asynchronously on the utterance's own stream: the worker enqueues utterance k + 1 while
+            # utterance k is still running and only waits for a slot's event when it needs that slot again -- no
+            # per-utterance stream synchronise, so the stream never drains between utterances.
+            slots = [dict(inp=None, out=None, up=None, done=None, idx=None, n=0) for _ in range(2)]
+
+            def finish(slot):
+                if slot["idx"] is not None:
+                    slot["done"].synchronize()
+                    results[slot["idx"]] = slot["out"][:slot["n"]].numpy().copy()
+                    slot["idx"] = None
+
             try:
                 stream = self._batch_streams[tid]
                 stream.wait_event(ready)
+                k = 0
                 with torch.cuda.stream(stream):
                     while True:
                         with lock:                 # shared queue: a stream takes the next utterance when it is free
@@ -173,7 +186,31 @@ class VoiceConverter:
                             cursor[0] += 1
                         if i >= len(audios):
                             break
-                        results[i] = self.convert_array(audios[i], **kwargs)
+                        a = audios[i]
+                        if torch.is_tensor(a) or kwargs.get("split_audio") or kwargs.get("noise_seed") is not None:
+                            results[i] = self.convert_array(a, **kwargs)
+                            continue
+                        slot = slots[k & 1]
+                        k += 1
+                        finish(slot)               # its previous utterance (two back) has long completed
+                        a = np.ascontiguousarray(a, dtype=np.float64)
+                        if slot["inp"] is None or slot["inp"].numel() < a.shape[0]:
+                            slot["inp"] = torch.empty(max(a.shape[0], 1 << 16), dtype=torch.float64, pin_memory=True)
+                            slot["up"] = torch.cuda.Event()
+                        else:
+                            slot["up"].synchronize()   # the upload that last read this buffer
+                        slot["inp"][:a.shape[0]].numpy()[:] = a
+                        a_dev = slot["inp"][:a.shape[0]].to(dev, non_blocking=True)
+                        slot["up"].record(stream)
+                        out = self.convert_array(a_dev, **kwargs).contiguous()
+                        if slot["out"] is None or slot["out"].numel() < out.shape[0] or slot["out"].dtype != out.dtype:
+                            slot["out"] = torch.empty(max(out.shape[0], 1 << 16), dtype=out.dtype, pin_memory=True)
+                            slot["done"] = torch.cuda.Event()
+                        slot["out"][:out.shape[0]].copy_(out, non_blocking=True)
+                        slot["done"].record(stream)
+                        slot["idx"], slot["n"] = i, out.shape[0]
+                for slot in slots:
+                    finish(slot)
             except Exception as error:  # surfaced after the join
                 errors.append(error)
 
