@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- end-to-end voice-conversion throughput of the MI355X path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--config {1,2,4,5}] [--inflight M]
+    python bench.py --gpus N --steps K --warmup W [--config {1,2,3,4,5}] [--inflight M]
 
 One "step" = one pass of the hot path over one synthetic utterance: `Pipeline.pipeline` from the 16 kHz input array to
 the float32 waveform at the model's rate.  `--config` picks the BASELINE.json configuration (default 2, the one the
-metric is quoted on); config 3 is config 2 at `--gpus 8`:
+metric is quoted on); config 3 is config 2's utterance as a 512-utterance batch: `--steps` defaults to 512 / N per rank, so
+`python bench.py --config 3 --gpus 8` is BASELINE cfg 3 literally:
   1  10 s clip, HuBERT-base + v2 40k NSF-HiFi-GAN, index_rate 0
   2  30 s clip, HuBERT-base + NSF-HiFi-GAN 48k, 100 000 x 768 index, index_rate 0.75
   4  30 s clip, MRF-HiFi-GAN 48k with bf16 weights, 100 000 x 768 index, index_rate 0.75
@@ -26,8 +27,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                 timed live with HIP events on the launch stream
   roofline_knn  the L2 top-8 search at this config's (queries x rows), HBM bytes per pass as SURVEY §8d defines them
   host_io       the same K steps with host NumPy in / host float32 out (PCIe inclusive) at the same `inflight`
-  cpu_baseline  the oracle (CPU restatement of the reference, oracle/rvc_oracle.py) on the host cores: bounded sample,
-                1 warm-up + median of 3 (rank 0, N = 1 only)
+  cpu_baseline  the oracle (CPU restatement of the reference, oracle/rvc_oracle.py) on the host cores, on the config's own
+                utterance and index: warm-up + median of 3 (rank 0, N = 1 only; --cpu-seconds bounds the sample)
 """
 import argparse
 import json
@@ -57,6 +58,9 @@ CONFIGS = {
             name="BASELINE cfg 1: 10 s 16 kHz clip, HuBERT-base + v2 40k NSF-HiFi-GAN, index_rate 0"),
     2: dict(seconds=30.0, sr=48000, vocoder="HiFi-GAN", index_rows=100_000, index_rate=0.75, weights="f32",
             name="BASELINE cfg 2: 30 s 16 kHz clip -> 48 kHz, HuBERT-base + NSF-HiFi-GAN 48k, 100000x768 index, index_rate 0.75"),
+    3: dict(seconds=30.0, sr=48000, vocoder="HiFi-GAN", index_rows=100_000, index_rate=0.75, weights="f32", batch=512,
+            name="BASELINE cfg 3: 512 x 30 s 48 kHz utterance batch sharded over the ranks (512 / N per GPU), HuBERT-base + "
+                 "NSF-HiFi-GAN 48k, 100000x768 index replicated by one RCCL broadcast, index_rate 0.75"),
     4: dict(seconds=30.0, sr=48000, vocoder="MRF HiFi-GAN", index_rows=100_000, index_rate=0.75, weights="bf16",
             name="BASELINE cfg 4: 30 s clip, MRF-HiFi-GAN 48k, vocoder weights stored as bf16 in HBM, 100000x768 index, index_rate 0.75"),
     5: dict(seconds=30.0, sr=48000, vocoder="RefineGAN", index_rows=2_000_000, index_rate=0.75, weights="f32",
@@ -68,7 +72,7 @@ CONFIGS = {
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=None, help="timed utterances per GPU (default 8; config 3: 512 / N)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--seconds", type=float, default=None, help="override the clip length of the config")
@@ -76,11 +80,17 @@ def parse_args(argv=None):
     ap.add_argument("--inflight", type=int, default=2, help="utterances in flight per GPU, each on its own HIP stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rooflines", action="store_true", help="skip the per-kernel roofline legs (timed region only)")
-    ap.add_argument("--cpu-seconds", type=float, default=3.0, help="clip length of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=None,
+                    help="clip length of the CPU-baseline sample (default: the config's own clip length, i.e. the same "
+                         "synthetic input as the GPU run; e.g. 3 for a quick bounded sample)")
+    ap.add_argument("--cpu-threads", type=int, default=None, help="torch threads of the CPU baseline (default min(host cpus, 32))")
     ap.add_argument("--control-flow-only", action="store_true",
                     help="CPU test hook: run the launcher / process-group / sharding / broadcast / report path over gloo "
                          "without any kernel (no throughput is measured; the line says so)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.steps is None:
+        args.steps = max(1, CONFIGS[args.config].get("batch", 8 * max(1, args.gpus)) // max(1, args.gpus))
+    return args
 
 
 def cpu_model_string():
@@ -173,11 +183,10 @@ def main():
 
     # ---- who am I: a rank started by a launcher, or the process that has to start the ranks ----
     if "WORLD_SIZE" not in os.environ and want > 1:
-        import torch  # device_count() does not initialise HIP on this image; nothing else here touches the GPU
-        from rvc_amd.infer import distributed as D
+        from rvc_amd.infer import distributed as D   # the parent never opens the GPU driver: no torch.cuda call here
         if not args.control_flow_only:
-            n_dev = torch.cuda.device_count()
-            if n_dev < want:
+            n_dev = D.count_gpus_sysfs()              # KFD topology in sysfs; None when it cannot be read (the ranks check)
+            if n_dev is not None and n_dev < want:
                 print(f"bench.py: --gpus {want} but only {n_dev} GPU(s) are visible; refusing to report a {want}-GPU "
                       "number from fewer devices", file=sys.stderr)
                 sys.exit(2)
@@ -194,11 +203,13 @@ def main():
     if args.control_flow_only:
         return control_flow_only(torch, D, args, cfg, rank, world)
 
-    assert torch.cuda.is_available(), "bench.py measures the HIP path; there is no CPU fallback"
     n_dev = torch.cuda.device_count()
-    if world > n_dev and os.environ.get("RVC_DIST_BACKEND") != "gloo":
-        print(f"bench.py: {world} ranks but {n_dev} GPU(s) visible", file=sys.stderr)
+    if world > max(n_dev, 1) and os.environ.get("RVC_DIST_BACKEND") != "gloo" or (world > 1 and n_dev == 0):
+        if rank == 0:
+            print(f"bench.py: --gpus {want} but only {n_dev} GPU(s) are visible; refusing to report a {want}-GPU number from "
+                  "fewer devices", file=sys.stderr)
         sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py measures the HIP path; there is no CPU fallback"
     local = local % n_dev   # ranks > devices only with RVC_DIST_BACKEND=gloo (several ranks share a GPU: control-flow runs)
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
@@ -301,6 +312,8 @@ def main():
         "dtype": "f32",
         "data": "synthetic (seeded random-init weights, FM-tone utterances, clustered index)",
         "rtf": round(value / sr, 2),
+        "headline_is": "inputs resident in HBM, waveform left in HBM (the bench contract's definition of `value`); `host_io` is the "
+                       "same run through the reference's host-array boundary and is the figure to quote for a drop-in user",
         "config": {"workload": f"{cfg['name']}; rmvpe, protect 0.5; 1 utterance per step per GPU, {inflight} utterance(s) in "
                                f"flight per GPU on separate HIP streams" + (f"; clip {cfg['seconds']:g} s" if args.seconds else ""),
                    "baseline_config": args.config,
@@ -321,31 +334,9 @@ def main():
     if not args.no_rooflines:
         line.update(rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev, audios[0]))
 
-    # ---- CPU baseline: the oracle on the host cores, bounded sample, 1 warm-up + median of 3 ----
+    # ---- CPU baseline: the oracle on the host cores, on the SAME synthetic utterance and index the GPU run used ----
     if world == 1 and not args.no_cpu_baseline:
-        from oracle import rvc_oracle as O
-        cores = min(os.cpu_count() or 1, 32)   # the restatement's torch ops stop scaling (and thrash) far below 256 threads
-        torch.set_num_threads(cores)
-        a = S.synth_audio(int(args.cpu_seconds * 16000), seed=0)
-        hub_sd, rm_sd = S.make_hubert_state_dict(1), S.make_rmvpe_state_dict(0)
-        cpu_rows = min(cfg["index_rows"], 100_000)
-        big_host = index_dev[:cpu_rows].cpu().numpy() if cpu_rows else None
-        times, n_out = [], 0
-        for rep in range(4):
-            torch.manual_seed(0)
-            t0 = time.perf_counter()
-            ref = O.pipeline(hub_sd, rm_sd, cpt, a, sid=0, pitch=0, big_npy=big_host, index_rate=cfg["index_rate"], protect=0.5,
-                             knn_dtype=np.float32)
-            times.append(time.perf_counter() - t0)
-            n_out = ref.shape[0]
-        t_cpu = float(np.median(times[1:]))
-        line["cpu_baseline"] = {
-            "value": round(n_out / t_cpu, 1), "unit": "samples/s", "cores": cores, "cpu_model": cpu_model_string(),
-            "host_cpus": os.cpu_count(), "kind": "port",
-            "sample": f"{args.cpu_seconds:g} s clip at this config's settings ({cfg['vocoder']} {sr // 1000}k, "
-                      f"{cpu_rows}x768 index, index_rate {cfg['index_rate']}), oracle.pipeline, torch threads = {cores}; "
-                      "1 warm-up run + median of 3",
-            "seconds_median": round(t_cpu, 2), "seconds_all": [round(t, 2) for t in times]}
+        line["cpu_baseline"] = cpu_baseline(torch, S, cfg, cpt, args, index_dev, sr)
     else:
         line["cpu_baseline"] = None
 
@@ -358,6 +349,43 @@ def main():
             torch.distributed.destroy_process_group()
     if rank == 0:
         print(json.dumps(line), flush=True)
+
+
+def cpu_baseline(torch, S, cfg, cpt, args, index_dev, sr):
+    """oracle.pipeline (the CPU restatement of the reference, pinned to reference-generated fixtures) on the box's host cores.
+    Default sample = the config's own utterance (seed 0, the first of the timed ones) and, up to 200 000 rows, its own index:
+    one warm-up on a 3 s clip (thread pool, mel basis, allocator), then the median of 3 full runs -- ~2-3 min for cfg 2.
+    `--cpu-seconds S` bounds the sample to an S-second clip instead.  Threads: min(host cpus, 32) unless --cpu-threads says
+    otherwise -- the restatement's torch ops stop scaling (and start thrashing) far below the 256+ hardware threads of the
+    GPU boxes; the line states what was used."""
+    from oracle import rvc_oracle as O
+    cores = args.cpu_threads or min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    secs = cfg["seconds"] if args.cpu_seconds is None else args.cpu_seconds
+    hub_sd, rm_sd = S.make_hubert_state_dict(1), S.make_rmvpe_state_dict(0)
+    cpu_rows = min(cfg["index_rows"], 200_000)     # cfg 5's 2 M rows x float64 scores do not fit a bounded run
+    big_host = index_dev[:cpu_rows].cpu().numpy() if cpu_rows else None
+    kw = dict(sid=0, pitch=0, big_npy=big_host, index_rate=cfg["index_rate"], protect=0.5, knn_dtype=np.float32)
+    torch.manual_seed(0)
+    O.pipeline(hub_sd, rm_sd, cpt, S.synth_audio(48000, seed=0), **kw)          # warm-up
+    a = S.synth_audio(int(round(secs * 16000)), seed=0)
+    times, n_out = [], 0
+    for _ in range(3):
+        torch.manual_seed(0)
+        t0 = time.perf_counter()
+        ref = O.pipeline(hub_sd, rm_sd, cpt, a, **kw)
+        times.append(time.perf_counter() - t0)
+        n_out = ref.shape[0]
+    t_cpu = float(np.median(times))
+    return {"value": round(n_out / t_cpu, 1), "unit": "samples/s", "cores": cores, "cpu_model": cpu_model_string(),
+            "host_cpus": os.cpu_count(), "kind": "port",
+            "cores_policy": "torch.set_num_threads(min(host cpus, 32)) unless --cpu-threads is given",
+            "rtf": round(n_out / t_cpu / sr, 3),
+            "sample": f"{secs:g} s clip (synth_audio seed 0" + (", the GPU run's first utterance" if args.cpu_seconds is None else "")
+                      + f") at this config's settings ({cfg['vocoder']} {sr // 1000}k, {cpu_rows}x768 index"
+                      + ("" if cpu_rows == cfg["index_rows"] else f" = the first {cpu_rows} of the GPU run's {cfg['index_rows']} rows")
+                      + f", index_rate {cfg['index_rate']}), oracle.pipeline, {cores} torch threads; warm-up on a 3 s clip + median of 3",
+            "seconds_median": round(t_cpu, 2), "seconds_all": [round(t, 2) for t in times]}
 
 
 def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev, utterance):

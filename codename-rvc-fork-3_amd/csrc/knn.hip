@@ -630,11 +630,10 @@ extern "C" int rvc_knn_search(const float *index_dev, const void *aux_dev, int64
         }
         static const int waves_env = getenv("RVC_KNN_DIRECT_WAVES") ? atoi(getenv("RVC_KNN_DIRECT_WAVES")) : 0;
         if (waves_env == 84) {   // RVC_KNN_DIRECT_WAVES=84: 4 line groups in flight (+1.5 % on a 2 M-row index)
-            static bool set84 = false;
-            if (!set84) {
+            static std::once_flag set84;
+            std::call_once(set84, [lds] {
                 (void)hipFuncSetAttribute((const void *)knn_direct_kernel<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                set84 = true;
-            }
+            });
             hipLaunchKernelGGL((knn_direct_kernel<8, 4>), grid, dim3(512), lds, (hipStream_t)stream, index_dev, norms_dev,
                                n_rows, dim, queries_dev, n_queries, plan.stripe_rows, part_d, part_id, n_slots);
         } else

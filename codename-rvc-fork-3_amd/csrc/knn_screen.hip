@@ -600,6 +600,7 @@ knn_finalize_kernel(const float *__restrict__ index, int64_t n_rows, const float
                     else if (compact) id[u] = keep_s[c];
                     else {
                         id[u] = cand_id[q * cap + base + c];
+                        if (id[u] >= n_rows) id[u] = -1;      // a caller-supplied id outside the index is ignored, never read
                         if (cand_s && id[u] >= 0 && !(cand_s[q * cap + base + c] <= tau)) id[u] = -1;
                     }
                 }
@@ -719,7 +720,9 @@ static ScreenPlan screen_plan(int64_t n_rows, int64_t n_queries, int dim) {
     return s;
 }
 
-static int g_knn_mode = 0;   // rvc_knn_set_mode: 0 auto, 1 exact fp32 GEMM, 2 screened whenever the shape allows
+// rvc_knn_set_mode (test hook): 0 auto, 1 exact fp32 GEMM, 2 screened whenever the shape allows.  Per calling thread, so a
+// test that pins a regime cannot change what a concurrent convert_batch worker thread runs.
+static thread_local int g_knn_mode = 0;
 
 bool knn_screen_applicable(int64_t n_rows, int64_t n_queries, int dim) {
     if (g_knn_mode == 1) return false;

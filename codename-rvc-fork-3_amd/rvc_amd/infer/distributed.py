@@ -34,6 +34,9 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+RENDEZVOUS_EXIT = 75   # EX_TEMPFAIL: rank 0 could not bind the rendezvous port (spawn_ranks starts the job again on a new one)
+
+
 def init_process_group(backend: str | None = None):
     """Idempotent init from the torchrun-style environment; returns (rank, world, local_rank).
 
@@ -46,7 +49,14 @@ def init_process_group(backend: str | None = None):
             backend = os.environ.get("RVC_DIST_BACKEND") or ("cpu:gloo,cuda:nccl" if torch.cuda.is_available() else "gloo")
         if "nccl" in backend:
             torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        except Exception as e:   # noqa: BLE001  (DistNetworkError / RuntimeError, depending on the torch build)
+            msg = str(e).lower()
+            if rank == 0 and ("address already in use" in msg or "eaddrinuse" in msg):
+                print(f"[rvc_amd.distributed] rendezvous port {os.environ.get('MASTER_PORT')} is taken: {e}", file=sys.stderr)
+                sys.exit(RENDEZVOUS_EXIT)
+            raise
     return rank, world, local
 
 
@@ -142,7 +152,19 @@ def broadcast_index(big_npy, device, src: int = 0, force_rccl: bool = False) -> 
             shape = shape_dev.cpu()
     if rank != src:
         t = torch.empty((int(shape[0]), int(shape[1])), dtype=torch.float32, device=device)
-    if on_gpu:
+    gloo_only = os.environ.get("RVC_DIST_BACKEND") == "gloo" and world > 1
+    if on_gpu and gloo_only:
+        # several ranks sharing one GPU (or a job told to stay off RCCL): RCCL refuses two ranks on one device, so the bytes
+        # ride the gloo group through host memory.  Test / control-flow transport, never the measured one.
+        t0 = time.perf_counter()
+        host = t.cpu() if rank == src else torch.empty(t.shape, dtype=torch.float32)
+        dist.broadcast(host, src)
+        if rank != src:
+            t.copy_(host)
+        torch.cuda.synchronize()
+        _last_broadcast.update(n_ranks=world, rank=rank, seconds=time.perf_counter() - t0, bytes=t.numel() * 4,
+                               transport="gloo (staged through host memory)")
+    elif on_gpu:
         comm = native_comm()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -217,42 +239,107 @@ def free_port() -> int:
     return port
 
 
-def spawn_ranks(argv: Sequence[str], n_ranks: int, env_extra: dict | None = None, timeout: float | None = None) -> int:
+def count_gpus_sysfs() -> int | None:
+    """GPUs of this node as the kernel driver lists them (KFD topology: nodes with SIMDs are GPUs, the others CPUs),
+    narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when those hold plain index lists.  Reads sysfs only -- the
+    launcher process never opens the GPU runtime.  None when the topology cannot be read (containers without /sys/class/kfd):
+    the ranks then validate the device count themselves and exit 2."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split(None, 1) for line in f if " " in line)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except (OSError, ValueError):
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            ids = [t for t in v.split(",") if t.strip() != ""]
+            if all(t.strip().isdigit() for t in ids):
+                n = min(n, len(ids))
+    return n
+
+
+def spawn_ranks(argv: Sequence[str], n_ranks: int, env_extra: dict | None = None, timeout: float | None = None,
+                port_retries: int = 3) -> int:
     """Start ``n_ranks`` copies of ``argv`` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, one per
     GPU, and wait for them; returns the first non-zero exit code (0 if all succeeded).  Rank 0 inherits stdout, so its
-    report line is the parent's.  When a rank fails the others are terminated (by PID) instead of being left at a barrier.
+    report line is the parent's.  When a rank fails -- or this process is interrupted (KeyboardInterrupt, SIGTERM) -- the
+    other ranks are terminated by PID instead of being left at a barrier.
+
+    The rendezvous port is found by binding port 0 and closing the socket again, so another process can take it before
+    rank 0 listens; a job whose ranks all fail within the first seconds with the rendezvous exit code
+    (RENDEZVOUS_EXIT = 75, raised by init_process_group when the store cannot be created) is started again on a new port,
+    ``port_retries`` times.
+
+    HSA_ENABLE_IPC_MODE_LEGACY=0 is set for the children unless the caller's environment already has a value: RCCL's
+    intra-node transport shares device buffers across the rank processes through IPC handles, and on hosts whose driver
+    only offers dmabuf IPC the legacy mode fails inside ncclCommInitRank with `hipIpcGetMemHandle: invalid argument`.
 
     The caller must not have touched the GPU: children are plain new processes (never an exec of a process that has
     initialised HIP)."""
+    import signal
+    rc = 0
+    for attempt in range(port_retries + 1):
+        rc = _spawn_once(argv, n_ranks, env_extra, timeout, signal)
+        if rc != RENDEZVOUS_EXIT or attempt == port_retries:
+            break
+        print(f"[spawn_ranks] rendezvous failed (port taken?); attempt {attempt + 2} on a new port", file=sys.stderr)
+    return rc
+
+
+
+def _spawn_once(argv, n_ranks, env_extra, timeout, signal) -> int:
     port = free_port()
     procs = []
-    for r in range(n_ranks):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        env.update(env_extra or {})
-        procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL))
-    deadline = None if timeout is None else time.time() + timeout
-    rc = 0
-    alive = set(range(n_ranks))
-    while alive:
-        for r in sorted(alive):
-            code = procs[r].poll()
-            if code is not None:
-                alive.discard(r)
-                if code != 0 and rc == 0:
-                    rc = code
-                    print(f"[spawn_ranks] rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
-        if rc != 0 or (deadline is not None and time.time() > deadline):
-            if rc == 0:
-                rc = 124
-                print(f"[spawn_ranks] timeout after {timeout} s; stopping all ranks", file=sys.stderr)
-            for r in alive:
+
+    def stop(which):
+        for r in which:
+            if procs[r].poll() is None:
                 procs[r].terminate()
-            for r in alive:
-                try:
-                    procs[r].wait(timeout=10)
-                except subprocess.TimeoutExpired:
-                    procs[r].kill()
-            break
-        time.sleep(0.05)
+        for r in which:
+            try:
+                procs[r].wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+
+    def on_term(signum, frame):
+        raise KeyboardInterrupt
+
+    old_term = None
+    try:
+        old_term = signal.signal(signal.SIGTERM, on_term)
+    except ValueError:          # not the main thread: SIGTERM keeps its handler, KeyboardInterrupt is still covered
+        pass
+    rc = 0
+    try:
+        for r in range(n_ranks):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            env.update(env_extra or {})
+            procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+        deadline = None if timeout is None else time.time() + timeout
+        alive = set(range(n_ranks))
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is not None:
+                    alive.discard(r)
+                    if code != 0 and rc == 0:
+                        rc = code
+                        print(f"[spawn_ranks] rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+            if rc != 0 or (deadline is not None and time.time() > deadline):
+                if rc == 0:
+                    rc = 124
+                    print(f"[spawn_ranks] timeout after {timeout} s; stopping all ranks", file=sys.stderr)
+                stop(alive)
+                break
+            time.sleep(0.05)
+    finally:
+        stop(range(len(procs)))   # interrupted parent (or any exception above): no rank is left waiting at a barrier
+        if old_term is not None:
+            signal.signal(signal.SIGTERM, old_term)
     return rc

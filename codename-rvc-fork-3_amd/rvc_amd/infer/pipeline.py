@@ -144,7 +144,11 @@ class FeatureIndex:
         self.ivf = None
         if ivf is not None:
             cent = torch.from_numpy(np.array(ivf.centroids, dtype=np.float32)).to(self.vectors.device)
-            self.ivf = {"centroids": cent, "aux": _native.knn_index_build(cent), "nprobe": max(1, min(int(ivf.nprobe), 8)),
+            if int(ivf.nprobe) > 8:
+                # the centroid search returns 8 neighbours; silently probing fewer lists than the file asks for would be a
+                # different (worse) search than the reference's.  extract_index.py:62-64 writes nprobe = 1.
+                raise ValueError(f"IVF index asks for nprobe = {ivf.nprobe}; this build probes at most 8 lists (the reference writes 1)")
+            self.ivf = {"centroids": cent, "aux": _native.knn_index_build(cent), "nprobe": max(1, int(ivf.nprobe)),
                         "lists": torch.from_numpy(np.array(ivf.padded_lists())).to(self.vectors.device)}
         elif search_mode == "ivf":
             raise ValueError("search_mode='ivf' needs the inverted lists of a faiss .index file")
@@ -157,8 +161,11 @@ class FeatureIndex:
     def search_device(self, queries: torch.Tensor, k: int = 8):
         if self.search_mode == "ivf" and self.ivf is not None:
             _, near = _native.knn_search(self.ivf["centroids"], self.ivf["aux"], queries, k)       # nearest centroids
-            probe = near[:, :self.ivf["nprobe"]].clamp_min(0)
-            cand = self.ivf["lists"][probe].reshape(queries.shape[0], -1)                          # members of those lists
+            probe = near[:, :self.ivf["nprobe"]]
+            # fewer lists than nprobe: the missing probes come back as -1 and contribute NO candidates (gathering list 0 for
+            # them would enter its rows twice and double their weight in the blend)
+            cand = self.ivf["lists"][probe.clamp_min(0)].masked_fill((probe < 0).unsqueeze(-1), -1)
+            cand = cand.reshape(queries.shape[0], -1)                                              # members of those lists
             return _native.knn_rank_candidates(self.vectors, self.aux, queries, cand, k)
         return _native.knn_search(self.vectors, self.aux, queries, k)
 

@@ -91,7 +91,8 @@ def resample(audio, orig_sr: int, target_sr: int, device="cuda:0"):
     key = (up, down, str(x.device))
     if key not in _filters_dev:
         _filters_dev[key] = torch.from_numpy(resample_filter(up, down)).to(x.device)
-    y = _native.resample_poly(x, up, down, _filters_dev[key])
+    with torch.cuda.device(x.device):   # the native call launches on the CURRENT stream: make it the stream of x's device
+        y = _native.resample_poly(x, up, down, _filters_dev[key])
     return y.cpu().numpy() if as_numpy else y
 
 

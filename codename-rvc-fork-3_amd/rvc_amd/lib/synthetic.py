@@ -119,10 +119,22 @@ def _noise_conv_geometry(stride):
     return kernel, padding
 
 
-def _text_encoder(g: _Gen, hidden=192, filt=768, inter=192, layers=6, k=3, emb=768, heads=2, window=10):
+def _text_encoder(g: _Gen, hidden=192, filt=768, inter=192, layers=6, k=3, emb=768, heads=2, window=10, smooth_pitch=False):
     # encoders.py:88-144, attentions.py:6-77
     g.linear("enc_p.emb_phone", hidden, emb)
-    g.normal("enc_p.emb_pitch.weight", (256, hidden), 1.0)
+    if smooth_pitch:
+        # a trained pitch embedding varies smoothly with the coarse-pitch index (neighbouring bins are neighbouring
+        # pitches); i.i.d. rows make ONE frame whose mel-scaled f0 rounds the other way at a .5 boundary swap in an
+        # unrelated vector.  Rows = a random band-limited function of the index (12 harmonics over 256 bins), unit RMS.
+        rng = g._rng("enc_p.emb_pitch.weight/smooth")
+        kk = np.arange(1, 13)[:, None, None]
+        idx = np.arange(256)[None, :, None]
+        amp = rng.standard_normal((12, 1, hidden)) / np.sqrt(12.0 / 2.0)
+        ph = rng.uniform(0, 2 * np.pi, (12, 1, hidden))
+        tab = (amp * np.cos(2 * np.pi * kk * idx / 256.0 + ph)).sum(0)
+        g.out["enc_p.emb_pitch.weight"] = torch.from_numpy(tab.astype(np.float32))
+    else:
+        g.normal("enc_p.emb_pitch.weight", (256, hidden), 1.0)
     kc = hidden // heads
     for i in range(layers):
         a = f"enc_p.encoder.attn_layers.{i}"
@@ -221,7 +233,7 @@ def _dec_refine(g: _Gen, rates, init_ch, inter=192, gin=256, rk=(3, 7, 11), nd=3
 
 def make_synth_checkpoint(sr: int = 48000, vocoder: str = "HiFi-GAN", seed: int = 0, *,
                           upsample_initial_channel: int = 512, spk_embed_dim: int = 109,
-                          half: bool = False, version: str = "v2") -> dict:
+                          half: bool = False, version: str = "v2", smooth_pitch: bool = False) -> dict:
     """An in-memory equivalent of an exported ``.pth`` (extract_model.py:56-107).
 
     ``half=True`` stores the weights as fp16 exactly like real exports do
@@ -230,7 +242,8 @@ def make_synth_checkpoint(sr: int = 48000, vocoder: str = "HiFi-GAN", seed: int 
     cfg = config_list(sr, upsample_initial_channel=upsample_initial_channel, spk_embed_dim=spk_embed_dim)
     rates, ksizes = cfg[12], cfg[14]
     g = _Gen(seed)
-    _text_encoder(g, emb=768 if version == "v2" else 256)   # v1 models take the 256-dim final_proj features (infer.py:472)
+    # v1 models take the 256-dim final_proj features (infer.py:472)
+    _text_encoder(g, emb=768 if version == "v2" else 256, smooth_pitch=smooth_pitch)
     if vocoder == "MRF HiFi-GAN":
         _dec_mrf(g, rates, ksizes, upsample_initial_channel)
     elif vocoder == "RefineGAN":
@@ -286,8 +299,78 @@ def make_hubert_state_dict(seed: int = 1, *, layers: int = 12, hidden: int = 768
     return g.out
 
 
-def make_rmvpe_state_dict(seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
-    """``E2E(4, 1, (2, 2))`` weights (RMVPE.py:289-339, 420-433), BatchNorm in eval form."""
+# ---- "peaked" RMVPE tail ---------------------------------------------------------------------------
+# A random-weight RMVPE has a flat, noise-like salience: the arg-max over its 360 bins sits within fp32 noise of
+# the runner-up on about one frame per 30 s, and because RMVPE.py:487-512 averages +-4 bins around the arg-max, two
+# correct fp32 evaluations of the network can then disagree on f0 by an octave on that frame.  A trained RMVPE is
+# unimodal: a bump of a few bins around the pitch, ~0 elsewhere (its training targets are Gaussian-blurred one-hots),
+# so an arg-max flip can only move to the neighbouring bin of the SAME bump and the local average barely moves.
+# `make_rmvpe_state_dict(seed, peaked=True)` keeps the seeded U-Net and output conv and replaces the recurrent layer +
+# linear head by a construction with exactly that property:
+#   s      = u . x_t                         one scalar projection of the 384-d output-conv features of frame t
+#   psi    = PSI_C + RHO (s - mu) / sigma    bump position in bins (mu, sigma: statistics of s on the SURVEY 8(d) input)
+#   n_j    = tanh(A (psi - c_j))             the GRU's candidate state: 512 units tiling [PSI_C - HALF, PSI_C + HALF]
+#                                            (forward units on even, backward units on odd positions)
+#   h      = (1 - z) n + z h_prev            update gate ~0.08 (bias -2.5) with small seeded random recurrent / gate weights,
+#                                            so the recurrence is live but the code of frame t dominates
+#   logit  = L0 + V h                        V: least-squares readout with  V n(psi) = (L1 - L0) exp(-(i - psi)^2 / 2 SB^2)
+# i.e. sigmoid(logit) is a Gaussian-shaped bump of height ~0.8 and sigma 1.25 bins (25 cents, RMVPE's label blur) at psi,
+# and ~6e-6 elsewhere.  The bump POSITION is a continuous function of the U-Net's output, so every conv of the network
+# still decides the result -- it follows the network's (random) features, not the input's true pitch.
+PEAKED = dict(PSI_C=180.0, RHO=8.0, HALF=24.0, A=1.5, SB=1.25, L0=-12.0, L1=3.0, Z_BIAS=-2.5)
+# (mean, std) of s over the frames of synth_audio(30 s, seed 0) after the pipeline's high-pass + 1 s reflect padding,
+# evaluated with the REFERENCE's own E2E module (tests/golden/make_golden_peaked.py prints them)
+PEAKED_STATS = {0: (82.851207, 85.552342)}
+
+
+def _peaked_tail(g: "_Gen", seed: int, stats=None):
+    P = PEAKED
+    if stats is None:
+        if seed not in PEAKED_STATS:
+            raise ValueError(f"peaked RMVPE: no feature statistics recorded for seed {seed}; pass stats=(mean, std)")
+        stats = PEAKED_STATS[seed]
+    mu, sigma = float(stats[0]), float(stats[1])
+    hid, inp = 256, 384
+    u = g._rng("peaked.u").standard_normal(inp)
+    u /= np.linalg.norm(u)
+    dc = 2.0 * P["HALF"] / (2 * hid)
+    centres = {}
+    for d, sfx in enumerate(("", "_reverse")):
+        c = P["PSI_C"] - P["HALF"] + (2.0 * np.arange(hid) + d + 0.5) * dc
+        centres[sfx] = c
+        w_ih = np.zeros((3 * hid, inp))
+        w_ih[:2 * hid] = g._rng(f"peaked.w_ih{sfx}").standard_normal((2 * hid, inp)) * (0.3 / (sigma * math.sqrt(inp)))
+        w_ih[2 * hid:] = (P["A"] * P["RHO"] / sigma) * u[None, :]
+        b_ih = np.zeros(3 * hid)
+        b_ih[hid:2 * hid] = P["Z_BIAS"]
+        b_ih[2 * hid:] = P["A"] * (P["PSI_C"] - P["RHO"] * mu / sigma - c)
+        w_hh = g._rng(f"peaked.w_hh{sfx}").standard_normal((3 * hid, hid)) * 0.02
+        w_hh[2 * hid:] *= 0.25
+        g.out[f"fc.0.gru.weight_ih_l0{sfx}"] = torch.from_numpy(w_ih.astype(np.float32))
+        g.out[f"fc.0.gru.weight_hh_l0{sfx}"] = torch.from_numpy(w_hh.astype(np.float32))
+        g.out[f"fc.0.gru.bias_ih_l0{sfx}"] = torch.from_numpy(b_ih.astype(np.float32))
+        g.out[f"fc.0.gru.bias_hh_l0{sfx}"] = torch.zeros(3 * hid)
+    # readout: ridge least squares over a grid of bump positions (beyond the tiled range the target stays at the range end)
+    lo, hi = P["PSI_C"] - P["HALF"], P["PSI_C"] + P["HALF"]
+    psi = np.arange(lo - 8.0, hi + 8.0, 0.04)
+    code = np.concatenate([np.tanh(P["A"] * (psi[:, None] - centres[sfx][None, :])) for sfx in ("", "_reverse")], axis=1)
+    X = np.concatenate([code, np.ones((len(psi), 1))], axis=1)
+    bins = np.arange(360)[None, :]
+    target = (P["L1"] - P["L0"]) * np.exp(-0.5 * ((bins - np.clip(psi, lo + 2.0, hi - 2.0)[:, None]) / P["SB"]) ** 2)
+    lam = 1e-4 * len(psi)
+    A_ = X.T @ X + lam * np.eye(X.shape[1])
+    A_[-1, -1] -= lam
+    W = np.linalg.solve(A_, X.T @ target)          # [513, 360]
+    g.out["fc.1.weight"] = torch.from_numpy(np.ascontiguousarray(W[:-1].T).astype(np.float32))
+    g.out["fc.1.bias"] = torch.from_numpy((P["L0"] + W[-1]).astype(np.float32))
+    return u
+
+
+def make_rmvpe_state_dict(seed: int = 0, *, peaked: bool = False, peaked_stats=None) -> "OrderedDict[str, torch.Tensor]":
+    """``E2E(4, 1, (2, 2))`` weights (RMVPE.py:289-339, 420-433), BatchNorm in eval form.
+
+    ``peaked=True``: same U-Net / output conv, but a recurrent layer + head that turn the features into a unimodal,
+    trained-like salience (see PEAKED above)."""
     g = _Gen(seed)
 
     def bn(prefix, c):
@@ -341,6 +424,8 @@ def make_rmvpe_state_dict(seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
         g.normal(f"fc.0.gru.bias_ih_l0{sfx}", (3 * hid,), s)
         g.normal(f"fc.0.gru.bias_hh_l0{sfx}", (3 * hid,), s)
     g.linear("fc.1", 360, 512, std=0.08)
+    if peaked:
+        _peaked_tail(g, seed, peaked_stats)
     return g.out
 
 

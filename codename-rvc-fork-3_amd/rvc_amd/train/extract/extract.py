@@ -47,7 +47,7 @@ class FeatureInput:
         if os.path.exists(opt_path_coarse) and os.path.exists(opt_path_full):
             return
         try:
-            np_arr = load_audio(inp_path, self.fs)
+            np_arr = load_audio(inp_path, self.fs, device=self.device)   # resampler tensors on THIS worker's GPU
             feature_pit = self.compute_f0(np_arr, f0_method, hop_length)
             np.save(opt_path_full, feature_pit, allow_pickle=False)
             np.save(opt_path_coarse, self.coarse_f0(feature_pit), allow_pickle=False)
@@ -95,7 +95,7 @@ def process_file_embedding(files, embedder_model, embedder_model_custom, device_
         for wav_file_path, _, _, out_file_path in files:
             if os.path.exists(out_file_path):
                 continue
-            feats = torch.from_numpy(load_audio(wav_file_path, 16000)).to(device).float().view(1, -1)
+            feats = torch.from_numpy(load_audio(wav_file_path, 16000, device=device)).to(device).float().view(1, -1)
             with torch.no_grad():
                 result = model(feats)["last_hidden_state"]
             feats_out = result.squeeze(0).float().cpu().numpy()

@@ -68,11 +68,13 @@ def librosa_mel_fn(sr, n_fft, n_mels=128, fmin=0.0, fmax=None):
 _transforms = {}
 
 
-def _transform(n_fft, hop_size, win_size, mel, device):
-    key = (n_fft, hop_size, win_size, None if mel is None else mel.tobytes(), str(device))
+def _transform(n_fft, hop_size, win_size, mel_key, device):
+    """mel_key: None (spectrogram only) or the (num_mels, sample_rate, fmin, fmax) of _basis -- scalars, so that looking a
+    cached handle up in the training loop does not hash half a megabyte of filter bank per call."""
+    key = (n_fft, hop_size, win_size, mel_key, str(device))
     if key not in _transforms:
         with torch.cuda.device(device):
-            m = mel if mel is not None else np.zeros((1, n_fft // 2 + 1), dtype=np.float32)
+            m = _basis(n_fft, *mel_key) if mel_key is not None else np.zeros((1, n_fft // 2 + 1), dtype=np.float32)
             _transforms[key] = _native.MelTransform(n_fft, hop_size, win_size, int((n_fft - hop_size) / 2), m, mag_eps=1e-6,
                                                     log_floor=1e-5)
     return _transforms[key]
@@ -113,4 +115,4 @@ def mel_spectrogram_torch(y, n_fft, num_mels, sample_rate, hop_size, win_size, f
     if center:
         raise NotImplementedError("the reference only calls this with center=False")
     y = _require_device(y)
-    return _transform(n_fft, hop_size, win_size, _basis(n_fft, num_mels, sample_rate, fmin, fmax), y.device).forward(y)[0]
+    return _transform(n_fft, hop_size, win_size, (num_mels, sample_rate, fmin, fmax), y.device).forward(y)[0]

@@ -75,8 +75,10 @@ int rvc_knn_rank_candidates(const float *index_dev, const void *aux_dev, int64_t
                             int64_t n_queries, const int32_t *cand_ids_dev, int cap, int k, float *out_d2_dev,
                             int64_t *out_ids_dev, void *stream);
 
-/* Test hook, process-wide: 0 = choose the regime by shape (default), 1 = never screen (fp32 GEMM / streaming only),
- * 2 = screen whenever the shape allows it (>= 4096 rows, dim a multiple of 256).  Results do not depend on it. */
+/* Test hook, per calling thread (searches issued by other host threads keep choosing by shape): 0 = choose the regime by
+ * shape (default), 1 = never screen (fp32 GEMM / streaming only), 2 = screen whenever the shape allows it (>= 4096 rows,
+ * dim a multiple of 256).  Results do not depend on it.  Candidate ids handed to rvc_knn_rank_candidates that are negative
+ * or >= n_rows are ignored. */
 int rvc_knn_set_mode(int mode);
 
 /* pipeline.py:500-506: w = (1/d2)^2, w /= sum(w); out = index_rate * sum_k w_k * index[id_k] + (1-index_rate) * feats.

@@ -45,7 +45,6 @@ def _converter(S, sr, voc, hubert, config=None):
     return vc
 
 
-PLAIN_GATE = 5e-3  # waveform RMS with each side on its OWN f0 contour (fp32-noise-level f0 differences through the phase integral)
 SAL_TIE = 2.5e-4   # salience near-tie bound: ~4x the largest GPU-vs-CPU salience difference measured (6e-5, tools/diag_rmvpe.py)
 F0_NOISE = 2e-5    # relative f0 difference that identical arg-max bins produce (measured ~1e-6: the 9-bin weighted mean
                    # moves with the salience's 1e-5-level differences)
@@ -109,7 +108,7 @@ def _run_pair(S, sds, vc, hubert, cpt, audio, big, rate, seed, **okw):
     # = 0.011 rad at the end of a 45 s clip, i.e. ~1e-3 waveform RMS (measured 1.35e-3 at 45 s, 4e-4 at 30 s).  So when the
     # plain comparison is within a factor of a few of the gate, the oracle is re-run ON THE PRODUCT'S CONTOUR: the f0 stage
     # has been checked on its own just above, this checks everything downstream of it at full length.  The plain error is
-    # reported and bounded by the callers (PLAIN_GATE).
+    # reported; the UNCONDITIONAL plain gate is test_full_length_plain_peaked_rmvpe below (trained-like salience).
     if len(differ) or len(flips) or plain_err > 3e-4:
         torch.manual_seed(seed)
         want = O.pipeline(sds[0], sds[1], cpt, audio.copy(), sid=0, pitch=0, big_npy=big, index_rate=rate, protect=0.5,
@@ -148,8 +147,77 @@ def test_baseline_config_full_length_vs_oracle(S, hubert, sds, cfg):
     assert err <= 1e-3, err
     assert info["tie_frames"] <= 0.002 * info["n_frames"], info   # a handful per 30 s at most
     assert info["coarse_flips"] <= 0.002 * info["n_frames"], info
-    if info["tie_frames"] == 0:
-        assert info["plain_err"] <= PLAIN_GATE, info
+
+
+@pytest.mark.parametrize("case", ["cfg2", "cfg1", "45s"])
+def test_full_length_plain_peaked_rmvpe(S, hubert, case):
+    """The north_star gate with NOTHING conditional: product vs oracle at the benchmarked lengths, each side on its OWN
+    f0 contour (no f0_override, no tie certificates on f0), waveform <= 1e-3 RMS, f0 <= 2e-5 relative on EVERY frame.
+
+    What makes that possible is the RMVPE checkpoint, not the comparison: synthetic.make_rmvpe_state_dict(peaked=True)
+    has a trained-like, unimodal salience (one bump of ~+-3 bins per frame, <= 2.5e-5 elsewhere -- verified with the
+    reference's own RMVPE0Predictor on exactly these inputs, tests/golden/make_golden_peaked.py), so two fp32
+    evaluations of the network can only disagree about which of two NEIGHBOURING bins of the same bump is the arg-max,
+    and the +-4-bin local average (RMVPE.py:487-512) is continuous across that.  The flat-salience (random-head) tests
+    above stay tie-aware.  The synthesizer checkpoint uses the smooth pitch embedding (synthetic: smooth_pitch=True): the
+    coarse pitch (pipeline.py:401-408) rounds a continuous value, so two contours equal to 1e-6 still round apart at a
+    .5 boundary on ~1 frame in 10^4; such frames must be certified rounding near-ties and are counted, every other
+    coarse integer is bit-exact."""
+    from oracle import rvc_oracle as O
+    secs, sr, rows, rate, aseed, seed = {"cfg2": (30, 48000, 100_000, 0.75, 0, 1234), "cfg1": (10, 40000, 0, 0.0, 0, 1234),
+                                         "45s": (45, 48000, 0, 0.0, 45, 99)}[case]
+    rm_sd = S.make_rmvpe_state_dict(0, peaked=True)
+    hub_sd = S.make_hubert_state_dict(1)
+    cpt = S.make_synth_checkpoint(sr, "HiFi-GAN", seed=0, smooth_pitch=True)
+    from rvc_amd.infer.infer import VoiceConverter
+    vc = VoiceConverter(device=DEV)
+    vc.load_checkpoint_dict(cpt)
+    vc.hubert_model = hubert
+    vc.vc.load_rmvpe_state_dict(rm_sd)
+    big = S.synth_index(rows, seed=0) if rows else None
+    if rows:
+        vc.vc.set_index(big)
+    audio = S.synth_audio(16000 * secs, seed=aseed)
+    taps = {}
+    t0 = time.time()
+    torch.manual_seed(seed)
+    want = O.pipeline(hub_sd, rm_sd, cpt, audio.copy(), sid=0, pitch=0, big_npy=big, index_rate=rate, protect=0.5, taps=taps,
+                      knn_dtype=np.float32)
+    t_oracle = time.time() - t0
+    vc.vc.debug_taps = {}
+    got = vc.vc.pipeline(hubert, vc.net_g, 0, audio.copy(), 0, "rmvpe", "", rate, True, 3, 1, "v2", 0.5, 128, False, 1, None,
+                         noise_seed=seed)
+    f0_p = vc.vc.debug_taps["f0_raw"].cpu().numpy()
+    sal_p = vc.vc.debug_taps["salience"].cpu().numpy()
+    vc.vc.debug_taps = None
+    f0_o, sal_o = taps["f0_raw"], taps["salience"]
+    assert got.dtype == np.float32 and got.shape == want.shape and f0_p.shape == f0_o.shape
+    if case == "45s":
+        assert len(taps["opt_ts"]) == 1
+    # the salience itself, and the bump property on the PRODUCT's side too
+    sal_err = float(np.abs(sal_p - sal_o).max())
+    am_p, am_o = sal_p.argmax(1), sal_o.argmax(1)
+    assert np.abs(am_p - am_o).max() <= 1, "arg-max moved by more than one bin"
+    off = sal_p.copy()
+    for k in range(-4, 5):
+        off[np.arange(len(am_p)), np.clip(am_p + k, 0, 359)] = 0
+    assert sal_p.max(1).min() >= 0.4 and off.max() <= 1e-4
+    # f0: every frame voiced, every frame within 2e-5 relative
+    assert np.all(f0_o > 0) and np.all(f0_p > 0)
+    f0_rel = float(np.abs(f0_p / f0_o - 1).max())
+    # coarse pitch: bit-exact except certified rounding near-ties
+    c_p, c_o = O.f0_to_coarse(f0_p.astype(np.float64))[0], O.f0_to_coarse(f0_o.astype(np.float64))[0]
+    flips = np.nonzero(c_p != c_o)[0]
+    for t in flips:
+        mel = (1127 * np.log(1 + float(f0_o[t]) / 700) - O.F0_MEL_MIN) * 254 / (O.F0_MEL_MAX - O.F0_MEL_MIN) + 1
+        assert abs(abs(mel - np.floor(mel)) - 0.5) <= 2e-3 and abs(int(c_p[t]) - int(c_o[t])) == 1, (t, f0_o[t], mel, c_p[t], c_o[t])
+    err = rms(got - want)
+    print(f"{case} plain (peaked RMVPE, no override): waveform rms err {err:.3e} (oracle rms {rms(want):.3f}, oracle {t_oracle:.0f} s); "
+          f"{len(f0_p)} frames: f0 max relative difference {f0_rel:.2e}, salience max abs difference {sal_err:.2e}, "
+          f"{int((am_p != am_o).sum())} arg-max moves to the neighbouring bin, {len(flips)} coarse-bin rounding near-ties")
+    assert f0_rel <= 2e-5, f0_rel
+    assert len(flips) <= 0.002 * len(f0_p), len(flips)
+    assert err <= 1e-3, err
 
 
 def test_multi_segment_matches_reference_golden(S, hubert):
@@ -185,8 +253,6 @@ def test_45s_two_segments_vs_oracle(S, hubert, sds):
     assert err <= 1e-3, err
     assert info["tie_frames"] <= 0.002 * info["n_frames"], info
     assert info["coarse_flips"] <= 0.002 * info["n_frames"], info
-    if info["tie_frames"] == 0:
-        assert info["plain_err"] <= PLAIN_GATE, info
 
 
 @pytest.mark.parametrize("hint", [1, 2])

@@ -266,6 +266,42 @@ def test_knn_screened_regime_survives_hostile_data(native, dev):
     assert (i_scr == torch.arange(8)[None, :]).all()
 
 
+def test_knn_screened_regime_fp16_subnormal_rows(native, dev):
+    """The screening bound measures the fp16 rounding residuals ||x - x~|| with scalar conversions that keep subnormals; it
+    is only a bound if the matrix cores do not flush fp16 subnormal operands to zero.  Rows (and queries) whose elements sit
+    in the fp16 subnormal range (|x| < 6.1e-5, down to below its smallest subnormal 6e-8) must give the exact regime's
+    answer bit for bit; so must a mixed index where only a sub-cluster is that small."""
+    g = torch.Generator().manual_seed(31)
+    n, dim = 20_000, 768
+    tiny = torch.randn(n, dim, generator=g) * 2e-5                  # almost every element subnormal in fp16
+    tiny[::7] *= 1e-3                                               # ... and some below the smallest subnormal
+    q = tiny[torch.randint(0, n, (140,), generator=g)] + 2e-6 * torch.randn(140, dim, generator=g)
+    (d_exact, i_exact), (d_scr, i_scr) = _both_regimes(native, tiny.to(dev), q.to(dev))
+    assert torch.equal(i_exact, i_scr) and torch.equal(d_exact, d_scr)
+    mixed = torch.randn(n, dim, generator=g) * 0.3
+    mixed[3000:6000] = torch.randn(3000, dim, generator=g) * 3e-5   # a cluster at the origin, subnormal in fp16
+    q = torch.cat([mixed[3000:3070] * 1.01, mixed[torch.randint(0, n, (70,), generator=g)] * 0.99])
+    (d_exact, i_exact), (d_scr, i_scr) = _both_regimes(native, mixed.to(dev), q.to(dev))
+    assert torch.equal(i_exact, i_scr) and torch.equal(d_exact, d_scr)
+    assert (i_scr[:70, 0] == torch.arange(3000, 3070)).all()
+
+
+@pytest.mark.parametrize("n_q", [96, 1599])
+def test_knn_screened_equals_exact_at_two_million_rows(native, dev, n_q):
+    """BASELINE cfg 5's index size (2 000 000 x 768, 6.1 GB): screened == exact regime, ids and distances bit-identical, at a
+    short clip's query count and at the full 30 s utterance's 1599."""
+    import bench
+    index = bench.synth_index_device(torch, 2_000_000, dev, seed=0)
+    g = torch.Generator(device=dev).manual_seed(5)
+    pick = torch.randint(0, index.shape[0], (n_q,), device=dev, generator=g)
+    q = index[pick] + 0.03 * torch.randn(n_q, 768, device=dev, generator=g)
+    q[::3] = torch.randn(len(q[::3]), 768, device=dev, generator=g)
+    (d_exact, i_exact), (d_scr, i_scr) = _both_regimes(native, index, q)
+    assert torch.equal(i_exact, i_scr)
+    assert torch.equal(d_exact, d_scr)
+    del index
+
+
 # ---- K4 log-mel --------------------------------------------------------------------------------------
 def test_logmel_golden(native, dev):
     g = load_golden("logmel")

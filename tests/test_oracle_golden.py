@@ -199,3 +199,31 @@ def test_whole_pipeline_multi_segment():
     assert len(taps["opt_ts"]) == 2 and g["segs"].shape == (3, 2)
     assert out.shape == g["out"].shape                       # segment lengths, crops: integer bookkeeping
     assert rms(out - g["out"]) <= 2e-5, rms(out - g["out"])
+
+
+def test_rmvpe_peaked_matches_reference():
+    """The trained-like (unimodal salience) synthetic RMVPE, synthetic.make_rmvpe_state_dict(peaked=True): oracle vs the
+    reference's own RMVPE0Predictor on a 3 s clip (fixture: make_golden_peaked.py), plus the property the unconditional
+    full-length GPU tests rest on -- one bump per frame, recorded there for the full-length inputs."""
+    g = load_golden("rmvpe_peaked")
+    assert (float(g["proj_mean"]), float(g["proj_std"])) == pytest.approx(S.PEAKED_STATS[0], rel=1e-5)
+    for k in ("30s_seed0", "45s_seed45"):
+        assert float(g[k + "_peak_min"]) >= 0.4 and float(g[k + "_off_bump_max"]) <= 1e-4
+    sd = S.make_rmvpe_state_dict(0, peaked=True)
+    assert np.array_equal(O.rmvpe_decode(g["salience"].copy()), g["f0"])
+    taps = {}
+    f0 = O.rmvpe_infer_from_audio(g["audio_pad"], sd, taps=taps)
+    assert taps["salience"].shape == g["salience"].shape
+    assert np.abs(taps["salience"] - g["salience"]).max() <= 2e-5
+    assert np.all(f0 > 0) and np.abs(f0 / g["f0"] - 1).max() <= 2e-5
+
+
+def test_whole_pipeline_peaked_rmvpe_smooth_pitch_embedding():
+    g = load_golden("pipeline_peaked")
+    cpt = S.make_synth_checkpoint(48000, "HiFi-GAN", seed=0, smooth_pitch=True)
+    torch.manual_seed(int(g["seed"]))
+    out = O.pipeline(S.make_hubert_state_dict(1), S.make_rmvpe_state_dict(0, peaked=True), cpt, g["audio"].copy(),
+                     sid=int(g["sid"]), big_npy=S.synth_index(4096, seed=0), index_rate=float(g["index_rate"]),
+                     protect=float(g["protect"]))
+    assert out.shape == g["out"].shape
+    assert rms(out - g["out"]) <= 2e-5, rms(out - g["out"])
