@@ -37,6 +37,7 @@ struct ConvParams {
     float out_scale = 1.f;
     int batch = 1;
     const uint32_t *w_wino16 = nullptr;   // ... stored as bf16 pairs (with w16)
+    const void *w_winobf = nullptr;  // the transformed taps as bf16x3 matrix-instruction fragments (winobf.hip): taken first where it applies
     const float *w_wino = nullptr;   // the same taps in wino.hip's layout: launch_conv may take the fast (Winograd) form for
                                      // plain 3 / 7 / 11-tap layers where it is the faster one
     int debug = 0;   // experiments only (RVC_CONV_DEBUG): 1 = skip x loads, 2 = skip y stores, 4 = skip res loads
@@ -76,6 +77,16 @@ int launch_wino_conv(const float *x, const void *u, bool u_bf16, const float *bi
 void wino_pack_host(const float *w_host, int c_out, int c_in, int k, std::vector<float> *out);
 void wino_pack_host_bf16(const float *w_host, int c_out, int c_in, int k, std::vector<uint32_t> *out);   // one word per channel pair
 int wino_pack_weight(const float *w_host, int c_out, int c_in, int k, float **out_dev);
+
+// the same 7- / 11-tap layers on the bf16 matrix cores with fp32 operands split exactly into three bf16 (winobf.hip)
+bool winobf_enabled();   // RVC_WINOBF != 0 (conv.hip)
+bool winobf_supported(int c_in, int c_out, int k, int dil);
+bool winobf_fits(int c_in, int c_out, int64_t L);
+size_t winobf_weight_bytes(int c_out, int c_in, int k);
+void winobf_pack_host(const float *w_host, int c_out, int c_in, int k, std::vector<uint16_t> *out);
+int winobf_pack_weight(const float *w_host, int c_out, int c_in, int k, void **out_dev);
+int launch_winobf_conv(const float *x, const void *u, const float *bias, const float *res, const float *accin, float *y, int batch,
+                       int c_in, int c_out, int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream);
 
 // host-side repacks (return freshly hipMalloc'ed device buffers)
 // regular conv weight [c_out][c_in][k] -> [k][c_in][c_out]

@@ -402,7 +402,22 @@ bool wino_enabled() {
     return mode != 0;
 }
 
+// The 7- / 11-tap layers at >= 64 channels run the same Winograd form on the bf16 matrix cores with fp32 operands split
+// exactly into three bf16 (winobf.hip): 1.06-1.36x the fp32-matrix-instruction form on every such shape of the 48 kHz
+// vocoders (tools/bench_convbf.py, profiles/r03_convbf_shapes.txt).  RVC_WINOBF=0 switches it off.
+bool winobf_enabled() {
+    static const int mode = env_int("RVC_WINOBF", 1);
+    return mode != 0;
+}
+
 int launch_conv(const ConvParams &p_in, hipStream_t stream) {
+    const bool plain_square = !p_in.x2 && p_in.up_stride == 0 && p_in.c1 == p_in.m_total && p_in.bias_bstride == 0 &&
+        p_in.l_in == p_in.l_out && p_in.n_cols == p_in.l_out && p_in.x1_bstride == (int64_t)p_in.c1 * p_in.l_in &&
+        p_in.y_bstride == (int64_t)p_in.m_total * p_in.l_out && p_in.slope1 >= 0.f && p_in.slope1 <= 1.f && p_in.padl == (p_in.kw - 1) / 2 * p_in.dil;
+    if (p_in.w_winobf && plain_square && wino_enabled() && winobf_enabled() && winobf_supported(p_in.c1, p_in.m_total, p_in.kw, p_in.dil) &&
+        winobf_fits(p_in.c1, p_in.m_total, p_in.l_in))
+        return launch_winobf_conv(p_in.x1, p_in.w_winobf, p_in.bias, p_in.res, p_in.accin, p_in.y, p_in.batch, p_in.c1, p_in.m_total, p_in.l_out,
+                                  p_in.kw, p_in.dil, p_in.slope1, p_in.out_scale, stream);
     if ((p_in.w_wino || p_in.w_wino16) && !p_in.x2 && p_in.up_stride == 0 && p_in.c1 == p_in.m_total && p_in.bias_bstride == 0 &&
         p_in.l_in == p_in.l_out && p_in.n_cols == p_in.l_out && p_in.x1_bstride == (int64_t)p_in.c1 * p_in.l_in &&
         p_in.y_bstride == (int64_t)p_in.m_total * p_in.l_out && p_in.c1 % 32 == 0 && p_in.slope1 >= 0.f && p_in.slope1 <= 1.f && p_in.padl == (p_in.kw - 1) / 2 * p_in.dil &&

@@ -44,6 +44,7 @@ struct ConvW {
     DevBuf16 w16;                 // set instead of w when the handle stores its ResBlock weights as bf16
     DevBuf wu;                    // square 3 / 7 / 11-tap layers: the taps again in wino.hip's layout
     DevBuf16 wu16;                // ... as bf16 pairs when the handle stores bf16 (two uint16 per word)
+    DevBuf16 wx;                  // square 7 / 11-tap layers at >= 64 channels (fp32 storage): transformed taps split in three bf16 (winobf.hip)
     int c_in = 0, c_out = 0, k = 0;
 };
 

@@ -393,6 +393,11 @@ int build_conv(const rvc_decoder *d, const std::string &prefix, int c_out, int c
         } else {
             wino_pack_host(w->data.data(), c_out, c_in, k, &packed);
             if (out->wu.upload(packed)) return 1;
+            if (winobf_enabled() && winobf_supported(c_in, c_out, k, 1)) {   // third copy: the bf16-matrix-core form's fragments
+                std::vector<uint16_t> frags;
+                winobf_pack_host(w->data.data(), c_out, c_in, k, &frags);
+                if (out->wx.upload(frags)) return 1;
+            }
         }
     }
     if (bias) {
@@ -769,14 +774,14 @@ extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const flo
                 const int dil = c.res_dilations[j];
                 ConvParams p;
                 p.x1 = xin; p.c1 = s.c_out; p.slope1 = 0.1f; p.x1_bstride = bs; p.l_in = len;
-                p.w = s.c1[m * nd + j].w.p; p.w16 = s.c1[m * nd + j].w16.p; p.bias = s.c1[m * nd + j].b.p; p.w_wino = s.c1[m * nd + j].wu.p;
+                p.w = s.c1[m * nd + j].w.p; p.w16 = s.c1[m * nd + j].w16.p; p.bias = s.c1[m * nd + j].b.p; p.w_wino = s.c1[m * nd + j].wu.p; p.w_winobf = s.c1[m * nd + j].wx.p;
                 p.w_wino16 = reinterpret_cast<const uint32_t *>(s.c1[m * nd + j].wu16.p);
                 p.y = T1; p.y_bstride = bs; p.m_total = s.c_out; p.c_out = s.c_out; p.n_cols = len; p.l_out = len;
                 p.kw = k; p.dil = dil; p.padl = (k - 1) / 2 * dil; p.batch = batch;
                 if (launch_conv(p, stream)) return 1;
                 ConvParams q;
                 q.x1 = T1; q.c1 = s.c_out; q.slope1 = 0.1f; q.x1_bstride = bs; q.l_in = len;
-                q.w = s.c2[m * nd + j].w.p; q.w16 = s.c2[m * nd + j].w16.p; q.bias = s.c2[m * nd + j].b.p; q.w_wino = s.c2[m * nd + j].wu.p;
+                q.w = s.c2[m * nd + j].w.p; q.w16 = s.c2[m * nd + j].w16.p; q.bias = s.c2[m * nd + j].b.p; q.w_wino = s.c2[m * nd + j].wu.p; q.w_winobf = s.c2[m * nd + j].wx.p;
                 q.w_wino16 = reinterpret_cast<const uint32_t *>(s.c2[m * nd + j].wu16.p);
                 q.res = xin;
                 q.y_bstride = bs; q.m_total = s.c_out; q.c_out = s.c_out; q.n_cols = len; q.l_out = len;

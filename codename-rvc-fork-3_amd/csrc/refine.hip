@@ -422,13 +422,13 @@ int refine_forward(rvc_decoder *d, const float *z_dev, const float *f0_dev, cons
                 const int dil = c.res_dilations[j];
                 ConvParams p;
                 p.x1 = xin; p.c1 = s.ch_out; p.slope1 = slope; p.x1_bstride = bs; p.l_in = lo;
-                p.w = s.c1[m * nd + j].w.p; p.bias = s.c1[m * nd + j].b.p; p.w_wino = s.c1[m * nd + j].wu.p;
+                p.w = s.c1[m * nd + j].w.p; p.bias = s.c1[m * nd + j].b.p; p.w_wino = s.c1[m * nd + j].wu.p; p.w_winobf = s.c1[m * nd + j].wx.p;
                 p.y = T1; p.y_bstride = bs; p.m_total = s.ch_out; p.c_out = s.ch_out; p.n_cols = lo; p.l_out = lo;
                 p.kw = k; p.dil = dil; p.padl = (k - 1) / 2 * dil; p.batch = batch;
                 if (launch_conv(p, stream)) return 1;
                 ConvParams q;
                 q.x1 = T1; q.c1 = s.ch_out; q.slope1 = slope; q.x1_bstride = bs; q.l_in = lo;
-                q.w = s.c2[m * nd + j].w.p; q.bias = s.c2[m * nd + j].b.p; q.w_wino = s.c2[m * nd + j].wu.p;
+                q.w = s.c2[m * nd + j].w.p; q.bias = s.c2[m * nd + j].b.p; q.w_wino = s.c2[m * nd + j].wu.p; q.w_winobf = s.c2[m * nd + j].wx.p;
                 q.res = xin; q.y = Y;
                 q.y_bstride = bs; q.m_total = s.ch_out; q.c_out = s.ch_out; q.n_cols = lo; q.l_out = lo;
                 q.kw = k; q.dil = 1; q.padl = (k - 1) / 2; q.batch = batch;

@@ -94,6 +94,10 @@ SYMBOLS = {
     "rvc_conv1d_wino_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rvc_conv1d_wino_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                         c_int64, c_int, c_int, c_float, c_float, c_void_p]),
+    "rvc_conv1d_winobf_weight_bytes": (c_int, [c_int, c_int, c_int, POINTER(c_size_t)]),
+    "rvc_conv1d_winobf_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rvc_conv1d_winobf_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                          c_int64, c_int, c_int, c_float, c_float, c_void_p]),
     "rvc_conv2d_packed_floats": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
     "rvc_conv2d_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rvc_conv2d_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
@@ -523,6 +527,27 @@ def conv1d_wino_forward(x, u_packed, bias, c_out, k, dilation=1, slope_in=1.0, r
                                         res.data_ptr() if res is not None else None,
                                         acc.data_ptr() if acc is not None else None, y.data_ptr(), b, c_in, c_out, length, k,
                                         dilation, float(slope_in), float(out_scale), _stream()), "rvc_conv1d_wino_forward")
+    return y
+
+
+def conv1d_winobf_pack_weight(w: torch.Tensor, device) -> torch.Tensor:
+    w = w.detach().float().cpu().contiguous()
+    c_out, c_in, k = w.shape
+    n = c_size_t()
+    _check(_lib.rvc_conv1d_winobf_weight_bytes(c_out, c_in, k, ctypes.byref(n)), "rvc_conv1d_winobf_weight_bytes")
+    u = torch.empty(n.value // 2, dtype=torch.int16, device=device)
+    _check(_lib.rvc_conv1d_winobf_pack_weight(w.data_ptr(), c_out, c_in, k, u.data_ptr(), _stream()), "rvc_conv1d_winobf_pack_weight")
+    return u
+
+
+def conv1d_winobf_forward(x, u_packed, bias, c_out, k, dilation=1, slope_in=1.0, res=None, acc=None, out_scale=1.0, out=None):
+    x = _dev_f32(x, "x")
+    b, c_in, length = x.shape
+    y = out if out is not None else torch.empty((b, c_out, length), dtype=torch.float32, device=x.device)
+    _check(_lib.rvc_conv1d_winobf_forward(x.data_ptr(), u_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                          res.data_ptr() if res is not None else None,
+                                          acc.data_ptr() if acc is not None else None, y.data_ptr(), b, c_in, c_out, length, k,
+                                          dilation, float(slope_in), float(out_scale), _stream()), "rvc_conv1d_winobf_forward")
     return y
 
 

@@ -325,6 +325,20 @@ int rvc_conv1d_wino_forward(const float *x_dev, const float *u_dev, const float 
                             const float *acc_dev, float *y_dev, int batch, int c_in, int c_out, int64_t length, int k,
                             int dilation, float slope_in, float out_scale, void *stream);
 
+/* ---- ... and on the bf16 matrix cores with fp32-exact operands (what the decoder uses for its 7- / 11-tap layers at
+ * >= 64 channels) ------------------------------------------------------------------------------------------------------- *
+ * The same F(4,4) form with every fp32 operand split exactly into three bf16 numbers (8 + 8 + 8 significand bits) and the six
+ * products of order <= 2^-16 formed by v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the dropped terms are below 2^-23
+ * of a product.  One layer agrees with float64 as closely as the fp32 Winograd form does.
+ * K in {7, 11}, dilation 1..5, C_in a multiple of 16, C_out a multiple of 64, leaky slope in [0, 1], C_in * L < 2^29.
+ * u_dev: rvc_conv1d_winobf_weight_bytes() bytes -- the tap transform, evaluated in float64 on the host, rounded to fp32, split
+ * into three bf16 and laid out as matrix-instruction fragments by rvc_conv1d_winobf_pack_weight. */
+int rvc_conv1d_winobf_weight_bytes(int c_out, int c_in, int k, size_t *bytes);
+int rvc_conv1d_winobf_pack_weight(const float *w_host, int c_out, int c_in, int k, void *u_dev, void *stream);
+int rvc_conv1d_winobf_forward(const float *x_dev, const void *u_dev, const float *bias_dev, const float *res_dev,
+                              const float *acc_dev, float *y_dev, int batch, int c_in, int c_out, int64_t length, int k,
+                              int dilation, float slope_in, float out_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

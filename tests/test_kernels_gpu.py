@@ -79,6 +79,41 @@ def test_conv1d_winograd_matches_float64(native, dev, c_in, c_out, k, dil, lengt
     assert (plain - direct).abs().max().item() <= 6e-5
 
 
+@pytest.mark.parametrize("c_in,c_out,k,dil,length,batch", [
+    (64, 64, 7, 3, 700, 1), (128, 128, 11, 5, 513, 1), (128, 128, 11, 1, 4096, 1), (128, 128, 7, 1, 4097, 1),
+    (256, 256, 11, 3, 2051, 1), (64, 128, 7, 1, 777, 1), (128, 64, 11, 1, 1234, 2), (64, 64, 11, 5, 9999, 1),
+    (256, 256, 7, 5, 300, 2), (128, 128, 11, 3, 31, 1), (64, 64, 7, 1, 16384, 1),
+])
+def test_conv1d_winograd_bf16x3_matches_float64(native, dev, c_in, c_out, k, dil, length, batch):
+    """winobf.hip: the F(4,4) form of the 7- / 11-tap ResBlock convs (residuals.py:75-86) on the bf16 matrix cores, every
+    fp32 operand split exactly into three bf16 and the six products of order <= 2^-16 accumulated in fp32.  Against
+    F.conv1d in float64 with the fused activation, bias, residual, running sum and scale; every dilation, lengths that are
+    not multiples of a tile, blocks with ragged tile counts, batch > 1.  The gate is the fp32 Winograd form's (6e-5 at
+    |y| ~ 1), and the relative RMS error must not exceed 1.5x the fp32 Winograd form's on the same input."""
+    g = torch.Generator().manual_seed(c_in * 1000 + k * 10 + dil)
+    x = torch.randn(batch, c_in, length, generator=g)
+    w = torch.randn(c_out, c_in, k, generator=g) / (c_in * k) ** 0.5
+    b = torch.randn(c_out, generator=g)
+    res = torch.randn(batch, c_out, length, generator=g)
+    acc = torch.randn(batch, c_out, length, generator=g)
+    ref = (F.conv1d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), padding=(k - 1) // 2 * dil, dilation=dil) + res.double()
+           + acc.double()) / 3
+    u = native.conv1d_winobf_pack_weight(w, dev)
+    got = native.conv1d_winobf_forward(x.to(dev), u, b.to(dev), c_out, k, dil, 0.1, res=res.to(dev), acc=acc.to(dev), out_scale=1 / 3).cpu()
+    err = (got.double() - ref).abs().max().item()
+    assert err <= 6e-5, err
+    ref2 = F.conv1d(x.double(), w.double(), None, padding=(k - 1) // 2 * dil, dilation=dil)
+    plain = native.conv1d_winobf_forward(x.to(dev), u, None, c_out, k, dil, 1.0).cpu()
+    assert (plain.double() - ref2).abs().max().item() <= 6e-5
+    fp32w = native.conv1d_wino_forward(x.to(dev), native.conv1d_wino_pack_weight(w, dev), None, c_out, k, dil, 1.0).cpu()
+    direct = native.conv1d_forward(x.to(dev), native.conv1d_pack_weight(w, dev), None, c_out, k, dil, 1.0).cpu()
+    rel = lambda t: ((t.double() - ref2).pow(2).mean().sqrt() / ref2.pow(2).mean().sqrt()).item()
+    r_bf, r_w, r_d = rel(plain), rel(fp32w), rel(direct)
+    print(f"C {c_in}->{c_out} k {k} d {dil} L {length}: relative RMS error vs float64: bf16x3 Winograd {r_bf:.2e}, fp32 Winograd {r_w:.2e}, "
+          f"fp32 direct {r_d:.2e}")
+    assert r_bf <= 1.5 * r_w
+
+
 def test_conv1d_winograd_f43_groups_still_pass():
     """7- and 11-tap layers default to F(4,4) groups; the F(4,3) form of the same kernel (RVC_WINO_R4=0, read once per
     process) stays covered by re-running the Winograd test above in a child process."""
