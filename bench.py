@@ -23,8 +23,8 @@ through the C ABI (rvc_index_broadcast) and verified by a device-side checksum; 
 ("scaling": "weak").  On each GPU `--inflight` utterances (default 2) are in flight at a time, each on its own HIP stream.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      the dominant kernel (the 11-tap 128-channel ResBlock conv of vocoder stage 1, fp32 MFMA implicit GEMM),
-                timed live with HIP events on the launch stream
+  roofline      the dominant kernel symbol (the 11-tap ResBlock convs of vocoder stages 0-2: Winograd F(4,4) on the bf16 matrix
+                cores with fp32 operands split exactly into three bf16), timed live with HIP events on the launch stream
   roofline_knn  the L2 top-8 search at this config's (queries x rows), HBM bytes per pass as SURVEY §8d defines them
   host_io       the same K steps with host NumPy in / host float32 out (PCIe inclusive) at the same `inflight`
   cpu_baseline  the oracle (CPU restatement of the reference, oracle/rvc_oracle.py) on the host cores, on the config's own
@@ -46,12 +46,15 @@ for p in (ROOT, os.path.join(ROOT, "codename-rvc-fork-3_amd")):
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = FP32 vector peak
 PEAK_F16_MFMA_TFLOPS = 2500.0   # dense fp16/bf16 MFMA
 PEAK_HBM_GBS = 8000.0           # HBM3E spec
+PMC_BF_BYTES = None             # set from profiles/r03_pmc_winobf.txt once collected
 # average HBM bytes per launch of the roofline kernel symbol at the cfg-2 shape, from the PMC passes committed under
 # profiles/ (cannot be collected inside bench.py: it needs rocprofv3)
-PMC_TRAFFIC_BYTES = 446.9e6
-PMC_TRAFFIC_SOURCE = ("profiles/r02_pmc_wino.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
-                      "tools/pmc_conv.py (this same 18-launch mix, tools/pmc_wino.sh), average per launch; FETCH_SIZE calibrated "
-                      "per access width on launches with known byte counts (4 B/lane loads 0.566, 16 B/lane 0.5)")
+PMC_TRAFFIC = {
+    "bf16x3": (PMC_BF_BYTES, "profiles/r03_pmc_winobf.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
+               "tools/pmc_conv.py (this same 18-launch mix of winobf_conv_kernel<11,0>, tools/pmc_wino.sh), average per launch; "
+               "FETCH_SIZE calibrated per access width on launches with known byte counts"),
+    "fp32": (446.9e6, "profiles/r02_pmc_wino.txt (round 2, wino_conv_kernel<11,2,2,8,0,false>: same bytes by construction as <...,false,4>)"),
+}
 
 CONFIGS = {
     1: dict(seconds=10.0, sr=40000, vocoder="HiFi-GAN", index_rows=0, index_rate=0.0, weights="f32",
@@ -106,28 +109,32 @@ def cpu_model_string():
 
 # ---- roofline legs ----------------------------------------------------------------------------------------------------
 def roofline_mix(torch, native, dev, T, rates, k=11):
-    """Every launch of the dominant kernel symbol, wino_conv_kernel<11,2,2,8,0,false,4> (11 taps, F(4,4) groups), in one utterance's vocoder forward: the
-    11-tap ResBlock of stages 0-2 (C = 256, 128, 64; the C = 32 stage takes the 1 x 4-wave symbol), per stage and for each
-    dilation d: conv1 (dilation d) then conv2 (dilation 1, + residual; the last one also + running sum, x 1/3) -- 18 launches,
-    the same population rocprofv3 --stats averages over for that symbol.
-    Returns (callable, algorithmic flops per call, launches per call, algorithmic HBM bytes per call, executed flops)."""
+    """Every launch of the dominant kernel symbol in one utterance's vocoder forward: the 11-tap ResBlock of stages 0-2
+    (C = 256, 128, 64; the C = 32 stage takes the fp32 1 x 4-wave symbol), per stage and for each dilation d: conv1
+    (dilation d) then conv2 (dilation 1, + residual; the last one also + running sum, x 1/3) -- 18 launches, the same
+    population rocprofv3 --stats averages over for that symbol.  The symbol is winobf_conv_kernel<11,0> (Winograd F(4,4) on
+    the bf16 matrix cores, fp32 operands split exactly into three bf16) unless RVC_WINOBF=0 / RVC_WINO=0 selects the round-2
+    form wino_conv_kernel<11,2,2,8,0,false,4> (fp32 matrix instruction).
+    Returns (callable, algorithmic flops per call, launches per call, algorithmic HBM bytes per call, executed flops, form)."""
     gen = torch.Generator().manual_seed(1)
     stages, flops, executed, alg_bytes = [], 0.0, 0.0, 0.0
-    # multiply-adds the kernel executes per 4 outputs and (c_in, c_out) pair: F(4,4) -- 7 points per group of four taps -- for
-    # 7 / 11 taps unless RVC_WINO_R4 masks it out (wino.hip), else F(4,3) -- 6 points per group of three
-    r4 = int(os.environ.get("RVC_WINO_R4", "3")) & (1 if k == 7 else 2 if k == 11 else 0)
-    points = 7 * ((k + 3) // 4) if r4 else 6 * ((k + 2) // 3)
+    form = "bf16x3" if os.environ.get("RVC_WINOBF", "1") != "0" and os.environ.get("RVC_WINO", "1") != "0" else "fp32"
+    # multiply-adds executed per 4 outputs and (c_in, c_out) pair: F(4,4) -- 7 points per group of four taps; the bf16x3 form
+    # spends six bf16 products on each
+    points = 7 * ((k + 3) // 4)
+    per_mac = 6 if form == "bf16x3" else 1
+    pack = native.conv1d_winobf_pack_weight if form == "bf16x3" else native.conv1d_wino_pack_weight
+    fwd = native.conv1d_winobf_forward if form == "bf16x3" else native.conv1d_wino_forward
     L = T
     for i in range(3):
         C, L = 512 >> (i + 1), L * rates[i]
         x = torch.randn(1, C, L, device=dev)
         st = dict(C=C, x=x, t1=torch.empty_like(x), y=torch.randn(1, C, L, device=dev), acc=torch.randn(1, C, L, device=dev),
-                  w1=native.conv1d_wino_pack_weight(torch.randn(C, C, k, generator=gen) * 0.02, dev),
-                  w2=native.conv1d_wino_pack_weight(torch.randn(C, C, k, generator=gen) * 0.02, dev),
+                  w1=pack(torch.randn(C, C, k, generator=gen) * 0.02, dev), w2=pack(torch.randn(C, C, k, generator=gen) * 0.02, dev),
                   bias=torch.zeros(C, device=dev))
         stages.append(st)
         flops += 6 * 2.0 * C * C * k * L                          # SURVEY 8d: 2 x MACs of the conv as the reference computes it
-        executed += 6 * 2.0 * C * C * points * (L / 4.0)
+        executed += 6 * 2.0 * C * C * points * (L / 4.0) * per_mac
         tensor = C * L * 4.0
         alg_bytes += 3 * (2 * tensor) + 2 * (3 * tensor) + 1 * (4 * tensor)   # conv1: r+w; conv2: r+res+w (+acc)
 
@@ -135,13 +142,12 @@ def roofline_mix(torch, native, dev, T, rates, k=11):
         for st in stages:
             C = st["C"]
             for j, d in enumerate((1, 3, 5)):
-                native.conv1d_wino_forward(st["x"], st["w1"], st["bias"], C, k, d, 0.1, out=st["t1"])
+                fwd(st["x"], st["w1"], st["bias"], C, k, d, 0.1, out=st["t1"])
                 if j < 2:
-                    native.conv1d_wino_forward(st["t1"], st["w2"], st["bias"], C, k, 1, 0.1, res=st["x"], out=st["y"])
+                    fwd(st["t1"], st["w2"], st["bias"], C, k, 1, 0.1, res=st["x"], out=st["y"])
                 else:
-                    native.conv1d_wino_forward(st["t1"], st["w2"], st["bias"], C, k, 1, 0.1, res=st["x"], acc=st["acc"],
-                                               out_scale=1 / 3, out=st["y"])
-    return run, flops, 18, alg_bytes, executed
+                    fwd(st["t1"], st["w2"], st["bias"], C, k, 1, 0.1, res=st["x"], acc=st["acc"], out_scale=1 / 3, out=st["y"])
+    return run, flops, 18, alg_bytes, executed, form
 
 
 def decoder_flops(T, rates, ksizes, c0=512, cin=192, res_k=(3, 7, 11), n_dil=3):
@@ -309,7 +315,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32 (vocoder 7/11-tap convs: fp32 operands as exact bf16x3 splits on the bf16 matrix cores, fp32 accumulate)" if os.environ.get("RVC_WINOBF", "1") != "0" else "f32",
         "data": "synthetic (seeded random-init weights, FM-tone utterances, clustered index)",
         "rtf": round(value / sr, 2),
         "headline_is": "inputs resident in HBM, waveform left in HBM (the bench contract's definition of `value`); `host_io` is the "
@@ -398,8 +404,8 @@ def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev, utterance):
     T = min(n_pad // 160, 2 * F_)                     # synth frames (pipeline.py:467)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    # ---- dominant kernel symbol: wino_conv_kernel<11,2,2,8,0,false,4> (the 11-tap ResBlock convs of stages 0-2) ----
-    run_mix, mix_flops, mix_launches, mix_alg_bytes, mix_executed = roofline_mix(torch, _native, dev, T, rates)
+    # ---- dominant kernel symbol: the 11-tap ResBlock convs of stages 0-2 ----
+    run_mix, mix_flops, mix_launches, mix_alg_bytes, mix_executed, form = roofline_mix(torch, _native, dev, T, rates)
     for _ in range(2):
         run_mix()
     reps = 5
@@ -412,26 +418,36 @@ def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev, utterance):
     flops_launch = mix_flops / mix_launches
     cfg2 = T == 3198 and list(rates[:3]) == [12, 10, 2]
     exe_launch = mix_executed / mix_launches
-    res["roofline"] = {
-        "kernel": f"rvc::wino_conv_kernel<11,2,2,8,0,false,4>: ALL 18 launches per utterance of this symbol -- the 11-tap ResBlock "
-                  f"convs of vocoder stages 0-2 (C=256/128/64 at {T * rates[0]}/{T * rates[0] * rates[1]}/"
-                  f"{T * rates[0] * rates[1] * rates[2]} columns), in the decoder's own mix (dilations 1/3/5, residual on every "
-                  "second one); per-launch figures are averages over the 18",
-        "bound": "mfma", "achieved": round(flops_launch / t_launch / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-        "unit": "TFLOP/s", "frac": round(flops_launch / t_launch / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-        "achieved_is": "ALGORITHMIC flops (2 x MACs of the 11-tap conv, SURVEY 8d) / launch time.  The kernel is a Winograd "
-                       "F(4,4) form (7 products per 4 outputs per group of 4 taps) and EXECUTES 7*3/(4*11) = 0.477 of them on "
-                       "the matrix pipe, so frac can pass 1; the pipe's own occupancy is executed_frac",
-        "executed_tflops": round(exe_launch / t_launch / 1e12, 2),
-        "executed_frac": round(exe_launch / t_launch / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-        "traffic": PMC_TRAFFIC_BYTES if cfg2 else None,
-        "traffic_source": PMC_TRAFFIC_SOURCE if cfg2 else None,
-        "algorithmic_bytes_per_launch": round(mix_alg_bytes / mix_launches),
-        "flops_per_launch": flops_launch, "executed_flops_per_launch": exe_launch, "avg_launch_ms": round(t_launch * 1e3, 4),
-        "launches_per_utterance": mix_launches,
-        "timing": "HIP events around the isolated launch mix on the launch stream (nothing else running); rocprofv3 "
-                  "--stats agrees for a sequential run (profiles/); with two utterances in flight a kernel's traced "
-                  "duration also contains the time it shares the chip"}
+    shapes = (f"the 11-tap ResBlock convs of vocoder stages 0-2 (C=256/128/64 at {T * rates[0]}/{T * rates[0] * rates[1]}/"
+              f"{T * rates[0] * rates[1] * rates[2]} columns), in the decoder's own mix (dilations 1/3/5, residual on every second "
+              "one); per-launch figures are averages over the 18")
+    traffic, traffic_src = PMC_TRAFFIC[form] if cfg2 else (None, None)
+    common = {"traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(mix_alg_bytes / mix_launches),
+              "algorithmic_flops_per_launch": flops_launch, "executed_flops_per_launch": exe_launch,
+              "algorithmic_tflops": round(flops_launch / t_launch / 1e12, 2),
+              "algorithmic_vs_fp32_mfma_peak": round(flops_launch / t_launch / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+              "avg_launch_ms": round(t_launch * 1e3, 4), "launches_per_utterance": mix_launches,
+              "timing": "HIP events around the isolated launch mix on the launch stream (nothing else running); rocprofv3 --stats "
+                        "agrees for a sequential run (profiles/); with two utterances in flight a kernel's traced duration also "
+                        "contains the time it shares the chip"}
+    if form == "bf16x3":
+        res["roofline"] = {
+            "kernel": "rvc::winobf_conv_kernel<11,0>: ALL 18 launches per utterance of this symbol -- " + shapes,
+            "bound": "mfma", "achieved": round(exe_launch / t_launch / 1e12, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(exe_launch / t_launch / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+            "achieved_is": "bf16 matrix flops the kernel EXECUTES / launch time, against the dense bf16 MFMA peak: the pipe's own "
+                           "occupancy.  One fp32 multiply-add of the Winograd F(4,4) form (7 * 3 / (4 * 11) = 0.477 of the conv's "
+                           "multiply-adds) costs six bf16 products (fp32 operands split exactly into three bf16, fp32 accumulate); "
+                           "the SURVEY 8d ALGORITHMIC rate (2 x MACs of the 11-tap conv / time) is algorithmic_tflops, "
+                           "i.e. algorithmic_vs_fp32_mfma_peak x the 157.3 TF an fp32-matrix-instruction kernel could reach",
+            **common}
+    else:
+        res["roofline"] = {
+            "kernel": "rvc::wino_conv_kernel<11,2,2,8,0,false,4>: ALL 18 launches per utterance of this symbol -- " + shapes,
+            "bound": "mfma", "achieved": round(exe_launch / t_launch / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(exe_launch / t_launch / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+            "achieved_is": "fp32 matrix flops the kernel EXECUTES (Winograd F(4,4): 0.477 of the conv's multiply-adds) / launch time",
+            **common}
     del run_mix
 
     # ---- whole vocoder, timed with events around rvc_decoder_forward ----

@@ -22,16 +22,34 @@
 //        the window of tile t + g d, so each window is transformed ONCE per block (wino.hip transforms it per group and per
 //        channel-block wave: 6x) and read back 2 G times.
 //
-// What bounds it is operand delivery, not the pipe: the transformed taps are 7 G / K x 1.5 = 2.9x the raw fp32 taps in
-// bytes, and a block can only amortise them over the tile columns its accumulators cover.  Block = 64 output channels x
-// 128 tiles (512 outputs), 8 waves (2 x 4, each 32 channels x 32 tiles x 7 points = 112 accumulator registers), one block
-// per CU: the tap stream is 16 B/clk/CU at full matrix rate, from L2.
+// Block = 64 output channels x 128 window columns, 8 waves (2 x 4, each 32 channels x 32 tiles x 7 points = 112 accumulator
+// registers), one block per CU.  The transformed taps are 7 G / K x 1.5 = 2.9x the raw fp32 taps in bytes and a block can only
+// amortise them over the columns its accumulators cover: at this shape the tap stream is 16 B/clk/CU at full matrix rate,
+// from L2.  Of the 128 columns, 128 - (G - 1) d are valid tiles and the rest are the windows the later groups reach, so the
+// 8 channel pairs x 128 windows of a chunk are exactly two rounds of the 512 threads.
 //
-// The K loop runs over STEPS = (chunk of 16 input channels) x (point p): a step needs 18 KiB of taps (LDS-DMA, ring of
-// three slots, issued two steps ahead) and the 14 KiB X_p of the chunk (ring of two), does G x 6 matrix instructions per
-// wave, and ends in one barrier.  While the matrix instructions of step s run, the vector ALU transforms X for step s + 1:
-// the two waves that share a SIMD run the two halves of a step in OPPOSITE order (waves 0-3 transform then multiply,
-// waves 4-7 multiply then transform), so one of them is always on the matrix pipe.
+// The K loop runs over STEPS = (chunk of 16 input channels) x (point p): a step needs 18 KiB of tap fragments (LDS-DMA, ring of
+// three slots, issued two steps ahead from inside the step) and the 14 KiB X_p of the chunk (ring of two), does 6 G matrix
+// instructions per wave into ONE accumulator, and ends in one barrier.  The raw input rows of the next chunk are fetched in
+// two halves into the second of two raw buffers.
+//
+// What shaped the step body (each item measured on MI355X, tools/ablate_winobf.sh, tools/pmc_winobf.sh):
+//   * a dependent v_mfma_f32_32x32x16_bf16 issues ~64 cycles after its predecessor (the pipe takes one every 32), so the 18
+//     instructions of a step are a 1152-cycle chain per wave; the two waves of a SIMD fill each other's slots.  Everything
+//     else a step does -- the input transform + split of the NEXT step (LDS reads, ~40 vector instructions, LDS writes), the
+//     fragment reads of the next tap group, the three LDS-DMA issues, the raw-row stores -- is cut into ~15 stages that are
+//     placed, one per gap, BETWEEN the matrix instructions of the wave's own chain (sched_barrier pins the order).  Left to
+//     the compiler the matrix instructions are issued back to back and the transform after them, and the two add up: 563 us
+//     instead of 458 at C = 128, K = 11 (first version: separate transform and multiply phases in opposite order on the two
+//     waves of a SIMD -- no overlap at all, the per-wave serial path is what counts);
+//   * the window fragments are single-buffered: the products of a group are ordered so that b2 and b1 die early and are
+//     reloaded for the next group while the current one finishes;
+//   * measured limits: matrix pipe busy 35 % (the chain latency + ~900 cycles per step of barrier, LDS latency after the
+//     barrier and DMA issue), LDS 35 % busy, 13 % of its cycles bank conflicts (the 4-byte B-fragment writes).  A second
+//     accumulator chain per step (products alternating between the point's accumulator and a step-local one) would let one
+//     wave saturate the pipe, but 7 x 16 + 16 accumulator registers next to the operand tuples do not fit 256 registers
+//     without spilling whole accumulators (tried with VGPR and with AGPR-pinned accumulators: 676 us); 16x16x32 instructions
+//     (four independent 16x16 tiles per wave tile, split pairs concatenated along K) need 1.7x the LDS fragment reads.
 #include <stdlib.h>
 
 #include <mutex>
@@ -119,7 +137,6 @@ winobf_conv_kernel(const WinoBfParams p) {
     constexpr int NP = WBF_NP, R = WBF_R, G = GM::G, C0 = GM::C0, MLO = GM::MLO, MHI = GM::MHI;
     constexpr int BM = WBF_BM, BNT = WBF_BNT, NW = WBF_NW, NTH = WBF_NTH, CIC = WBF_CIC, CP = WBF_CP;
     constexpr int XT = GM::XT, XTS = GM::XTS, XBP = GM::XBP, NJ = GM::NJ, UPW = GM::UPW;
-    constexpr bool CHAINS2 = (DBG & 128) != 0;
 
     extern __shared__ __attribute__((aligned(16))) float wbf_smem[];
     unsigned char *const smem = reinterpret_cast<unsigned char *>(wbf_smem);
@@ -386,28 +403,17 @@ winobf_conv_kernel(const WinoBfParams p) {
             if (M) { f_read_a(0, ab); f_read_b(0, 2, bb); f_read_b(0, 1, bb); f_read_b(0, 0, bb); }
             if (T) t_read(PN{}, 0, raw);
             __builtin_amdgcn_sched_barrier(0);
-            // A matrix instruction can issue every 32 cycles but its result is ready after ~64, so a single accumulator chain
-            // runs the pipe at half rate.  CHAINS2: the 6 G products of a step alternate between the point's accumulator and a
-            // step-local one that starts from zero and is added at the end of the step (one extra fp32 rounding per step).
-            f32x16 part;
-            int n_mm = 0;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 constexpr int ia[6] = {0, 1, 0, 2, 1, 0}, ib[6] = {2, 1, 1, 0, 0, 0};
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
-                    if (M) {
-                        if (!CHAINS2 || (n_mm & 1) == 0) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g & 1][ia[i]], fb[ib[i]], acc[pt], 0, 0, 0);
-                        else if (n_mm == 1) part = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g & 1][ia[i]], fb[ib[i]], f32x16{}, 0, 0, 0);
-                        else part = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g & 1][ia[i]], fb[ib[i]], part, 0, 0, 0);
-                    }
-                    ++n_mm;
+                    if (M) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g & 1][ia[i]], fb[ib[i]], acc[pt], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     filler(g * 6 + i);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (M && CHAINS2) acc[pt] += part;
             if (!M) {   // ablation: the fillers that did not get a slot
 #pragma unroll
                 for (int k = 6 * G; k < 18; ++k) filler(k);
@@ -447,6 +453,13 @@ winobf_conv_kernel(const WinoBfParams p) {
         o[r].y = fmaf(0.5f, m34, m12) + fmaf(2.f, t5, bv);
         o[r].z = fmaf(0.25f, s34, s12) + fmaf(4.f, t5, bv);
         o[r].w = fmaf(0.125f, m34, m12) + fmaf(8.f, t5, t6) + bv;
+    }
+    if (DBG & 32) {   // ablation: no epilogue traffic (and the register count of the loop alone)
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += o[r].x + o[r].y + o[r].z + o[r].w;
+        if (sum == 12345.678f) y[tid] = sum;
+        return;
     }
     const bool l4 = (L & 3) == 0;
     if (d == 1 && l4) {
@@ -579,7 +592,7 @@ int launch_winobf_conv(const float *x, const void *u, const float *bias, const f
             case 15: return winobf_launch<11, 15>(p, stream);
             case 16: return winobf_launch<11, 16>(p, stream);
             case 31: return winobf_launch<11, 31>(p, stream);
-            case 128: return winobf_launch<11, 128>(p, stream);
+            case 32: return winobf_launch<11, 32>(p, stream);
             default: break;
         }
     }

@@ -18,8 +18,8 @@ for C, L in ((128, T * 120),):
         y.copy_(x)                                                            # known: 1 tensor read, 1 written (16 B/lane)
         _native.conv1d_forward_into(x, w1, bias, C, 1, 1, 0.1, res=res, out=y)    # known: x + res read (4 B/lane loads), y written
     print("calibration tensor bytes", C, L, x.numel() * 4)
-run, flops, launches, alg, executed = bench.roofline_mix(torch, _native, dev, T, rates)
+run, flops, launches, alg, executed, form = bench.roofline_mix(torch, _native, dev, T, rates)
 for _ in range(3):
     run()
 torch.cuda.synchronize()
-print("mix: flops", flops, "executed", executed, "launches", launches, "algorithmic bytes", alg)
+print("mix:", form, "flops", flops, "executed", executed, "launches", launches, "algorithmic bytes", alg)

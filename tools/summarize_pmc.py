@@ -18,7 +18,7 @@ cal16 = 0.5   # the guide's factor for 16 B/lane streaming reads (measured 0.500
 out.append(f"calibration, 4 B/lane loads (direct conv, K=1, x + res): known reads {2*tensor/1e6:.1f} MB -> FETCH_SIZE {f1/1e6:.1f} MB "
            f"(factor {cal4:.3f}); known writes {tensor/1e6:.1f} MB -> WRITE_SIZE {w1/1e6:.1f} MB (factor {w1/tensor:.3f}); "
            f"16 B/lane loads: factor {cal16}")
-wk = lambda r: "wino_conv_kernel<11, 2, 2, 8, 0" in r["Kernel_Name"]
+wk = lambda r: "wino_conv_kernel<11, 2, 2, 8, 0" in r["Kernel_Name"] or "winobf_conv_kernel<11" in r["Kernel_Name"]
 f, w = vals(F, wk), vals(W, wk)
 n = len(f) // 18
 pos_f = [st.mean(f[i::18][-n:]) for i in range(18)]
@@ -34,6 +34,7 @@ for i in range(18):
     reads = x_raw / cal4 + extra_raw / cal16
     tot += reads + pos_w[i]
     out.append(f"  stage {stage} launch {j} {names[j]:18s}: FETCH_SIZE raw {pos_f[i]/1e6:7.1f} MB -> reads {reads/1e6:7.1f} MB; WRITE_SIZE {pos_w[i]/1e6:7.1f} MB")
-out.append(f"roofline kernel wino_conv_kernel<11,2,2,8,0>: {len(f)} launches profiled ({n} runs of the 18-launch mix)")
+names_seen = sorted({r["Kernel_Name"].split("(")[0] for r in F if wk(r)})
+out.append(f"roofline kernel {names_seen}: {len(f)} launches profiled ({n} runs of the 18-launch mix)")
 out.append(f"TRAFFIC_BYTES_PER_LAUNCH {tot / 18:.0f}")
 print("\n".join(out))
