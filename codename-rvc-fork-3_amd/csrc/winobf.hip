@@ -49,7 +49,10 @@
 //     accumulator chain per step (products alternating between the point's accumulator and a step-local one) would let one
 //     wave saturate the pipe, but 7 x 16 + 16 accumulator registers next to the operand tuples do not fit 256 registers
 //     without spilling whole accumulators (tried with VGPR and with AGPR-pinned accumulators: 676 us); 16x16x32 instructions
-//     (four independent 16x16 tiles per wave tile, split pairs concatenated along K) need 1.7x the LDS fragment reads.
+//     (four independent 16x16 tiles per wave tile, two splits concatenated along K: (a0|a1).(b1|b0) = a0 b1 + a1 b0 ...) need
+//     1.7x the LDS fragment reads and measured 524 us.  Four waves of 512 registers, each 32 channels x 64 tiles (two
+//     accumulators per point = two chains per wave), measured 467 us: without a partner wave the ~550 cycles of barrier /
+//     LDS latency / DMA issue per step are exposed.  What remains is the per-step synchronisation, not the chain.
 #include <stdlib.h>
 
 #include <mutex>
