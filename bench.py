@@ -46,7 +46,7 @@ for p in (ROOT, os.path.join(ROOT, "codename-rvc-fork-3_amd")):
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = FP32 vector peak
 PEAK_F16_MFMA_TFLOPS = 2500.0   # dense fp16/bf16 MFMA
 PEAK_HBM_GBS = 8000.0           # HBM3E spec
-PMC_BF_BYTES = None             # set from profiles/r03_pmc_winobf.txt once collected
+PMC_BF_BYTES = 465.3e6          # profiles/r03_pmc_winobf.txt
 # average HBM bytes per launch of the roofline kernel symbol at the cfg-2 shape, from the PMC passes committed under
 # profiles/ (cannot be collected inside bench.py: it needs rocprofv3)
 PMC_TRAFFIC = {
@@ -283,7 +283,7 @@ def main():
     del outs
 
     # the boundary as the reference has it: host NumPy in, host float32 NumPy out (PCIe inclusive), same schedule
-    run_steps(audios_host, 0, inflight)
+    run_steps(audios_host, 0, 2 * inflight)   # every stream touches both of its page-locked slots once
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     houts = run_steps(audios_host, args.warmup, args.steps)

@@ -591,6 +591,9 @@ int launch_winobf_conv(const float *x, const void *u, const float *bias, const f
             case 3: return winobf_launch<11, 3>(p, stream);
             case 4: return winobf_launch<11, 4>(p, stream);
             case 8: return winobf_launch<11, 8>(p, stream);
+            case 9: return winobf_launch<11, 9>(p, stream);
+            case 13: return winobf_launch<11, 13>(p, stream);
+            case 29: return winobf_launch<11, 29>(p, stream);
             case 11: return winobf_launch<11, 11>(p, stream);
             case 15: return winobf_launch<11, 15>(p, stream);
             case 16: return winobf_launch<11, 16>(p, stream);

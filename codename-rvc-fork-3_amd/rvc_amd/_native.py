@@ -98,6 +98,11 @@ SYMBOLS = {
     "rvc_conv1d_winobf_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rvc_conv1d_winobf_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                           c_int64, c_int, c_int, c_float, c_float, c_void_p]),
+    "rvc_gemm_bf16x3_weight_bytes": (c_int, [c_int, c_int, POINTER(c_size_t)]),
+    "rvc_gemm_bf16x3_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rvc_linear_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "rvc_conv1d_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_int, c_int,
+                                  c_void_p]),
     "rvc_conv2d_packed_floats": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
     "rvc_conv2d_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rvc_conv2d_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
@@ -548,6 +553,46 @@ def conv1d_winobf_forward(x, u_packed, bias, c_out, k, dilation=1, slope_in=1.0,
                                           res.data_ptr() if res is not None else None,
                                           acc.data_ptr() if acc is not None else None, y.data_ptr(), b, c_in, c_out, length, k,
                                           dilation, float(slope_in), float(out_scale), _stream()), "rvc_conv1d_winobf_forward")
+    return y
+
+
+# ---- K11: fp32 GEMM / strided conv1d as exact bf16x3 splits on the bf16 matrix cores ----------------------------
+def gemm_bf16x3_pack_weight(w: torch.Tensor, device) -> torch.Tensor:
+    """nn.Linear weight [out, in] or nn.Conv1d weight [c_out, c_in, taps] -> fragment slab on the device."""
+    w = w.detach().float().cpu().contiguous()
+    taps = w.shape[2] if w.dim() == 3 else 1
+    m, k_total = w.shape[0], w.shape[1] * taps
+    n = c_size_t()
+    _check(_lib.rvc_gemm_bf16x3_weight_bytes(m, k_total, ctypes.byref(n)), "rvc_gemm_bf16x3_weight_bytes")
+    a = torch.empty(n.value // 2, dtype=torch.int16, device=device)
+    _check(_lib.rvc_gemm_bf16x3_pack_weight(w.data_ptr(), m, k_total, taps, a.data_ptr(), _stream()), "rvc_gemm_bf16x3_pack_weight")
+    return a
+
+
+def linear_bf16x3(x: torch.Tensor, a_packed: torch.Tensor, bias, out_features: int, act: str = "none", res=None) -> torch.Tensor:
+    """y = act(x W^T + b) + res for x [..., in] (fp32, HBM, contiguous)."""
+    x = _dev_f32(x, "x")
+    in_features = x.shape[-1]
+    n_rows = x.numel() // in_features
+    y = torch.empty(x.shape[:-1] + (out_features,), dtype=torch.float32, device=x.device)
+    if res is not None:
+        res = _dev_f32(res, "res")
+        assert res.shape == y.shape
+    _check(_lib.rvc_linear_bf16x3(x.data_ptr(), a_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                  res.data_ptr() if res is not None else None, y.data_ptr(), n_rows, in_features, out_features,
+                                  {"none": 0, "gelu": 1}[act], _stream()), "rvc_linear_bf16x3")
+    return y
+
+
+def conv1d_bf16x3(x: torch.Tensor, a_packed: torch.Tensor, bias, c_out: int, k: int, stride: int = 1, padding: int = 0,
+                  act: str = "none") -> torch.Tensor:
+    """nn.Conv1d(c_in, c_out, k, stride, padding) + activation for x [batch, c_in, L] (fp32, HBM, contiguous)."""
+    x = _dev_f32(x, "x")
+    b, c_in, l_in = x.shape
+    l_out = (l_in + 2 * padding - k) // stride + 1
+    y = torch.empty((b, c_out, l_out), dtype=torch.float32, device=x.device)
+    _check(_lib.rvc_conv1d_bf16x3(x.data_ptr(), a_packed.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(), b,
+                                  c_in, c_out, l_in, k, stride, padding, {"none": 0, "gelu": 1}[act], _stream()), "rvc_conv1d_bf16x3")
     return y
 
 

@@ -156,6 +156,7 @@ class VoiceConverter:
             n_workers = 1   # parity mode replays torch's GLOBAL CPU generator stream: one utterance at a time
         if not hasattr(self, "_batch_streams"):
             self._batch_streams = []
+            self._batch_slots = {}
         while len(self._batch_streams) < n_workers:
             self._batch_streams.append(torch.cuda.Stream(device=dev))
         ready = torch.cuda.Event()
@@ -167,7 +168,8 @@ class VoiceConverter:
             # stream, both ways asynchronously on the utterance's own stream: the worker enqueues utterance k + 1 while
             # utterance k is still running and only waits for a slot's event when it needs that slot again -- no
             # per-utterance stream synchronise, so the stream never drains between utterances.
-            slots = [dict(inp=None, out=None, up=None, done=None, idx=None, n=0) for _ in range(2)]
+            # (the page-locked buffers belong to the stream, not to the call: allocating them costs milliseconds)
+            slots = self._batch_slots.setdefault(tid, [dict(inp=None, out=None, up=None, done=None, idx=None, n=0) for _ in range(2)])
 
             def finish(slot):
                 if slot["idx"] is not None:

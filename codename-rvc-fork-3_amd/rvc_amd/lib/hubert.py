@@ -9,6 +9,7 @@ run through hipBLASLt / SDPA on the matrix cores; everything stays fp32 (README.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict
 
 import torch
@@ -34,6 +35,17 @@ class HubertModelWithFinalProj:
     def load_state_dict(self, sd, strict: bool = True):
         w = fold_weight_norm(sd)
         self.w = {k: v.to(self.device) for k, v in w.items() if v.is_floating_point()}
+        # feature-extractor convs 1-4 (512 -> 512, 3 taps, stride 2; 51 k .. 6 k columns for a 30 s clip) run in librvc_amd's K11
+        # (gemmbf.hip: exact bf16x3 splits on the bf16 matrix cores, GELU in the epilogue): 1.1-1.5x MIOpen's NHWC igemm + its
+        # transposes + the GELU pass (tools/bench_gemmbf.py).  The two short 2-tap layers and the fp32 projections stay on the
+        # libraries, which are faster at those sizes (the 1599-row GEMMs fill a third of the chip in 128 x 128 tiles).
+        self._conv_bf = {}
+        if self.device.type == "cuda" and os.environ.get("RVC_HUBERT_CONV", "1") != "0":
+            from rvc_amd import _native
+            for i in (1, 2, 3, 4):
+                cw = self.w[f"feature_extractor.conv_layers.{i}.conv.weight"]
+                if cw.shape[0] % 128 == 0 and cw.shape[1] % 16 == 0:
+                    self._conv_bf[i] = _native.gemm_bf16x3_pack_weight(cw, self.device)
         self._qkv = {}
         for i in range(self.n_layers):
             L = f"encoder.layers.{i}.attention"
@@ -50,6 +62,7 @@ class HubertModelWithFinalProj:
         self.device = torch.device(device)
         self.w = {k: v.to(self.device) for k, v in self.w.items()}
         self._qkv = {i: (a.to(self.device), b.to(self.device), s) for i, (a, b, s) in self._qkv.items()}
+        self._conv_bf = {i: a.to(self.device) for i, a in self._conv_bf.items()} if self.device.type == "cuda" else {}
         return self
 
     def float(self):
@@ -66,7 +79,12 @@ class HubertModelWithFinalProj:
         w = self.w
         x = wav[:, None, :]
         for i, s in enumerate(CONV_STRIDES):
-            x = F.conv1d(x, w[f"feature_extractor.conv_layers.{i}.conv.weight"], None, stride=s)
+            cw = w[f"feature_extractor.conv_layers.{i}.conv.weight"]
+            if i in self._conv_bf and x.is_cuda:
+                from rvc_amd import _native
+                x = _native.conv1d_bf16x3(x, self._conv_bf[i], None, cw.shape[0], cw.shape[2], stride=s, act="gelu")
+                continue
+            x = F.conv1d(x, cw, None, stride=s)
             if i == 0:
                 x = F.group_norm(x, x.shape[1], w["feature_extractor.conv_layers.0.layer_norm.weight"],
                                  w["feature_extractor.conv_layers.0.layer_norm.bias"], 1e-5)

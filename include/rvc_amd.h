@@ -339,6 +339,21 @@ int rvc_conv1d_winobf_forward(const float *x_dev, const void *u_dev, const float
                               const float *acc_dev, float *y_dev, int batch, int c_in, int c_out, int64_t length, int k,
                               int dilation, float slope_in, float out_scale, void *stream);
 
+/* ---- K11: fp32 GEMM / strided conv1d on the bf16 matrix cores with fp32-exact operands ------------------------------------ *
+ * Replaces the fp32 library GEMMs behind `transformers`' HubertModel at rvc/infer/pipeline.py:450: the attention / FFN
+ * projections (nn.Linear: y = act(x W^T + b) + res, x [n_rows][in] row-major) and the stride-2 convolutions of the feature
+ * extractor (nn.Conv1d without padding + GELU, x [batch][C_in][L] channel-major).  Every fp32 operand is split exactly into three
+ * bf16 numbers and the six products of order <= 2^-16 are accumulated in fp32 (csrc/gemmbf.hip); results agree with float64 as
+ * closely as an fp32 GEMM does.  act: 0 none, 1 GELU (erf form, what torch.nn.functional.gelu computes).
+ * Weights: rvc_gemm_bf16x3_weight_bytes() bytes filled by rvc_gemm_bf16x3_pack_weight from the [out][in] (linear, conv_taps = 1) or
+ * [C_out][C_in][taps] (conv, conv_taps = taps, k_total = taps * C_in) host tensor.  out / C_out a multiple of 128, in / C_in of 16. */
+int rvc_gemm_bf16x3_weight_bytes(int m, int k_total, size_t *bytes);
+int rvc_gemm_bf16x3_pack_weight(const float *w_host, int m, int k_total, int conv_taps, void *a_dev, void *stream);
+int rvc_linear_bf16x3(const float *x_dev, const void *a_dev, const float *bias_dev, const float *res_dev, float *y_dev,
+                      int64_t n_rows, int in_features, int out_features, int act, void *stream);
+int rvc_conv1d_bf16x3(const float *x_dev, const void *a_dev, const float *bias_dev, float *y_dev, int batch, int c_in,
+                      int c_out, int64_t l_in, int k, int stride, int padding, int act, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

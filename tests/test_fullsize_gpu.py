@@ -324,6 +324,41 @@ def test_convert_array_caller_vs_oracle(S, hubert, sds, tmp_path):
     assert rms(no_index - got) > 1e-3                                             # the index file really was found and used
 
 
+def test_convert_array_split_audio_vs_oracle(S, hubert):
+    """a18's split branch on the GPU (infer.py:283-318): the input is cut at its silences (process_audio), every chunk goes
+    through Pipeline.pipeline on the device, merge_audio puts them back on the time line.  Expected value: the oracle run on
+    the same chunks under the same seed, merged by the same host function (process_audio / merge_audio themselves are pinned
+    to the reference on CPU, tests/test_host_logic_cpu.py).  Trained-like RMVPE / pitch embedding, so nothing is tie-aware."""
+    from oracle import rvc_oracle as O
+    from rvc_amd.infer.infer import VoiceConverter
+    from rvc_amd.lib.tools.split_audio import merge_audio, process_audio
+    rm_sd, hub_sd = S.make_rmvpe_state_dict(0, peaked=True), S.make_hubert_state_dict(1)
+    cpt = S.make_synth_checkpoint(48000, "HiFi-GAN", seed=0, smooth_pitch=True)
+    vc = VoiceConverter(device=DEV)
+    vc.load_checkpoint_dict(cpt)
+    vc.hubert_model = hubert
+    vc.vc.load_rmvpe_state_dict(rm_sd)
+    gap = np.zeros(12000)
+    audio = np.concatenate([np.zeros(3000), S.synth_audio(28000, seed=31), gap, S.synth_audio(36000, seed=32), gap,
+                            S.synth_audio(24000, seed=33), np.zeros(5000)])
+    chunks, intervals = process_audio(audio, 16000)
+    assert len(chunks) == 3 and all(len(c) > 16000 for c in chunks), [len(c) for c in chunks]
+    want_chunks = []
+    for c in chunks:
+        torch.manual_seed(808)
+        want_chunks.append(O.pipeline(hub_sd, rm_sd, cpt, np.asarray(c, dtype=np.float64).copy(), sid=0, pitch=0, big_npy=None,
+                                      index_rate=0.0, protect=0.5).astype(np.float32))
+    want = merge_audio(chunks, want_chunks, intervals, 16000, 48000)
+    got = vc.convert_array(audio, index_path="", index_rate=0.0, protect=0.5, sid=0, noise_seed=808, split_audio=True)
+    assert got.shape == want.shape and got.dtype == np.float32
+    assert 0 <= 3 * len(audio) - got.shape[0] <= 3 * 16000 * 0.5           # the 48 kHz time line of the input, minus its trailing silence
+    err = rms(got - want)
+    print(f"convert_array(split_audio=True), 3 chunks: rms err {err:.3e} (oracle rms {rms(want):.3f})")
+    assert err <= 1e-3, err
+    whole = vc.convert_array(audio, index_path="", index_rate=0.0, protect=0.5, sid=0, noise_seed=808, split_audio=False)
+    assert whole.shape != got.shape or rms(whole - got) > 1e-3               # the split path really ran
+
+
 def test_rccl_single_rank_broadcast_and_device_checksum():
     """The C-ABI RCCL path on one GPU: bind librccl at run time, ncclCommInitRank with one rank, broadcast in place,
     ncclCommCount == 1; rvc_checksum64 equals the documented formula evaluated in NumPy."""

@@ -114,6 +114,60 @@ def test_conv1d_winograd_bf16x3_matches_float64(native, dev, c_in, c_out, k, dil
     assert r_bf <= 1.5 * r_w
 
 
+@pytest.mark.parametrize("n_rows,k,m,act,with_res", [
+    (1599, 768, 2304, "none", False), (1599, 768, 768, "none", True), (1599, 768, 3072, "gelu", False),
+    (1599, 3072, 768, "none", True), (149, 768, 768, "gelu", True), (1, 512, 768, "none", False), (130, 16, 128, "none", False),
+])
+def test_linear_bf16x3_matches_float64(native, dev, n_rows, k, m, act, with_res):
+    """gemmbf.hip, linear mode: the HuBERT projections (transformers' HubertModel behind pipeline.py:450) as exact bf16x3
+    splits on the bf16 matrix cores.  Against float64; the relative RMS error must stay at the level torch's fp32 GEMM
+    (hipBLASLt) leaves on the same operands (<= 2x + 1e-7).  Shapes: the four projection shapes at the cfg-2 frame count, a short clip,
+    one row, the smallest legal k."""
+    g = torch.Generator().manual_seed(n_rows + k + m)
+    x = torch.randn(n_rows, k, generator=g)
+    w = torch.randn(m, k, generator=g) / k ** 0.5
+    b = torch.randn(m, generator=g)
+    res = torch.randn(n_rows, m, generator=g) if with_res else None
+    ref = F.linear(x.double(), w.double(), b.double())
+    if act == "gelu":
+        ref = F.gelu(ref)
+    if with_res:
+        ref = ref + res.double()
+    a = native.gemm_bf16x3_pack_weight(w, dev)
+    got = native.linear_bf16x3(x.to(dev), a, b.to(dev), m, act=act, res=res.to(dev) if with_res else None).cpu()
+    lib = F.linear(x.to(dev), w.to(dev), b.to(dev))
+    lib = (F.gelu(lib) if act == "gelu" else lib).cpu()
+    if with_res:
+        lib = lib + res
+    rel = lambda t: ((t.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    print(f"linear {n_rows} x {k} -> {m} ({act}{', +res' if with_res else ''}): relative RMS error vs float64: bf16x3 {rel(got):.2e}, "
+          f"torch fp32 {rel(lib):.2e}; max abs {(got.double() - ref).abs().max().item():.2e}")
+    assert (got.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert rel(got) <= 2.0 * rel(lib) + 1e-7          # both at the fp32 rounding level (1-3e-7)
+
+
+@pytest.mark.parametrize("c_in,c_out,k,stride,length,batch,act", [
+    (512, 512, 3, 2, 5119, 1, "gelu"), (512, 512, 2, 2, 640, 2, "gelu"), (64, 128, 3, 1, 300, 1, "none"), (512, 512, 3, 2, 4, 1, "none"),
+])
+def test_conv1d_bf16x3_matches_float64(native, dev, c_in, c_out, k, stride, length, batch, act):
+    """gemmbf.hip, conv mode: HuBERT's feature-extractor convs (Conv1d(512, 512, k in {3, 2}, stride 2, no padding) + GELU)."""
+    g = torch.Generator().manual_seed(c_in + c_out + k + length)
+    x = torch.randn(batch, c_in, length, generator=g)
+    w = torch.randn(c_out, c_in, k, generator=g) / (c_in * k) ** 0.5
+    ref = F.conv1d(x.double(), w.double(), None, stride=stride)
+    if act == "gelu":
+        ref = F.gelu(ref)
+    a = native.gemm_bf16x3_pack_weight(w, dev)
+    got = native.conv1d_bf16x3(x.to(dev), a, None, c_out, k, stride=stride, act=act).cpu()
+    assert got.shape == ref.shape
+    lib = F.conv1d(x.to(dev), w.to(dev), None, stride=stride)
+    lib = (F.gelu(lib) if act == "gelu" else lib).cpu()
+    rel = lambda t: ((t.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    print(f"conv1d {c_in}->{c_out} k {k} s {stride} L {length}: relative RMS error vs float64: bf16x3 {rel(got):.2e}, torch fp32 {rel(lib):.2e}")
+    assert (got.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert rel(got) <= 1e-6          # 1536 sequentially accumulated terms: the level of conv.hip's direct fp32 form (4-10e-7)
+
+
 def test_conv1d_winograd_f43_groups_still_pass():
     """7- and 11-tap layers default to F(4,4) groups; the F(4,3) form of the same kernel (RVC_WINO_R4=0, read once per
     process) stays covered by re-running the Winograd test above in a child process."""
