@@ -56,7 +56,8 @@ typedef __bf16 gbf_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned gbf_u32x4 __attribute__((ext_vector_type(4)));
 typedef void __attribute__((address_space(3))) *gbf_lptr_t;
 
-template <int XMODE>
+// DBG (ablations, wrong results): 1 no activation staging after the prologue, 2 no matrix instructions, 4 no tap DMA, 8 no barrier
+template <int XMODE, int DBG = 0>
 __global__ void __launch_bounds__(GBF_NTH) __attribute__((amdgpu_waves_per_eu(2, 2)))
 gemmbf_kernel(const GemmBfParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gbf_smem[];
@@ -155,9 +156,9 @@ gemmbf_kernel(const GemmBfParams p) {
 
     for (int s = 0; s < n_steps; ++s) {
         const bool more1 = s + 1 < n_steps, more2 = s + 2 < n_steps;
-        if (more2) dma_a(s + 2);
-        if (more1) store_x(s + 1);          // registers fetched during step s - 1
-        if (more2) load_x(s + 2);
+        if (more2 && !(DBG & 4)) dma_a(s + 2);
+        if (more1 && !(DBG & 1)) store_x(s + 1);          // registers fetched during step s - 1
+        if (more2 && !(DBG & 1)) load_x(s + 2);
         const unsigned char *ab = as + (s % 3) * GBF_A_SLOT + wm * 2 * 3 * 1024 + lane * 16;
         const unsigned char *bb = bs + (s & 1) * GBF_B_SLOT + half * GBF_B_PLANE + (wn * 64 + l31) * 16;
         gbf_bf16x8 fb[2][3];
@@ -175,12 +176,12 @@ gemmbf_kernel(const GemmBfParams p) {
             for (int i = 0; i < 6; ++i)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ia[i]], fb[ni][ib[i]], acc[mi][ni], 0, 0, 0);
+                    if (!(DBG & 2)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ia[i]], fb[ni][ib[i]], acc[mi][ni], 0, 0, 0);
         }
         // everything older than this step's own memory operations has completed: the tap fragments of step s + 1 are in LDS
-        if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + (XMODE == 0 ? 2 : 8)) : "memory");
+        if (more2 && !(DBG & 5)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + (XMODE == 0 ? 2 : 8)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        lds_barrier();
+        if (!(DBG & 8)) lds_barrier();
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------
@@ -232,6 +233,21 @@ static int gemmbf_launch(GemmBfParams p, hipStream_t stream) {
     p.n_col_blocks = (int)ceil_div(p.N, GBF_BN);
     const int n_m = p.M / GBF_BM;
     dim3 grid((unsigned)(ceil_div(p.n_col_blocks, 8) * 8 * n_m), 1, (unsigned)p.batch);
+    static const int dbg = getenv("RVC_GBF_DBG") ? atoi(getenv("RVC_GBF_DBG")) : 0;
+    if (dbg && p.x_mode == 1) {
+        auto go = [&](auto k) { (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, GBF_LDS); hipLaunchKernelGGL(k, grid, dim3(GBF_NTH), GBF_LDS, stream, p); };
+        switch (dbg) {
+            case 1: go(gemmbf_kernel<1, 1>); break;
+            case 2: go(gemmbf_kernel<1, 2>); break;
+            case 3: go(gemmbf_kernel<1, 3>); break;
+            case 4: go(gemmbf_kernel<1, 4>); break;
+            case 8: go(gemmbf_kernel<1, 8>); break;
+            case 7: go(gemmbf_kernel<1, 7>); break;
+            default: go(gemmbf_kernel<1, 0>); break;
+        }
+        RVC_LAUNCH_CHECK();
+        return 0;
+    }
     if (p.x_mode == 0) hipLaunchKernelGGL(gemmbf_kernel<0>, grid, dim3(GBF_NTH), GBF_LDS, stream, p);
     else hipLaunchKernelGGL(gemmbf_kernel<1>, grid, dim3(GBF_NTH), GBF_LDS, stream, p);
     RVC_LAUNCH_CHECK();
