@@ -97,42 +97,56 @@ gemmbf_kernel(const GemmBfParams p) {
     const int64_t n_col = n0 + t_l;
     const bool col_ok = n_col < p.N;
     float xv[8];
-    auto load_x = [&](int s) __attribute__((always_inline)) {
+    bool lx_ok_prev = true;   // conv mode: was the column of the values now in xv inside the input?
+    // (pieces, so that the step body can place them between matrix instructions)
+    const float *lx_src = nullptr;
+    bool lx_ok = true;
+    auto load_x_begin = [&](int s) __attribute__((always_inline)) {
         if constexpr (XMODE == 0) {
-            const float *src = x + (col_ok ? n_col : 0) * p.ldx + 16 * s + 8 * kh;
-            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src), v1 = *reinterpret_cast<const f32x4 *>(src + 4);
-            xv[0] = v0.x; xv[1] = v0.y; xv[2] = v0.z; xv[3] = v0.w; xv[4] = v1.x; xv[5] = v1.y; xv[6] = v1.z; xv[7] = v1.w;
+            lx_src = x + (col_ok ? n_col : 0) * p.ldx + 16 * s + 8 * kh;
         } else {
             const int k0 = 16 * s;
             const int tap = k0 / p.c_in, ci0 = k0 - tap * p.c_in + 8 * kh;
             const int64_t t_in = n_col * p.stride + (int64_t)tap * p.dil - p.pad;
-            const bool ok = col_ok && t_in >= 0 && t_in < p.l_in;
-            const float *src = x + (int64_t)ci0 * p.ldx + (ok ? t_in : 0);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) xv[e] = src[(int64_t)e * p.ldx];
-            if (!ok) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xv[e] = 0.f;
-            }
+            lx_ok = col_ok && t_in >= 0 && t_in < p.l_in;
+            lx_src = x + (int64_t)ci0 * p.ldx + (lx_ok ? t_in : 0);
         }
     };
-    // exact three-way split of the 8 values -> three 16-byte B-fragment pieces
-    auto store_x = [&](int s) __attribute__((always_inline)) {
-        gbf_u32x4 w[3];
-#pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2) {
-            gbf_f32x2 v = {xv[2 * e2], xv[2 * e2 + 1]};
-            if (XMODE == 0 && !col_ok) v = gbf_f32x2{0.f, 0.f};
-            const unsigned w0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, gbf_bf16x2));
-            const gbf_f32x2 r1 = v - gbf_f32x2{__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u)};
-            const unsigned w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, gbf_bf16x2));
-            const gbf_f32x2 r2 = r1 - gbf_f32x2{__uint_as_float(w1 << 16), __uint_as_float(w1 & 0xffff0000u)};
-            const unsigned w2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, gbf_bf16x2));
-            w[0][e2] = w0; w[1][e2] = w1; w[2][e2] = w2;
+    auto load_x_piece = [&](int e) __attribute__((always_inline)) {   // XMODE 0: e = 0, 1 (a float4 each); XMODE 1: e = 0..7
+        if constexpr (XMODE == 0) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(lx_src + 4 * e);
+            xv[4 * e] = v.x; xv[4 * e + 1] = v.y; xv[4 * e + 2] = v.z; xv[4 * e + 3] = v.w;
+        } else {
+            xv[e] = lx_src[(int64_t)e * p.ldx];
         }
+    };
+    constexpr int LX_PIECES = XMODE == 0 ? 2 : 8;
+    auto load_x = [&](int s) __attribute__((always_inline)) {
+        load_x_begin(s);
+#pragma unroll
+        for (int e = 0; e < LX_PIECES; ++e) load_x_piece(e);
+    };
+    // exact three-way split of the 8 values -> three 16-byte B-fragment pieces
+    gbf_u32x4 sw[3];
+    auto split_pair = [&](int e2) __attribute__((always_inline)) {
+        gbf_f32x2 v = {xv[2 * e2], xv[2 * e2 + 1]};
+        if (XMODE == 0 ? !col_ok : !lx_ok_prev) v = gbf_f32x2{0.f, 0.f};
+        const unsigned w0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, gbf_bf16x2));
+        const gbf_f32x2 r1 = v - gbf_f32x2{__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u)};
+        const unsigned w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, gbf_bf16x2));
+        const gbf_f32x2 r2 = r1 - gbf_f32x2{__uint_as_float(w1 << 16), __uint_as_float(w1 & 0xffff0000u)};
+        const unsigned w2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, gbf_bf16x2));
+        sw[0][e2] = w0; sw[1][e2] = w1; sw[2][e2] = w2;
+    };
+    auto store_split = [&](int s) __attribute__((always_inline)) {
         unsigned char *dst = bs + (s & 1) * GBF_B_SLOT + kh * GBF_B_PLANE + t_l * 16;
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) *reinterpret_cast<gbf_u32x4 *>(dst + sp * 2 * GBF_B_PLANE) = w[sp];
+        for (int sp = 0; sp < 3; ++sp) *reinterpret_cast<gbf_u32x4 *>(dst + sp * 2 * GBF_B_PLANE) = sw[sp];
+    };
+    auto store_x = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) split_pair(e2);
+        store_split(s);
     };
 
     f32x16 acc[2][2];
@@ -149,35 +163,65 @@ gemmbf_kernel(const GemmBfParams p) {
     dma_a(0);
     if (n_steps > 1) dma_a(1);
     load_x(0);
+    lx_ok_prev = lx_ok;
     store_x(0);
-    if (n_steps > 1) load_x(1);
+    if (n_steps > 1) { load_x(1); lx_ok_prev = lx_ok; }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XMODE == 0 ? 2 : 8) : "memory");   // the DMA pieces (older than step 1's loads) have landed
     lds_barrier();
 
+    // A wave's 24 matrix instructions per step run on four independent accumulators and issue every 32 cycles; the staging of
+    // the next steps (the three DMA issues, the split of step s + 1's values, their LDS writes, the global loads of step s + 2)
+    // is placed in the gaps between them -- left in front of them the two phases add up (193 + 187 + 187 us on the first conv
+    // layer: two blocks share a CU but start together and stay in lock step).
     for (int s = 0; s < n_steps; ++s) {
         const bool more1 = s + 1 < n_steps, more2 = s + 2 < n_steps;
-        if (more2 && !(DBG & 4)) dma_a(s + 2);
-        if (more1 && !(DBG & 1)) store_x(s + 1);          // registers fetched during step s - 1
-        if (more2 && !(DBG & 1)) load_x(s + 2);
         const unsigned char *ab = as + (s % 3) * GBF_A_SLOT + wm * 2 * 3 * 1024 + lane * 16;
         const unsigned char *bb = bs + (s & 1) * GBF_B_SLOT + half * GBF_B_PLANE + (wn * 64 + l31) * 16;
+        auto filler = [&](int k) __attribute__((always_inline)) {
+            if (k < 3) {
+                if (more2 && !(DBG & 4)) {
+                    unsigned char *dst = as + ((s + 2) % 3) * GBF_A_SLOT;
+                    const int n = wave + GBF_NW * k;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (gbf_lptr_t)(dst + n * 1024), 16, 16 * lane, blk_base + (s + 2) * GBF_A_SLOT + n * 1024, 0, 0);
+                }
+            } else if (k < 7) {
+                if (more1 && !(DBG & 1)) split_pair(k - 3);
+            } else if (k == 7) {
+                if (more1 && !(DBG & 1)) store_split(s + 1);
+            } else if (k == 8) {
+                if (more2 && !(DBG & 1)) load_x_begin(s + 2);
+            } else if (k < 9 + LX_PIECES) {
+                if (more2 && !(DBG & 1)) load_x_piece(k - 9);
+            }
+        };
         gbf_bf16x8 fb[2][3];
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int sp = 0; sp < 3; ++sp) fb[ni][sp] = rd(bb + sp * 2 * GBF_B_PLANE + ni * 32 * 16);
+        gbf_bf16x8 fa[2][3];
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) fa[0][sp] = rd(ab + sp * 1024);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
-            gbf_bf16x8 fa[3];
-#pragma unroll
-            for (int sp = 0; sp < 3; ++sp) fa[sp] = rd(ab + (mi * 3 + sp) * 1024);
             constexpr int ia[6] = {2, 0, 1, 1, 0, 0}, ib[6] = {0, 2, 1, 0, 1, 0};   // small terms first
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    if (!(DBG & 2)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ia[i]], fb[ni][ib[i]], acc[mi][ni], 0, 0, 0);
+                for (int ni = 0; ni < 2; ++ni) {
+                    if (!(DBG & 2)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][ia[i]], fb[ni][ib[i]], acc[mi][ni], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int k = mi * 12 + i * 2 + ni;
+                    if (k == 1) {
+#pragma unroll
+                        for (int sp = 0; sp < 3; ++sp) fa[1][sp] = rd(ab + (3 + sp) * 1024);
+                    }
+                    filler(k);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
         }
+        lx_ok_prev = lx_ok;
         // everything older than this step's own memory operations has completed: the tap fragments of step s + 1 are in LDS
         if (more2 && !(DBG & 5)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + (XMODE == 0 ? 2 : 8)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

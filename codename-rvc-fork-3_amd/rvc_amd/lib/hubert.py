@@ -35,14 +35,14 @@ class HubertModelWithFinalProj:
     def load_state_dict(self, sd, strict: bool = True):
         w = fold_weight_norm(sd)
         self.w = {k: v.to(self.device) for k, v in w.items() if v.is_floating_point()}
-        # feature-extractor convs 1-4 (512 -> 512, 3 taps, stride 2; 51 k .. 6 k columns for a 30 s clip) run in librvc_amd's K11
-        # (gemmbf.hip: exact bf16x3 splits on the bf16 matrix cores, GELU in the epilogue): 1.1-1.5x MIOpen's NHWC igemm + its
-        # transposes + the GELU pass (tools/bench_gemmbf.py).  The two short 2-tap layers and the fp32 projections stay on the
+        # feature-extractor convs 1-5 (512 -> 512, 3 / 2 taps, stride 2; 51 k .. 3 k columns for a 30 s clip) run in librvc_amd's K11
+        # (gemmbf.hip: exact bf16x3 splits on the bf16 matrix cores, GELU in the epilogue): 1.06-1.63x MIOpen's NHWC igemm + its
+        # transposes + the GELU pass (tools/bench_gemmbf.py).  The last 2-tap layer and the fp32 projections stay on the
         # libraries, which are faster at those sizes (the 1599-row GEMMs fill a third of the chip in 128 x 128 tiles).
         self._conv_bf = {}
         if self.device.type == "cuda" and os.environ.get("RVC_HUBERT_CONV", "1") != "0":
             from rvc_amd import _native
-            for i in (1, 2, 3, 4):
+            for i in (1, 2, 3, 4, 5):
                 cw = self.w[f"feature_extractor.conv_layers.{i}.conv.weight"]
                 if cw.shape[0] % 128 == 0 and cw.shape[1] % 16 == 0:
                     self._conv_bf[i] = _native.gemm_bf16x3_pack_weight(cw, self.device)
