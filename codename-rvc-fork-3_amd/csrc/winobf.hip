@@ -22,14 +22,20 @@
 //        the window of tile t + g d, so each window is transformed ONCE per block (wino.hip transforms it per group and per
 //        channel-block wave: 6x) and read back 2 G times.
 //
-// Block = 64 output channels x 128 window columns, 8 waves (2 x 4, each 32 channels x 32 tiles x 7 points = 112 accumulator
-// registers), one block per CU.  The transformed taps are 7 G / K x 1.5 = 2.9x the raw fp32 taps in bytes and a block can only
-// amortise them over the columns its accumulators cover: at this shape the tap stream is 16 B/clk/CU at full matrix rate,
-// from L2.  Of the 128 columns, 128 - (G - 1) d are valid tiles and the rest are the windows the later groups reach, so the
-// 8 channel pairs x 128 windows of a chunk are exactly two rounds of the 512 threads.
+// Block = BM output channels x BNT window columns, 8 waves (BM / 32 x BNT / 32, each 32 channels x 32 tiles x 7 points = 112
+// accumulator registers), one block per CU, in two shapes picked per layer by winobf_block_rows():
+//   64 x 128   the transformed taps are 7 G / K x 1.5 = 2.9x the raw fp32 taps in bytes and a block can only amortise them
+//              over the columns its accumulators cover: at this shape the tap stream is 16 B/clk/CU at full matrix rate, from
+//              L2.  Of the 128 columns, 128 - (G - 1) d are valid tiles and the rest are the windows the later groups reach;
+//              the 8 channel pairs x 128 windows of a chunk are two rounds of the 512 threads;
+//   128 x 64   the same matrix work per step with HALF the window transforms, splits and raw-row staging (one round of the
+//              512 threads) and twice the tap bytes (36 KiB per 11-tap step: LDS is full to 128 bytes); it gives up
+//              (G - 1) d of 64 columns instead of 128.  The kernels run power-limited, so the vector work
+//              removed is time removed: -12 .. -17 % on the 7-tap layers, -7 % on the 256-channel 11-tap ones; level on the
+//              128-channel 11-tap ones, which keep 64 x 128.
 //
-// The K loop runs over STEPS = (chunk of 16 input channels) x (point p): a step needs 18 KiB of tap fragments (LDS-DMA, ring of
-// three slots, issued two steps ahead from inside the step) and the 14 KiB X_p of the chunk (ring of two), does 6 G matrix
+// The K loop runs over STEPS = (chunk of 16 input channels) x (point p): a step needs 18 KiB of tap fragments (64 x 128, 11 taps;
+// LDS-DMA, ring of three slots, issued two steps ahead from inside the step) and the 14 KiB X_p of the chunk (ring of two), does 6 G matrix
 // instructions per wave into ONE accumulator, and ends in one barrier.  The raw input rows of the next chunk are fetched in
 // two halves into the second of two raw buffers.
 //
@@ -81,7 +87,9 @@ struct WinoBfParams {
 };
 
 constexpr int WBF_MAX_DIL = 5;
-constexpr int WBF_BM = 64, WBF_BNT = 128, WBF_NW = 8, WBF_NTH = 512, WBF_CIC = 16, WBF_CP = 8, WBF_NP = 7, WBF_R = 4;
+constexpr int WBF_NW = 8, WBF_NTH = 512, WBF_CIC = 16, WBF_CP = 8, WBF_NP = 7, WBF_R = 4;
+// block shapes: 64 channels x 128 window columns (waves 2 x 4), or 128 channels x 64 columns (4 x 2) where c_out allows -- all of a
+// 128-channel layer's outputs of a time tile in ONE block, so the raw rows are staged and transformed once instead of twice
 
 typedef float wbf_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 wbf_bf16x2 __attribute__((ext_vector_type(2)));
@@ -103,7 +111,7 @@ __device__ __forceinline__ float wbf_buf_load(__amdgpu_buffer_rsrc_t r, unsigned
 constexpr int WBF_RSRC_FLAGS = 0x00020000;
 
 // geometry shared by the kernel and the launcher
-template <int KW>
+template <int KW, int BM, int BNT>
 struct WbfGeom {
     static constexpr int G = (KW + WBF_R - 1) / WBF_R;
     static constexpr int C0 = (KW - 1) / 2;
@@ -112,33 +120,37 @@ struct WbfGeom {
     static constexpr int MHI = SMAX / 4;
     // a block's valid tiles + the (G - 1) d windows behind them are 128 transformed windows, so the raw rows span at most
     // 128 + (MHI - MLO - G + 1) d tiles
-    static constexpr int XT = WBF_BNT + (MHI - MLO - G + 1) * WBF_MAX_DIL;
+    static constexpr int WM = BM / 32, WN = BNT / 32;
+    static_assert(WM * WN == WBF_NW, "eight waves of 32 x 32");
+    static constexpr int XT = BNT + (MHI - MLO - G + 1) * WBF_MAX_DIL;
     static constexpr int XTS = ((XT - 12 + 31) / 32) * 32 + 12;         // raw row stride in float2, == 12 mod 32: the 4 de-interleaved
                                                                         // rows of a ds_write_b64 land in 4 bank groups
     static_assert(XTS >= XT + 2, "");
     static constexpr int RAW_BYTES = WBF_CP * 4 * XTS * 8;              // one raw chunk; two buffers
-    static constexpr int XB = WBF_BNT + (G - 1) * WBF_MAX_DIL;           // transformed windows per point
-    static constexpr int XBP = ((XB + 15) / 16) * 16;                   // plane stride in tiles
+    static constexpr int XB = BNT + (G - 1) * WBF_MAX_DIL;               // transformed windows per point (the matrix side reads up to here)
+    static constexpr int XBP = BNT == 128 ? ((XB + 15) / 16) * 16 : XB;  // plane stride in tiles (the 128 x 64 shape has 128 bytes of LDS to spare)
     static constexpr int B_SLOT = 3 * 2 * XBP * 16;                     // [split][k half][tile][8 bf16]
-    static constexpr int A_PIECES = G * 2 * 3;                          // 1 KiB fragments per step: [g][32-channel half][split]
+    static constexpr int A_PIECES = G * WM * 3;                         // 1 KiB fragments per step: [g][32-channel block][split]
     static constexpr int A_SLOT = A_PIECES * 1024;
     static constexpr int UPW = (A_PIECES + WBF_NW - 1) / WBF_NW;        // DMA pieces per wave per step
-    static_assert(UPW == G, "the step body places UPW pieces by hand");
+    static_assert(UPW <= (G == 3 ? 5 : 3), "the step body places UPW pieces by hand");
     static constexpr int NJ = (4 * XT + WBF_NTH - 1) / WBF_NTH;         // staged samples per thread per channel row
     static constexpr int LOOP_BYTES = 2 * RAW_BYTES + 2 * B_SLOT + 3 * A_SLOT;
-    static constexpr int YS = 4 * WBF_BNT + 4;
-    static constexpr int OUT_BYTES = WBF_BM * YS * 4;
+    static constexpr int YS = 4 * BNT + 4;
+    static constexpr int OUT_BYTES = BM * YS * 4;
+    static constexpr int TQ = BNT / 64;                                 // transform rounds per step: 8 channel pairs x BNT windows / 512 threads
     static constexpr int LDS_BYTES = LOOP_BYTES > OUT_BYTES ? LOOP_BYTES : OUT_BYTES;
+    static_assert(LDS_BYTES <= 163840, "LDS budget");
 };
 
 // DBG (ablations, wrong results; tools/ablate_winobf.sh): 1 no input transform, 2 no matrix instructions, 4 no tap DMA,
 // 8 no per-step barrier, 16 no raw-row staging after the first chunk
-template <int KW, int DBG = 0>
+template <int KW, int DBG = 0, int BM = 64, int BNT = 128>
 __global__ void __launch_bounds__(WBF_NTH) __attribute__((amdgpu_waves_per_eu(2, 2)))
 winobf_conv_kernel(const WinoBfParams p) {
-    using GM = WbfGeom<KW>;
+    using GM = WbfGeom<KW, BM, BNT>;
     constexpr int NP = WBF_NP, R = WBF_R, G = GM::G, C0 = GM::C0, MLO = GM::MLO, MHI = GM::MHI;
-    constexpr int BM = WBF_BM, BNT = WBF_BNT, NW = WBF_NW, NTH = WBF_NTH, CIC = WBF_CIC, CP = WBF_CP;
+    constexpr int NW = WBF_NW, NTH = WBF_NTH, CIC = WBF_CIC, CP = WBF_CP, WM = GM::WM, WN = GM::WN, TQ = GM::TQ;
     constexpr int XT = GM::XT, XTS = GM::XTS, XBP = GM::XBP, NJ = GM::NJ, UPW = GM::UPW;
 
     extern __shared__ __attribute__((aligned(16))) float wbf_smem[];
@@ -151,7 +163,7 @@ winobf_conv_kernel(const WinoBfParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     __builtin_assume(wave >= 0 && wave < NW);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.z;
     const int n_m = p.c_out / BM;
@@ -247,16 +259,16 @@ winobf_conv_kernel(const WinoBfParams p) {
     // The work of a round is cut into stages (LDS reads / transform / two split levels / LDS writes) that the step body
     // places between the matrix instructions.
     static_assert(GM::XB <= GM::XBP, "");
-    int t_src[2], t_dst[2];
+    int t_src[TQ], t_dst[TQ];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int cp = (wave >> 1) + 4 * q, tau = 64 * (wave & 1) + lane;
+    for (int q = 0; q < TQ; ++q) {
+        const int cp = wave / TQ + (NW / TQ) * q, tau = 64 * (wave % TQ) + lane;
         t_src[q] = cp * 4 * XTS - MLO * d + tau;
         t_dst[q] = (cp >> 2) * (XBP * 16) + tau * 16 + (cp & 3) * 4;
     }
-    wbf_f32x2 tq[2][NP];           // the window samples a point needs (round q)
-    wbf_f32x2 tv[2];               // transformed pair, then the split residual
-    unsigned tw[2][3];             // the three bf16 pairs
+    wbf_f32x2 tq[TQ][NP];          // the window samples a point needs (round q)
+    wbf_f32x2 tv[TQ];              // transformed pair, then the split residual
+    unsigned tw[TQ][3];            // the three bf16 pairs
     auto t_read = [&](auto PT, int q, const wbf_f32x2 *raw) __attribute__((always_inline)) {
         constexpr int pt = decltype(PT)::value;
         const wbf_f32x2 *const src = raw + t_src[q];
@@ -302,7 +314,7 @@ winobf_conv_kernel(const WinoBfParams p) {
     auto transform_all = [&](auto PT, int slot) __attribute__((always_inline)) {   // prologue only
         unsigned char *const dstb = bs + slot * GM::B_SLOT;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < TQ; ++q) {
             t_read(PT, q, xs); t_xform(PT, q); t_split(q, 0); t_split(q, 1); t_split(q, 2); t_write(q, dstb);
         }
     };
@@ -321,7 +333,7 @@ winobf_conv_kernel(const WinoBfParams p) {
     wbf_bf16x8 fa[2][3], fb[3];
     auto f_read_a = [&](int g, const unsigned char *ab) __attribute__((always_inline)) {
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) fa[g & 1][sp] = __builtin_bit_cast(wbf_bf16x8, *reinterpret_cast<const wbf_u32x4 *>(ab + (g * 6 + sp) * 1024));
+        for (int sp = 0; sp < 3; ++sp) fa[g & 1][sp] = __builtin_bit_cast(wbf_bf16x8, *reinterpret_cast<const wbf_u32x4 *>(ab + (g * WM * 3 + sp) * 1024));
     };
     auto f_read_b = [&](int g, int sp, const unsigned char *bb) __attribute__((always_inline)) {
         fb[sp] = __builtin_bit_cast(wbf_bf16x8, *reinterpret_cast<const wbf_u32x4 *>(bb + sp * 2 * (XBP * 16) + g * d * 16));
@@ -358,12 +370,13 @@ winobf_conv_kernel(const WinoBfParams p) {
             constexpr bool LOADS = (pt == 0 || pt == 2) && !(DBG & 16), STORES = (pt == 1 || pt == 3) && !(DBG & 16);
             if (LOADS && more) load_x(c + 1, pt / 2);
             unsigned char *const dstb = bs + ((s + 1) & 1) * GM::B_SLOT;
-            const unsigned char *ab = as + (s % 3) * GM::A_SLOT + wm * 3 * 1024 + lane * 16;
+            const unsigned char *ab = as + (s % 3) * GM::A_SLOT + wm * 3 * 1024 + lane * 16;   // [g][32-channel block wm][split]
             const unsigned char *bb = bs + (s & 1) * GM::B_SLOT + b_lane;
             const wbf_f32x2 *const raw = xs + ((pt == NP - 1 ? c + 1 : c) & 1) * XRAW;    // the chunk of step s + 1
             constexpr bool T = !(DBG & 1), M = !(DBG & 2);
             // filler stage k goes after matrix instruction k of the step
             auto filler = [&](int k) __attribute__((always_inline)) {
+                constexpr bool T1 = T && TQ > 1;     // a second transform round (128-column blocks)
                 if constexpr (G == 3) {
                     switch (k) {
                         case 0: if (M) f_read_a(1, ab); break;
@@ -372,19 +385,20 @@ winobf_conv_kernel(const WinoBfParams p) {
                         case 3: if (T) t_split(0, 0); if (dma) dma_a1(s + 2, 0); break;
                         case 4: if (T) { t_split(0, 1); t_split(0, 2); } break;
                         case 5: if (M) { f_read_b(1, 0, bb); f_read_a(2, ab); } break;
-                        case 6: if (T) { t_write(0, dstb); t_read(PN{}, 1, raw); } break;
+                        case 6: if (T) t_write(0, dstb); if (T1) t_read(PN{}, TQ - 1, raw); break;
                         case 7: if (STORES && more) store_x1(c + 1, pt / 2, 0); if (dma) dma_a1(s + 2, 1); break;
                         case 8: if (M) { f_read_b(2, 2, bb); f_read_b(2, 1, bb); } break;
-                        case 9: if (T) t_xform(PN{}, 1); break;
-                        case 10: if (T) t_split(1, 0); break;
+                        case 9: if (T1) t_xform(PN{}, TQ - 1); if (dma && UPW > 3) dma_a1(s + 2, 3); break;
+                        case 10: if (T1) t_split(TQ - 1, 0); if (dma && UPW > 4) dma_a1(s + 2, 4); break;
                         case 11: if (M) f_read_b(2, 0, bb); break;
-                        case 12: if (T) { t_split(1, 1); t_split(1, 2); } break;
-                        case 13: if (T) t_write(1, dstb); if (dma) dma_a1(s + 2, 2); break;
+                        case 12: if (T1) { t_split(TQ - 1, 1); t_split(TQ - 1, 2); } break;
+                        case 13: if (T1) t_write(TQ - 1, dstb); if (dma) dma_a1(s + 2, 2); break;
                         case 14: if (STORES && more) store_x1(c + 1, pt / 2, 1); break;
                         case 15: if (STORES && more) store_x1(c + 1, pt / 2, 2); break;
                         case 16: if (STORES && more) store_x1(c + 1, pt / 2, 3); break;
                         default: break;
                     }
+                    static_assert(UPW <= 5, "");
                 } else {
                     switch (k) {
                         case 0: if (M) f_read_a(1, ab); break;
@@ -393,14 +407,15 @@ winobf_conv_kernel(const WinoBfParams p) {
                         case 3: if (T) t_split(0, 0); if (dma) dma_a1(s + 2, 0); break;
                         case 4: if (T) { t_split(0, 1); t_split(0, 2); } break;
                         case 5: if (M) f_read_b(1, 0, bb); if (dma) dma_a1(s + 2, 1); break;
-                        case 6: if (T) { t_write(0, dstb); t_read(PN{}, 1, raw); } break;
+                        case 6: if (T) t_write(0, dstb); if (T1) t_read(PN{}, TQ - 1, raw); break;
                         case 7: if (STORES && more) { store_x1(c + 1, pt / 2, 0); store_x1(c + 1, pt / 2, 1); } break;
-                        case 8: if (T) t_xform(PN{}, 1); break;
-                        case 9: if (T) t_split(1, 0); break;
-                        case 10: if (T) { t_split(1, 1); t_split(1, 2); } break;
-                        case 11: if (T) t_write(1, dstb); if (STORES && more) { store_x1(c + 1, pt / 2, 2); store_x1(c + 1, pt / 2, 3); } break;
+                        case 8: if (T1) t_xform(PN{}, TQ - 1); if (dma && UPW > 2) dma_a1(s + 2, 2); break;
+                        case 9: if (T1) t_split(TQ - 1, 0); break;
+                        case 10: if (T1) { t_split(TQ - 1, 1); t_split(TQ - 1, 2); } break;
+                        case 11: if (T1) t_write(TQ - 1, dstb); if (STORES && more) { store_x1(c + 1, pt / 2, 2); store_x1(c + 1, pt / 2, 3); } break;
                         default: break;
                     }
+                    static_assert(UPW <= 3, "");
                 }
             };
             if (M) { f_read_a(0, ab); f_read_b(0, 2, bb); f_read_b(0, 1, bb); f_read_b(0, 0, bb); }
@@ -545,27 +560,37 @@ winobf_conv_kernel(const WinoBfParams p) {
     }
 }
 
-template <int KW, int DBG = 0>
+template <int KW, int DBG = 0, int BM = 64, int BNT = 128>
 static int winobf_launch(WinoBfParams p, hipStream_t stream) {
-    using GM = WbfGeom<KW>;
-    p.sb_per_block = (WBF_BNT - (GM::G - 1) * p.dil) / p.dil;   // valid tiles + the (G - 1) d windows behind them = 128 transformed windows
+    using GM = WbfGeom<KW, BM, BNT>;
+    p.sb_per_block = (BNT - (GM::G - 1) * p.dil) / p.dil;   // valid tiles + the (G - 1) d windows behind them = BNT transformed windows
     p.n_sb = ceil_div(p.L, (int64_t)4 * p.dil);
     static std::once_flag once;
     static hipError_t err = hipSuccess;
     std::call_once(once, [] {
-        err = hipFuncSetAttribute((const void *)winobf_conv_kernel<KW, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, GM::LDS_BYTES);
+        err = hipFuncSetAttribute((const void *)winobf_conv_kernel<KW, DBG, BM, BNT>, hipFuncAttributeMaxDynamicSharedMemorySize, GM::LDS_BYTES);
     });
     if (err != hipSuccess) return fail("winobf conv: cannot reserve %d bytes of LDS: %s", GM::LDS_BYTES, hipGetErrorString(err));
     p.n_tile_blocks = (int)ceil_div(p.n_sb, p.sb_per_block);
-    const int n_m = p.c_out / WBF_BM;
+    const int n_m = p.c_out / BM;
     dim3 grid((unsigned)(ceil_div(p.n_tile_blocks, 8) * 8 * n_m), 1, (unsigned)p.batch);
-    hipLaunchKernelGGL((winobf_conv_kernel<KW, DBG>), grid, dim3(WBF_NTH), GM::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((winobf_conv_kernel<KW, DBG, BM, BNT>), grid, dim3(WBF_NTH), GM::LDS_BYTES, stream, p);
     RVC_LAUNCH_CHECK();
     return 0;
 }
 
+// the block shape a layer runs with (the tap fragments are packed for it).  128 channels x 64 columns halves the window
+// transforms and raw-row staging per product but loses (G - 1) d of 64 columns instead of 128 to the tap-group overlap:
+// measured (profiles/r03_convbf_shapes.txt) it wins 12-17 % on the 7-tap layers and 7 % on 256-channel 11-tap ones, and is
+// level (+5 .. -3 %) on 128-channel 11-tap ones, which keep 64 x 128.  RVC_WBF_BM128=0 forces 64 x 128 everywhere.
+int winobf_block_rows(int c_out, int k) {
+    static const int wide = getenv("RVC_WBF_BM128") ? atoi(getenv("RVC_WBF_BM128")) : 1;
+    if (!wide || c_out % 128) return 64;
+    return (k == 7 || c_out >= 256 || wide == 2) ? 128 : 64;
+}
+
 bool winobf_supported(int c_in, int c_out, int k, int dil) {
-    return (k == 7 || k == 11) && dil >= 1 && dil <= WBF_MAX_DIL && c_in % WBF_CIC == 0 && c_out % WBF_BM == 0;
+    return (k == 7 || k == 11) && dil >= 1 && dil <= WBF_MAX_DIL && c_in % WBF_CIC == 0 && c_out % 64 == 0;
 }
 
 bool winobf_fits(int c_in, int c_out, int64_t L) {
@@ -583,7 +608,7 @@ int launch_winobf_conv(const float *x, const void *u, const float *bias, const f
     WinoBfParams p;
     p.x = x; p.u = u; p.bias = bias; p.res = res; p.accin = accin; p.y = y;
     p.c_in = c_in; p.c_out = c_out; p.L = L; p.dil = dil; p.slope = slope; p.out_scale = out_scale; p.batch = batch;
-    if (k == 11) {   // ablations (wrong results): where does the time go
+    if (k == 11 && winobf_block_rows(c_out, k) == 64) {   // ablations (wrong results): where does the time go
         static const int dbg = getenv("RVC_WBF_DBG") ? atoi(getenv("RVC_WBF_DBG")) : 0;
         switch (dbg) {
             case 1: return winobf_launch<11, 1>(p, stream);
@@ -602,15 +627,18 @@ int launch_winobf_conv(const float *x, const void *u, const float *bias, const f
             default: break;
         }
     }
+    if (winobf_block_rows(c_out, k) == 128) return k == 7 ? winobf_launch<7, 0, 128, 64>(p, stream) : winobf_launch<11, 0, 128, 64>(p, stream);
     return k == 7 ? winobf_launch<7>(p, stream) : winobf_launch<11>(p, stream);
 }
 
-// w_host [c_out][c_in][k] -> [c_out / 64][c_in / 16][point 7][group G][32-channel half 2][split 3][lane 64][8] bf16:
+// w_host [c_out][c_in][k] -> [c_out / BM][c_in / 16][point 7][group G][32-channel block BM / 32][split 3][lane 64][8] bf16
+// (BM = winobf_block_rows(c_out, k)):
 // the tap transform (Vandermonde rows of the points 0, 1, -1, 1/2, -1/2, 2, inf without their 1 / N_j, which the epilogue
 // applies) in float64, rounded to fp32, split exactly into three bf16, in the lane order of a 32x32x16 A fragment
 // (lane l: channel l & 31, input channels 8 (l >> 5) .. + 7).
 void winobf_pack_host(const float *w_host, int c_out, int c_in, int k, std::vector<uint16_t> *out) {
-    const int G = (k + 3) / 4, n_chunks = c_in / WBF_CIC, n_m = c_out / WBF_BM;
+    const int BM = winobf_block_rows(c_out, k), WM = BM / 32;
+    const int G = (k + 3) / 4, n_chunks = c_in / WBF_CIC, n_m = c_out / BM;
     out->assign((size_t)c_out * c_in * WBF_NP * G * 3, 0);
     auto split3 = [](float v, uint16_t s[3]) {
         float r = v;
@@ -626,10 +654,10 @@ void winobf_pack_host(const float *w_host, int c_out, int c_in, int k, std::vect
         for (int c = 0; c < n_chunks; ++c)
             for (int pt = 0; pt < WBF_NP; ++pt)
                 for (int g = 0; g < G; ++g)
-                    for (int mi = 0; mi < 2; ++mi)
+                    for (int mi = 0; mi < WM; ++mi)
                         for (int lane = 0; lane < 64; ++lane)
                             for (int e = 0; e < 8; ++e) {
-                                const int co = mb * WBF_BM + mi * 32 + (lane & 31);
+                                const int co = mb * BM + mi * 32 + (lane & 31);
                                 const int ci = c * WBF_CIC + 8 * (lane >> 5) + e;
                                 double w[4];
                                 for (int kk = 0; kk < 4; ++kk) {
@@ -650,14 +678,14 @@ void winobf_pack_host(const float *w_host, int c_out, int c_in, int k, std::vect
                                 split3((float)u, s);
                                 const size_t step = ((size_t)mb * n_chunks + c) * WBF_NP + pt;
                                 for (int sp = 0; sp < 3; ++sp) {
-                                    const size_t piece = (step * G + g) * 6 + mi * 3 + sp;
+                                    const size_t piece = ((step * G + g) * WM + mi) * 3 + sp;
                                     (*out)[piece * 512 + lane * 8 + e] = s[sp];
                                 }
                             }
 }
 
 int winobf_pack_weight(const float *w_host, int c_out, int c_in, int k, void **out_dev) {
-    if (c_in % WBF_CIC || c_out % WBF_BM || !(k == 7 || k == 11)) return fail("winobf_pack_weight: unsupported shape");
+    if (c_in % WBF_CIC || c_out % 64 || !(k == 7 || k == 11)) return fail("winobf_pack_weight: unsupported shape");
     std::vector<uint16_t> u;
     winobf_pack_host(w_host, c_out, c_in, k, &u);
     hipError_t e = hipMalloc(out_dev, u.size() * sizeof(uint16_t));
@@ -671,7 +699,7 @@ int winobf_pack_weight(const float *w_host, int c_out, int c_in, int k, void **o
 using namespace rvc;
 
 extern "C" int rvc_conv1d_winobf_weight_bytes(int c_out, int c_in, int k, size_t *bytes) {
-    if (!bytes || c_in <= 0 || c_out <= 0 || c_in % WBF_CIC || c_out % WBF_BM || !(k == 7 || k == 11))
+    if (!bytes || c_in <= 0 || c_out <= 0 || c_in % WBF_CIC || c_out % 64 || !(k == 7 || k == 11))
         return fail("rvc_conv1d_winobf_weight_bytes: c_in must be a multiple of 16, c_out of 64, k 7 or 11");
     *bytes = winobf_weight_bytes(c_out, c_in, k);
     return 0;
