@@ -32,6 +32,7 @@
 // [64 h, 64 h + 64) of its row per chunk (h = lane / 32) as four MFMA operands -- a dot product may walk k in any order
 // as long as both operands agree.  The 7 query tiles of one row stripe are placed on ONE XCD so the stripe crosses the
 // fabric once and is re-read from that XCD's L2.
+#include <limits.h>
 #include <stdlib.h>
 
 #include <mutex>
@@ -140,7 +141,54 @@ struct ScreenParams {
     int n_slots;
 };
 
-template <bool APPEND, int WM, int BK>
+// ---- selection epilogue of one finished tile: this lane's 64 rows x 2 queries --------------------------------------------
+// APPEND: a row goes to its query's candidate list iff s~ = ||x||^2 - 2 q~.x~ is not provably above the threshold ("not >=":
+// a NaN score -- inf in the fp16 data -- must be kept, too).  Survivors are a few dozen per query out of the whole index, so
+// the test is branch-free over groups of 4 rows x 2 queries (fma + compare + or per element) with ONE wave-uniform branch
+// per group into the append code.  MIN: running minimum per query.  Zeroes the accumulators for the next tile.
+template <bool APPEND>
+__device__ __forceinline__ void screen_select(f32x16 (&acc)[4][2], const float *xn_t, int row_base, int row_limit, const float (&thr)[2],
+                                              float (&mn)[2], int64_t q_lane, int64_t n_queries, int64_t n_rows, int *cand_cnt,
+                                              int *cand_id, int cap) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            float v[4][2];
+            bool hit = false;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int ro = m * 32 + r4 + 8 * rg;
+                const float xnv = row_base + ro < row_limit ? xn_t[ro] : INFINITY;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    v[r4][n] = fmaf(-2.f, acc[m][n][4 * rg + r4], xnv);
+                    if (APPEND) hit |= !(v[r4][n] >= thr[n]);
+                    else mn[n] = fminf(mn[n], v[r4][n]);
+                    acc[m][n][4 * rg + r4] = 0.f;
+                }
+            }
+            if (APPEND && __any(hit)) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        if (!(v[r4][n] >= thr[n])) {
+                            const int64_t q = q_lane + 32 * n;
+                            const int row = row_base + m * 32 + r4 + 8 * rg;
+                            if (q < n_queries && row < n_rows) {
+                                const int pos = atomicAdd(&cand_cnt[q], 1);
+                                if (pos < cap) cand_id[q * cap + pos] = row;
+                            }
+                        }
+            }
+        }
+}
+
+// DBG (ablations, wrong results; RVC_KNN_DBG, tools/ablate_knn.py, tools/clock_knn.sh): 2 no staging after the prologue,
+// 4 no barrier, 8 no matrix instructions, 16 fragments read from LDS in the first chunk only, 32 threshold -inf (nothing is
+// appended, so that 2 / 16 do not flood the candidate lists; always set together with the others)
+template <bool APPEND, int WM, int BK, int DBG = 0>
 __global__ void __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(2, 2)))
 knn_screen_kernel(const ScreenParams p) {
     using TL = ScreenTile<WM, BK>;
@@ -216,7 +264,7 @@ knn_screen_kernel(const ScreenParams p) {
         const int64_t q = q0 + 64 * wn + 32 * n + l31;
         mn[n] = INFINITY;
         thr[n] = -INFINITY;
-        if (APPEND && q < n_queries) thr[n] = p.thr[q];
+        if (APPEND && q < n_queries && !(DBG & 32)) thr[n] = p.thr[q];
     }
 
     f32x16 acc[4][2];
@@ -227,6 +275,7 @@ knn_screen_kernel(const ScreenParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
+    f16x8 a[2][4], bq[2][2];
     load_chunk(0);
     store_chunk(0, 0);
     if (n_chunks > 1) load_chunk(1);
@@ -236,59 +285,37 @@ knn_screen_kernel(const ScreenParams p) {
         // lane (row i, half h) owns bytes [BK h, BK h + BK) of its row's chunk: KSTEPS operands of 8 halves
         const unsigned char *ab = As + ((size_t)buf * BM + 128 * wm + l31) * ROWB + BK * h;
         const unsigned char *bb = Bs + ((size_t)buf * KS_BN + 64 * wn + l31) * ROWB + BK * h;
-        f16x8 a[2][4], bq[2][2];
         auto frag = [&](int t, f16x8 (&av)[4], f16x8 (&bv)[2]) __attribute__((always_inline)) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f16x8 *>(ab + (size_t)m * 32 * ROWB + 16 * t);
 #pragma unroll
             for (int n = 0; n < 2; ++n) bv[n] = *reinterpret_cast<const f16x8 *>(bb + (size_t)n * 32 * ROWB + 16 * t);
         };
-        frag(0, a[0], bq[0]);
+        if (!((DBG & 16) && c > 0)) frag(0, a[0], bq[0]);
 #pragma unroll
         for (int t = 0; t < TL::KSTEPS; ++t) {
-            if (t + 1 < TL::KSTEPS) frag(t + 1, a[(t + 1) & 1], bq[(t + 1) & 1]);
+            if (t + 1 < TL::KSTEPS && !((DBG & 16) && c > 0)) frag(t + 1, a[(t + 1) & 1], bq[(t + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t & 1][m], bq[t & 1][n], acc[m][n], 0, 0, 0);
+                    if (!(DBG & 8)) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t & 1][m], bq[t & 1][n], acc[m][n], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         const int t_cur = c / n_kc;
         if (c - t_cur * n_kc == n_kc - 1) {
-            // the tile is complete: s~ = ||x||^2 - 2 q~.x~ for this lane's 64 rows x 2 queries
+            // the tile is complete: s~ = ||x||^2 - 2 q~.x~ for this lane's 64 rows x 2 queries (rows past the end: +inf in xn_s)
             const float *xn_t = xn_s + (t_cur & 1) * BM + 128 * wm + 4 * h;
             const int row_base = (int)(tile_row0(t_cur)) + 128 * wm + 4 * h;
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ro = m * 32 + (r & 3) + 8 * (r >> 2);
-                    const float xnv = xn_t[ro];
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        const float v = fmaf(-2.f, acc[m][n][r], xnv);
-                        if (APPEND) {
-                            // "not provably above the threshold": a NaN score (inf in the fp16 data) must be kept, too
-                            if (!(v >= thr[n])) {
-                                const int64_t q = q0 + 64 * wn + 32 * n + l31;
-                                if (q < n_queries && row_base + ro < n_rows) {
-                                    const int pos = atomicAdd(&p.cand_cnt[q], 1);
-                                    if (pos < p.cap) p.cand_id[q * p.cap + pos] = row_base + ro;
-                                }
-                            }
-                        } else {
-                            mn[n] = fminf(mn[n], v);
-                        }
-                        acc[m][n][r] = 0.f;
-                    }
-                }
+            screen_select<APPEND>(acc, xn_t, row_base, INT_MAX, thr, mn, q0 + 64 * wn + l31, n_queries, n_rows, p.cand_cnt, p.cand_id, p.cap);
         }
         if (c + 1 < n_chunks) {
-            store_chunk(buf ^ 1, c + 1);
-            if (c + 2 < n_chunks) load_chunk(c + 2);
-            __syncthreads();
+            if (!(DBG & 2)) {
+                store_chunk(buf ^ 1, c + 1);
+                if (c + 2 < n_chunks) load_chunk(c + 2);
+            }
+            if (!(DBG & 4)) __syncthreads();
         }
     }
     if (!APPEND) {
@@ -427,29 +454,8 @@ knn_screen_glds_kernel(const ScreenParams p) {
         if (c - t_cur * n_kc == n_kc - 1) {
             const float *xn_t = xn_s + (t_cur & 1) * BM + 128 * wm + 4 * h;
             const int row_base = (int)(tile_row0(t_cur)) + 128 * wm + 4 * h;
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ro = m * 32 + (r & 3) + 8 * (r >> 2);
-                    const float xnv = row_base + ro < n_rows ? xn_t[ro] : INFINITY;
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        const float v = fmaf(-2.f, acc[m][n][r], xnv);
-                        if (APPEND) {
-                            if (!(v >= thr[n])) {
-                                const int64_t q = q0 + 64 * wn + 32 * n + l31;
-                                if (q < n_queries && row_base + ro < n_rows) {
-                                    const int pos = atomicAdd(&p.cand_cnt[q], 1);
-                                    if (pos < p.cap) p.cand_id[q * p.cap + pos] = row_base + ro;
-                                }
-                            }
-                        } else {
-                            mn[n] = fminf(mn[n], v);
-                        }
-                        acc[m][n][r] = 0.f;
-                    }
-                }
+            // rows past the end of the index were fetched clamped: their ||x||^2 is replaced by +inf
+            screen_select<APPEND>(acc, xn_t, row_base, (int)n_rows, thr, mn, q0 + 64 * wn + l31, n_queries, n_rows, p.cand_cnt, p.cand_id, p.cap);
         }
         if (c + 1 < n_chunks) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of chunk c + 1 have landed
@@ -804,7 +810,20 @@ int knn_screened_search(const float *index, const void *aux_dev, int64_t n_rows,
         if (s.wm == 2 && s.bk == 64 && glds_env) {
             if (append) hipLaunchKernelGGL(knn_screen_glds_kernel<true>, dim3(nblocks), dim3(512), (ScreenTile<2, 64>::LDS_BYTES), stream, p);
             else hipLaunchKernelGGL(knn_screen_glds_kernel<false>, dim3(nblocks), dim3(512), (ScreenTile<2, 64>::LDS_BYTES), stream, p);
-        } else if (s.wm == 2 && s.bk == 64) { if (append) RVC_SCREEN(true, 2, 64); else RVC_SCREEN(false, 2, 64); }
+        } else if (s.wm == 2 && s.bk == 64) {
+            static const int dbg = env_i("RVC_KNN_DBG", 0);
+            if (append && dbg) {
+#define RVC_SCREEN_DBG(D) hipLaunchKernelGGL((knn_screen_kernel<true, 2, 64, D>), dim3(nblocks), dim3(512), (ScreenTile<2, 64>::LDS_BYTES), stream, p)
+                auto res = [](const void *fn) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ScreenTile<2, 64>::LDS_BYTES); };
+                switch (dbg) {
+#define RVC_SD(D) case D: res((const void *)knn_screen_kernel<true, 2, 64, D>); RVC_SCREEN_DBG(D); break
+                    RVC_SD(32); RVC_SD(34); RVC_SD(48); RVC_SD(50); RVC_SD(54); RVC_SD(36); RVC_SD(40);
+#undef RVC_SD
+                    default: RVC_SCREEN(true, 2, 64); break;
+                }
+#undef RVC_SCREEN_DBG
+            } else if (append) RVC_SCREEN(true, 2, 64); else RVC_SCREEN(false, 2, 64);
+        }
         else { if (append) RVC_SCREEN(true, 1, 32); else RVC_SCREEN(false, 1, 32); }
 #undef RVC_SCREEN
     };
