@@ -46,12 +46,12 @@ for p in (ROOT, os.path.join(ROOT, "codename-rvc-fork-3_amd")):
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = FP32 vector peak
 PEAK_F16_MFMA_TFLOPS = 2500.0   # dense fp16/bf16 MFMA
 PEAK_HBM_GBS = 8000.0           # HBM3E spec
-PMC_BF_BYTES = 465.3e6          # profiles/r03_pmc_winobf.txt
+PMC_BF_BYTES = 467.2e6          # profiles/r03_pmc_winobf.txt
 # average HBM bytes per launch of the roofline kernel symbol at the cfg-2 shape, from the PMC passes committed under
 # profiles/ (cannot be collected inside bench.py: it needs rocprofv3)
 PMC_TRAFFIC = {
     "bf16x3": (PMC_BF_BYTES, "profiles/r03_pmc_winobf.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
-               "tools/pmc_conv.py (this same 18-launch mix of winobf_conv_kernel<11,0>, tools/pmc_wino.sh), average per launch; "
+               "tools/pmc_conv.py (this same 18-launch mix of winobf_conv_kernel<11,0,*,*>, tools/pmc_wino.sh), average per launch; "
                "FETCH_SIZE calibrated per access width on launches with known byte counts"),
     "fp32": (446.9e6, "profiles/r02_pmc_wino.txt (round 2, wino_conv_kernel<11,2,2,8,0,false>: same bytes by construction as <...,false,4>)"),
 }
@@ -112,8 +112,9 @@ def roofline_mix(torch, native, dev, T, rates, k=11):
     """Every launch of the dominant kernel symbol in one utterance's vocoder forward: the 11-tap ResBlock of stages 0-2
     (C = 256, 128, 64; the C = 32 stage takes the fp32 1 x 4-wave symbol), per stage and for each dilation d: conv1
     (dilation d) then conv2 (dilation 1, + residual; the last one also + running sum, x 1/3) -- 18 launches, the same
-    population rocprofv3 --stats averages over for that symbol.  The symbol is winobf_conv_kernel<11,0> (Winograd F(4,4) on
-    the bf16 matrix cores, fp32 operands split exactly into three bf16) unless RVC_WINOBF=0 / RVC_WINO=0 selects the round-2
+    population rocprofv3 --stats averages over for that kernel.  The kernel is winobf_conv_kernel<11,0,BM,BNT> (Winograd F(4,4)
+    on the bf16 matrix cores, fp32 operands split exactly into three bf16; two block shapes = two symbols in a trace:
+    <11,0,128,64> for the six C = 256 launches, <11,0,64,128> for the twelve C = 128 / 64 ones) unless RVC_WINOBF=0 / RVC_WINO=0 selects the round-2
     form wino_conv_kernel<11,2,2,8,0,false,4> (fp32 matrix instruction).
     Returns (callable, algorithmic flops per call, launches per call, algorithmic HBM bytes per call, executed flops, form)."""
     gen = torch.Generator().manual_seed(1)
@@ -435,7 +436,8 @@ def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev, utterance):
                         "contains the time it shares the chip"}
     if form == "bf16x3":
         res["roofline"] = {
-            "kernel": "rvc::winobf_conv_kernel<11,0>: ALL 18 launches per utterance of this symbol -- " + shapes,
+            "kernel": "rvc::winobf_conv_kernel<11,0,BM,BNT>: ALL 18 launches per utterance of this kernel (block shape 128 x 64 for the 6 "
+                      "C=256 launches, 64 x 128 for the 12 C=128/64 ones: two symbols in a trace) -- " + shapes,
             "bound": "mfma", "achieved": round(exe_launch / t_launch / 1e12, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(exe_launch / t_launch / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
             "achieved_is": "bf16 matrix flops the kernel EXECUTES / launch time, against the dense bf16 MFMA peak: the pipe's own "
