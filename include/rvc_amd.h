@@ -56,7 +56,10 @@ const char *rvc_last_error(void);
 int rvc_knn_index_aux_bytes(int64_t n_rows, int dim, size_t *bytes);
 int rvc_knn_index_build(const float *index_dev, int64_t n_rows, int dim, void *aux_dev, size_t aux_bytes, void *stream);
 
-/* bytes of scratch rvc_knn_search needs for (n_rows, n_queries, dim) */
+/* bytes of scratch rvc_knn_search needs for (n_rows, n_queries, dim).  In the fp16-screened regime (> 64 queries, >= 16384 rows)
+ * this is ~42 KB per query (8192 candidate ids + up to 2048 sample minima + the fp16 copy of the query): 67 MB at the 1599
+ * queries of a 30 s clip.  The scratch is per concurrent search -- a caller with several streams in flight holds one per
+ * stream -- and grows linearly with n_queries: split very long query sets rather than sizing for them. */
 int rvc_knn_workspace_bytes(int64_t n_rows, int64_t n_queries, int dim, int k, size_t *bytes);
 
 /* out_d2_dev [n_queries,k] squared distances ascending; out_ids_dev [n_queries,k] int64 row ids (-1 where the index has
