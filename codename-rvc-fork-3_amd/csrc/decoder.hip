@@ -400,6 +400,14 @@ int build_conv(const rvc_decoder *d, const std::string &prefix, int c_out, int c
             }
         }
     }
+    // 7- / 11-tap layers that change the channel count (conv_pre, RefineGAN's mel_conv / input_conv): the bf16-matrix-core
+    // Winograd form takes any (c_in % 16, c_out % 64) pair; the fp32 Winograd kernel is square-only, so these only carry
+    // the direct-form slab and the bf16x3 fragments
+    if (c_in != c_out && !as_bf16 && k >= 7 && winobf_enabled() && winobf_supported(c_in, c_out, k, 1)) {
+        std::vector<uint16_t> frags;
+        winobf_pack_host(w->data.data(), c_out, c_in, k, &frags);
+        if (out->wx.upload(frags)) return 1;
+    }
     if (bias) {
         if (need(d, prefix + ".bias", &b, {c_out})) return 1;
         if (out->b.upload(b->data)) return 1;

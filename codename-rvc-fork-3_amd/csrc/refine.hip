@@ -397,7 +397,7 @@ int refine_forward(rvc_decoder *d, const float *z_dev, const float *f0_dev, cons
         {
             ConvParams p;
             p.x1 = cat; p.c1 = ctot; p.slope1 = 1.f; p.x1_bstride = cat_bs; p.l_in = lo;
-            p.w = s.input_conv.w.p; p.bias = s.input_conv.b.p;
+            p.w = s.input_conv.w.p; p.bias = s.input_conv.b.p; p.w_winobf = s.input_conv.wx.p;   // bf16x3 Winograd where c_out % 64 == 0
             p.y = XIN; p.y_bstride = bs; p.m_total = s.ch_out; p.c_out = s.ch_out; p.n_cols = lo; p.l_out = lo;
             p.kw = 7; p.dil = 1; p.padl = 3; p.batch = batch;
             if (launch_conv(p, stream)) return 1;
