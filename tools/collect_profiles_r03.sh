@@ -13,6 +13,7 @@ cp /tmp/pb1/b_kernel_stats.csv $O/bench_kernel_stats_inflight1.csv
 rocprofv3 --kernel-trace --output-format csv -d /tmp/pp -o t -- python3 $R/tools/profile_pipeline.py > $O/profile_pipeline.log 2>&1
 python3 $R/tools/summarize_trace.py /tmp/pp/t_kernel_trace.csv 0 all lastgap > $O/pipeline_kernels.txt
 rocprofv3 --kernel-trace --output-format csv -d /tmp/d1 -o t -- python3 $R/tools/profile_decoder.py >/dev/null 2>&1; python3 $R/tools/summarize_trace.py /tmp/d1/t_kernel_trace.csv > $O/decoder_kernels_nsf.txt
+rocprofv3 --kernel-trace --output-format csv -d /tmp/d2 -o t -- python3 $R/tools/profile_decoder.py RefineGAN >/dev/null 2>&1; python3 $R/tools/summarize_trace.py /tmp/d2/t_kernel_trace.csv > $O/decoder_kernels_refinegan.txt
 python3 $R/tools/bench_convbf.py > $O/convbf_shapes.txt 2>&1
 (cd $R && bash tools/ablate_winobf.sh) > $O/winobf_ablation.txt 2>&1
 for c in 2 1 4 5; do python3 - <<PY
