@@ -92,11 +92,4 @@ int launch_winobf_conv(const float *x, const void *u, const float *bias, const f
 // regular conv weight [c_out][c_in][k] -> [k][c_in][c_out]
 int pack_conv_weight(const float *w_host, int c_out, int c_in, int k, float **out_dev);
 
-// gemmbf.hip: the vocoders' polyphase ConvTranspose1d (rows (phase, channel), two input sources) on the bf16x3 GEMM kernel
-bool gemmbf_upsample_supported(int c_in, int c2, int m_total);
-void gemmbf_pack_upsample(const float *w_tkm, int taps, int ctot, int m_total, std::vector<uint16_t> *out);
-int launch_gemmbf_upsample(const float *x, int c_in, int64_t l_in, float slope, const float *x2, int c2, int64_t l_in2, const void *a,
-                           const float *bias, float *y, int c_out, int rate, int up_pad, int taps, int64_t n_cols, int64_t l_out, int batch,
-                           hipStream_t stream);
-
 }  // namespace rvc

@@ -52,10 +52,9 @@ struct Stage {
     int c_in = 0, c_out = 0, rate = 0, ksize = 0, pad = 0, opad = 0;
     int taps = 0;                 // polyphase taps J = ceil(k / rate)
     int nc_stride = 0, nc_k = 0, nc_pad = 0;
-    int vk = 0, vk_rows = 0;      // folded noise-conv rows: valid, padded to a multiple of 16
+    int vk = 0, vk_rows = 0;      // folded noise-conv rows: valid, padded to a multiple of 8
     int64_t S = 0, P = 0;         // V[k][q] = har[q*S + k - P]
     DevBuf w, b;                  // [taps][c_in + vk_rows][rate * c_out], [c_out]
-    DevBuf16 wg;                  // the same matrix as bf16x3 A fragments (gemmbf.hip) where rate * c_out % 128 == 0, else empty
     // nc_rows > 0: the noise conv is NOT folded into the upsampler's GEMM (w has c_in rows per tap) but added by its own
     // launch, y += W_nc V2 with V2[k][t] = har[t * nc_stride + k - nc_pad].  Folding it costs (rate - 1) * nc_stride + nc_k
     // GEMM rows per tap for nc_k useful ones: 520 against 512 real input channels in the first stage of the 48 k vocoder

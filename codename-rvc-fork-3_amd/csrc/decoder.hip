@@ -498,7 +498,7 @@ extern "C" int rvc_decoder_finalize(rvc_decoder *d) {
         s.nc_k = stride_f0 == 1 ? 1 : stride_f0 * 2 - stride_f0 % 2;
         s.nc_pad = stride_f0 == 1 ? 0 : (s.nc_k - stride_f0) / 2;
         s.vk = (s.rate - 1) * s.nc_stride + s.nc_k;
-        s.vk_rows = (s.vk + 15) / 16 * 16;
+        s.vk_rows = (s.vk + 7) / 8 * 8;
         s.S = (int64_t)s.rate * s.nc_stride;
         s.P = (int64_t)s.pad * s.nc_stride + s.nc_pad;
         static const int nc_sep_env = getenv("RVC_NC_SEPARATE") ? atoi(getenv("RVC_NC_SEPARATE")) : 1;
@@ -541,14 +541,6 @@ extern "C" int rvc_decoder_finalize(rvc_decoder *d) {
                     packed[((size_t)tp0 * ctot + s.c_in + kq) * m_total + ph * s.c_out + co] = nw->data[(size_t)co * s.nc_k + k];
             }
         if (s.w.upload(packed)) return 1;
-        // the upsampler as a bf16x3 GEMM (exact fp32 operands on the bf16 matrix cores, gemmbf.hip) where its row count allows.
-        // RVC_UPS_BF=0: off
-        static const int ups_bf = getenv("RVC_UPS_BF") ? atoi(getenv("RVC_UPS_BF")) : 1;
-        if (ups_bf && gemmbf_upsample_supported(s.c_in, s.vk_rows, m_total)) {
-            std::vector<uint16_t> frags;
-            gemmbf_pack_upsample(packed.data(), s.taps, ctot, m_total, &frags);
-            if (s.wg.upload(frags)) return 1;
-        }
         if (s.nc_rows) {
             std::vector<float> ncw((size_t)s.nc_rows * s.c_out, 0.f);
             for (int k = 0; k < s.nc_k; ++k)
@@ -739,11 +731,7 @@ extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const flo
             RVC_LAUNCH_CHECK();
         }
         float *X = buf[1], *Y = buf[2], *T1 = buf[3];
-        if (s.wg.p) {
-            if (launch_gemmbf_upsample(cur, s.c_in, len, 0.1f, V, s.vk_rows, nq, s.wg.p, s.b.p, X, s.c_out, s.rate, s.pad, s.taps, nq, len_out,
-                                       batch, stream))
-                return 1;
-        } else {
+        {
             ConvParams p;
             p.x1 = cur; p.c1 = s.c_in; p.slope1 = 0.1f; p.x1_bstride = (int64_t)s.c_in * len;
             if (s.vk_rows) { p.x2 = V; p.c2 = s.vk_rows; p.slope2 = 1.f; p.x2_bstride = (int64_t)s.vk_rows * nq; }

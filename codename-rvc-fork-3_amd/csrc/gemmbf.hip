@@ -34,17 +34,9 @@ struct GemmBfParams {
     int c_in = 0;                    // conv: channels per tap (K for a plain GEMM)
     int64_t N = 0;                   // columns
     int x_mode = 0;                  // 0: x[n][k] row-major (ldx floats per row); 1: x[ci][t] channel-major, t = n * stride + tap * dil - pad
-                                     // 2: as 1 with TWO channel-major sources per tap: rows [0, c_in) from x (leaky slope in_slope
-                                     //    applied), rows [c_in, c_in + c2) from x2 (row length ldx2, valid columns [0, l_in2))
     int64_t ldx = 0, l_in = 0;
     int stride = 1, dil = 1, pad = 0;
-    const float *x2 = nullptr;
-    int c2 = 0;
-    int64_t ldx2 = 0, l_in2 = 0, x2_bstride = 0;
-    float in_slope = 1.f;
-    int y_mode = 0;                  // 0: y[n][m] row-major (ldy); 1: y[m][n] channel-major (ldy);
-                                     // 2: polyphase scatter: row m = (phase, channel) of up_cout channels, y[channel][n * up_rate + phase - up_pad]
-    int up_rate = 0, up_pad = 0, up_cout = 0;
+    int y_mode = 0;                  // 0: y[n][m] row-major (ldy); 1: y[m][n] channel-major (ldy)
     int64_t ldy = 0;
     int act = 0;                     // 0 none, 1 GELU (erf form)
     int batch = 1;
@@ -106,41 +98,26 @@ gemmbf_kernel(const GemmBfParams p) {
     const bool col_ok = n_col < p.N;
     float xv[8];
     bool lx_ok_prev = true;   // conv mode: was the column of the values now in xv inside the input?
-    bool lx_act = false, lx_act_prev = false;   // two-source mode: do the values now in xv take the input activation?
     // (pieces, so that the step body can place them between matrix instructions)
     const float *lx_src = nullptr;
     bool lx_ok = true;
     auto load_x_begin = [&](int s) __attribute__((always_inline)) {
         if constexpr (XMODE == 0) {
             lx_src = x + (col_ok ? n_col : 0) * p.ldx + 16 * s + 8 * kh;
-        } else if constexpr (XMODE == 1) {
+        } else {
             const int k0 = 16 * s;
             const int tap = k0 / p.c_in, ci0 = k0 - tap * p.c_in + 8 * kh;
             const int64_t t_in = n_col * p.stride + (int64_t)tap * p.dil - p.pad;
             lx_ok = col_ok && t_in >= 0 && t_in < p.l_in;
             lx_src = x + (int64_t)ci0 * p.ldx + (lx_ok ? t_in : 0);
-        } else {
-            const int k0 = 16 * s, ctot = p.c_in + p.c2;
-            const int tap = k0 / ctot, r0 = k0 - tap * ctot + 8 * kh;       // c_in and c2 are multiples of 16: no straddling
-            const int64_t t_in = n_col * p.stride + (int64_t)tap * p.dil - p.pad;
-            lx_act = r0 < p.c_in;
-            if (lx_act) {
-                lx_ok = col_ok && t_in >= 0 && t_in < p.l_in;
-                lx_src = x + (int64_t)r0 * p.ldx + (lx_ok ? t_in : 0);
-            } else {
-                lx_ok = col_ok && t_in >= 0 && t_in < p.l_in2;
-                lx_src = p.x2 + (int64_t)bz * p.x2_bstride + (int64_t)(r0 - p.c_in) * p.ldx2 + (lx_ok ? t_in : 0);
-            }
         }
     };
     auto load_x_piece = [&](int e) __attribute__((always_inline)) {   // XMODE 0: e = 0, 1 (a float4 each); XMODE 1: e = 0..7
         if constexpr (XMODE == 0) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(lx_src + 4 * e);
             xv[4 * e] = v.x; xv[4 * e + 1] = v.y; xv[4 * e + 2] = v.z; xv[4 * e + 3] = v.w;
-        } else if constexpr (XMODE == 1) {
-            xv[e] = lx_src[(int64_t)e * p.ldx];
         } else {
-            xv[e] = lx_src[(int64_t)e * (lx_act ? p.ldx : p.ldx2)];
+            xv[e] = lx_src[(int64_t)e * p.ldx];
         }
     };
     constexpr int LX_PIECES = XMODE == 0 ? 2 : 8;
@@ -154,10 +131,6 @@ gemmbf_kernel(const GemmBfParams p) {
     auto split_pair = [&](int e2) __attribute__((always_inline)) {
         gbf_f32x2 v = {xv[2 * e2], xv[2 * e2 + 1]};
         if (XMODE == 0 ? !col_ok : !lx_ok_prev) v = gbf_f32x2{0.f, 0.f};
-        if (XMODE == 2 && lx_act_prev) {        // leaky ReLU of the first source (slope in [0, 1])
-            const gbf_f32x2 sv = v * p.in_slope;
-            v = gbf_f32x2{fmaxf(v.x, sv.x), fmaxf(v.y, sv.y)};
-        }
         const unsigned w0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, gbf_bf16x2));
         const gbf_f32x2 r1 = v - gbf_f32x2{__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u)};
         const unsigned w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, gbf_bf16x2));
@@ -190,9 +163,9 @@ gemmbf_kernel(const GemmBfParams p) {
     dma_a(0);
     if (n_steps > 1) dma_a(1);
     load_x(0);
-    lx_ok_prev = lx_ok; lx_act_prev = lx_act;
+    lx_ok_prev = lx_ok;
     store_x(0);
-    if (n_steps > 1) { load_x(1); lx_ok_prev = lx_ok; lx_act_prev = lx_act; }
+    if (n_steps > 1) { load_x(1); lx_ok_prev = lx_ok; }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XMODE == 0 ? 2 : 8) : "memory");   // the DMA pieces (older than step 1's loads) have landed
     lds_barrier();
 
@@ -248,7 +221,7 @@ gemmbf_kernel(const GemmBfParams p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
         }
-        lx_ok_prev = lx_ok; lx_act_prev = lx_act;
+        lx_ok_prev = lx_ok;
         // everything older than this step's own memory operations has completed: the tap fragments of step s + 1 are in LDS
         if (more2 && !(DBG & 5)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + (XMODE == 0 ? 2 : 8)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -281,21 +254,13 @@ gemmbf_kernel(const GemmBfParams p) {
                     if (res) o += *reinterpret_cast<const f32x4 *>(res + n * p.ldy + m);
                     *reinterpret_cast<f32x4 *>(dst) = o;
                 }
-            } else if (p.y_mode == 1) {   // channel-major: a wave's 32 columns are 128 contiguous bytes per row
+            } else {               // channel-major: a wave's 32 columns are 128 contiguous bytes per row
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mb + (r & 3) + 8 * (r >> 2);
                     float v = finish(acc[mi][ni][r], m);
                     if (res) v += res[(int64_t)m * p.ldy + n];
                     y[(int64_t)m * p.ldy + n] = v;
-                }
-            } else {               // polyphase ConvTranspose1d: row = (phase, channel); output time = column * rate + phase - pad
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mb + (r & 3) + 8 * (r >> 2);
-                    const int phase = m / p.up_cout, co = m - phase * p.up_cout;
-                    const int64_t t = n * p.up_rate + phase - p.up_pad;
-                    if (t >= 0 && t < p.ldy) y[(int64_t)co * p.ldy + t] = acc[mi][ni][r] + (p.bias ? p.bias[co] : 0.f);
                 }
             }
         }
@@ -307,7 +272,6 @@ static int gemmbf_launch(GemmBfParams p, hipStream_t stream) {
     std::call_once(once, [] {
         err = hipFuncSetAttribute((const void *)gemmbf_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, GBF_LDS);
         if (err == hipSuccess) err = hipFuncSetAttribute((const void *)gemmbf_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, GBF_LDS);
-        if (err == hipSuccess) err = hipFuncSetAttribute((const void *)gemmbf_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, GBF_LDS);
     });
     if (err != hipSuccess) return fail("gemm bf16x3: cannot reserve %d bytes of LDS: %s", GBF_LDS, hipGetErrorString(err));
     p.n_col_blocks = (int)ceil_div(p.N, GBF_BN);
@@ -329,8 +293,7 @@ static int gemmbf_launch(GemmBfParams p, hipStream_t stream) {
         return 0;
     }
     if (p.x_mode == 0) hipLaunchKernelGGL(gemmbf_kernel<0>, grid, dim3(GBF_NTH), GBF_LDS, stream, p);
-    else if (p.x_mode == 1) hipLaunchKernelGGL(gemmbf_kernel<1>, grid, dim3(GBF_NTH), GBF_LDS, stream, p);
-    else hipLaunchKernelGGL(gemmbf_kernel<2>, grid, dim3(GBF_NTH), GBF_LDS, stream, p);
+    else hipLaunchKernelGGL(gemmbf_kernel<1>, grid, dim3(GBF_NTH), GBF_LDS, stream, p);
     RVC_LAUNCH_CHECK();
     return 0;
 }
@@ -356,34 +319,6 @@ static void gemmbf_pack_rows(const float *w, int M, int K, std::vector<uint16_t>
                             (*out)[piece * 512 + lane * 8 + e] = h;
                         }
                     }
-}
-
-// ---- polyphase ConvTranspose1d of the vocoders (decoder.hip) on this kernel -----------------------------------------------
-// w_tkm: the direct kernel's slab [taps][c_in + c2][rate * c_out] (rows (phase, channel)); -> A fragments of the matrix
-// [rate * c_out][taps * (c_in + c2)]
-bool gemmbf_upsample_supported(int c_in, int c2, int m_total) { return c_in % 16 == 0 && c2 % 16 == 0 && m_total % GBF_BM == 0; }
-
-void gemmbf_pack_upsample(const float *w_tkm, int taps, int ctot, int m_total, std::vector<uint16_t> *out) {
-    const int K = taps * ctot;
-    std::vector<float> rows((size_t)m_total * K);
-    for (int k = 0; k < K; ++k)
-        for (int m = 0; m < m_total; ++m) rows[(size_t)m * K + k] = w_tkm[(size_t)k * m_total + m];
-    gemmbf_pack_rows(rows.data(), m_total, K, out);
-}
-
-// y[co][q * rate + phase - pad] = bias[co] + sum_tap ( sum_ci W lrelu(x[ci][q + tap - (taps - 1)]) + sum_k W V[k][q + tap - (taps - 1)] )
-int launch_gemmbf_upsample(const float *x, int c_in, int64_t l_in, float slope, const float *x2, int c2, int64_t l_in2, const void *a,
-                           const float *bias, float *y, int c_out, int rate, int up_pad, int taps, int64_t n_cols, int64_t l_out, int batch,
-                           hipStream_t stream) {
-    if ((int64_t)rate * c_out * taps * (c_in + c2) * 6 >= ((int64_t)1 << 31)) return fail("gemm bf16x3 upsampler: weight slab exceeds 2 GiB");
-    GemmBfParams p;
-    p.a = a; p.x = x; p.y = y; p.bias = bias;
-    p.M = rate * c_out; p.K = taps * (c_in + c2); p.c_in = c_in; p.N = n_cols;
-    p.x_mode = 2; p.ldx = l_in; p.l_in = l_in; p.stride = 1; p.dil = 1; p.pad = taps - 1; p.in_slope = slope;
-    p.x2 = x2; p.c2 = c2; p.ldx2 = l_in2; p.l_in2 = l_in2; p.x2_bstride = (int64_t)c2 * l_in2;
-    p.y_mode = 2; p.ldy = l_out; p.up_rate = rate; p.up_pad = up_pad; p.up_cout = c_out;
-    p.batch = batch; p.x_bstride = (int64_t)c_in * l_in; p.y_bstride = (int64_t)c_out * l_out;
-    return gemmbf_launch(p, stream);
 }
 
 }  // namespace rvc

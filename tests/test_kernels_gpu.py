@@ -498,6 +498,42 @@ def test_decoder_full_synth_golden(native, dev, ref_inputs):
     assert rms(out - g["o"]) <= 5e-5, rms(out - g["o"])
 
 
+def test_decoder_forwards_on_two_streams_are_bit_exact(native, dev):
+    """Two host threads run the same decoder handle on their own streams (what convert_batch does): every output must equal
+    its one-at-a-time reference BIT FOR BIT.  This is the regression test of a hardware interaction found in round 3: a
+    workgroup issuing bf16 matrix instructions (gemmbf.hip) that shares a CU with a workgroup of the fp32 Winograd kernel
+    (wino.hip) corrupts the latter's results, so no default path may put such kernels next to the vocoder."""
+    import threading
+    from rvc_amd.lib import synthetic as S
+    from rvc_amd.lib.algorithm.weights import fold_weight_norm
+    cpt = S.make_synth_checkpoint(48000, "HiFi-GAN", seed=0)
+    folded = {k[4:]: v for k, v in fold_weight_norm(cpt["weight"]).items() if k.startswith("dec.")}
+    dec = native.Decoder("HiFi-GAN", 48000, folded)
+    Ts = (500, 800)
+    ins = []
+    for i, T in enumerate(Ts):
+        g = torch.Generator(device=dev).manual_seed(i)
+        ins.append((torch.randn(1, 192, T, device=dev, generator=g), torch.full((1, T), 220.0, device=dev),
+                    torch.randn(1, 256, device=dev, generator=g), torch.zeros(1, T * 480, 1, device=dev), torch.zeros(1, 1, device=dev)))
+    refs = [dec.forward(z, f0, gv, src_randn=nz, src_rand=rnd).clone() for z, f0, gv, nz, rnd in ins]
+    torch.cuda.synchronize()
+    bad = [0, 0]
+
+    def worker(i):
+        st = torch.cuda.Stream(device=dev)
+        z, f0, gv, nz, rnd = ins[i]
+        with torch.cuda.stream(st):
+            for _ in range(25):
+                out = dec.forward(z, f0, gv, src_randn=nz, src_rand=rnd)
+                st.synchronize()
+                bad[i] += int((out != refs[i]).any().item())
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert bad == [0, 0], f"decoder outputs changed under concurrency in {bad} of 25 runs per thread"
+
+
 # ---- K5 BiGRU ----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("multi_cu", [False, True])
 @pytest.mark.parametrize("batch,steps", [(1, 96), (2, 333), (1, 3232)])
