@@ -8,14 +8,16 @@ import torch
 from rvc_amd import _native
 from rvc_amd.lib import synthetic as S
 from rvc_amd.lib.algorithm.weights import fold_weight_norm
-cpt = S.make_synth_checkpoint(48000, "HiFi-GAN", seed=0)
+VOC = os.environ.get("VOC", "HiFi-GAN")
+cpt = S.make_synth_checkpoint(48000, VOC, seed=0)
 folded = {k[4:]: v for k, v in fold_weight_norm(cpt["weight"]).items() if k.startswith("dec.")}
-dec = _native.Decoder("HiFi-GAN", 48000, folded)
+dec = _native.Decoder(VOC, 48000, folded)
+DIM = 9 if VOC.startswith("MRF") else 1
 dev = "cuda:0"
 def inputs(T, seed):
     g = torch.Generator(device=dev).manual_seed(seed)
     return (torch.randn(1, 192, T, device=dev, generator=g), torch.full((1, T), 220.0, device=dev), torch.randn(1, 256, device=dev, generator=g),
-            torch.zeros(1, T * 480, 1, device=dev), torch.zeros(1, 1, device=dev))
+            torch.zeros(1, T * 480, DIM, device=dev), torch.zeros(1, DIM, device=dev))
 Ts = [int(v) for v in os.environ.get("TS", "500,800").split(",")]
 ins = [inputs(T, i) for i, T in enumerate(Ts)]
 refs = []
