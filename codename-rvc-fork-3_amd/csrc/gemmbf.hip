@@ -9,12 +9,11 @@
 // terms < 2^-23 of a product) -- 6 x 32 matrix cycles for 16 k where the fp32 matrix instruction needs 8 x 64.
 //
 // Weights: split once at load into ready-made A fragments (1 KiB: 32 rows x 16 k x one split), streamed by LDS-DMA through a
-// ring of three 12 KiB slots.  Activations: fetched by the block's 256 threads (thread = one column x 8 consecutive k), split
+// ring of three 12 KiB slots.  Activations: fetched by the block's 512 threads (thread = one column x 8 consecutive k), split
 // with v_cvt_pk_bf16_f32 and written to LDS as B fragments (ring of two), one k16-step ahead of the matrix instructions.
-// Block = 128 rows x 128 columns, 4 waves (2 x 2) of 64 x 64: FOUR independent accumulators per wave, so a wave's matrix
+// Block = 128 rows x 256 columns, 8 waves (2 x 4) of 64 x 64: FOUR independent accumulators per wave, so a wave's matrix
 // instructions issue every 32 cycles without waiting on each other (the lesson of winobf.hip, where one accumulator per step
-// made a 64-cycle chain); two blocks per CU (60 KiB LDS each) keep two such waves on every SIMD, out of step with each other,
-// which hides the per-step barrier, the LDS latency and the staging arithmetic.
+// made a 64-cycle chain); two waves per SIMD, and the staging of the next steps placed between the matrix instructions.
 #include <stdlib.h>
 
 #include <mutex>
@@ -44,11 +43,19 @@ struct GemmBfParams {
     int n_col_blocks = 0;
 };
 
-constexpr int GBF_BM = 128, GBF_BN = 128, GBF_NW = 4, GBF_NTH = 256;
+// Block = 128 rows x 256 columns, 8 waves (2 x 4) of 64 x 64, ONE block per CU: the launch asks for the CU's whole LDS although
+// it uses 84 KiB of it, so that no other kernel's workgroup can sit next to it -- a workgroup issuing bf16 matrix
+// instructions that shares a CU with a workgroup of the fp32 Winograd kernel (wino.hip) corrupts that kernel's results
+// (profiles/r03_mfma_cohabitation.txt).  The first form of this kernel (128 x 128, 4 waves, two blocks of 60 KiB per CU with
+// independent barriers) was ~10 % faster and is what the measurements in that file were taken with.
+constexpr int GBF_BM = 128, GBF_WN = 4, GBF_BN = 64 * GBF_WN, GBF_NW = 2 * GBF_WN, GBF_NTH = 64 * GBF_NW;
+constexpr int GBF_UPW = (12 + GBF_NW - 1) / GBF_NW;   // tap-fragment DMA instructions per wave per step (12 KiB pieces)
 constexpr int GBF_A_SLOT = 4 * 3 * 1024;            // [32-row block 4][split 3][1 KiB]
-constexpr int GBF_B_PLANE = GBF_BN * 16;            // [128 columns][8 bf16]
+constexpr int GBF_B_PLANE = GBF_BN * 16;            // [256 columns][8 bf16]
 constexpr int GBF_B_SLOT = 3 * 2 * GBF_B_PLANE;     // [split][k half]
-constexpr int GBF_LDS = 3 * GBF_A_SLOT + 2 * GBF_B_SLOT;
+constexpr int GBF_LDS_USED = 3 * GBF_A_SLOT + 2 * GBF_B_SLOT;
+constexpr int GBF_LDS = 163840;                     // requested: the whole CU (see above)
+static_assert(GBF_LDS_USED <= GBF_LDS, "");
 
 typedef float gbf_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 gbf_bf16x2 __attribute__((ext_vector_type(2)));
@@ -66,7 +73,7 @@ gemmbf_kernel(const GemmBfParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     __builtin_assume(wave >= 0 && wave < GBF_NW);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / GBF_WN, wn = wave % GBF_WN;
     const int half = lane >> 5, l31 = lane & 31;
     const int bz = blockIdx.z;
     // the row blocks of one column tile read the same activations: ids 8 apart land on the same XCD (its L2)
@@ -86,14 +93,15 @@ gemmbf_kernel(const GemmBfParams p) {
         unsigned char *dst = as + (s % 3) * GBF_A_SLOT;
         const int s0 = blk_base + s * GBF_A_SLOT;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int n = wave + GBF_NW * i;
+        for (int i = 0; i < GBF_UPW; ++i) {
+            int n = wave + GBF_NW * i;
+            if (n >= 12) n -= GBF_NW;          // the overhang repeats a piece this wave has already issued: same bytes, same place
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (gbf_lptr_t)(dst + n * 1024), 16, 16 * lane, s0 + n * 1024, 0, 0);
         }
     };
 
     // ---- activation staging: thread = column t_l, k half kh (8 consecutive k of the step) -------------------------------
-    const int t_l = tid & 127, kh = tid >> 7;
+    const int t_l = tid % GBF_BN, kh = tid / GBF_BN;
     const int64_t n_col = n0 + t_l;
     const bool col_ok = n_col < p.N;
     float xv[8];
@@ -179,9 +187,10 @@ gemmbf_kernel(const GemmBfParams p) {
         const unsigned char *bb = bs + (s & 1) * GBF_B_SLOT + half * GBF_B_PLANE + (wn * 64 + l31) * 16;
         auto filler = [&](int k) __attribute__((always_inline)) {
             if (k < 3) {
-                if (more2 && !(DBG & 4)) {
+                if (k < GBF_UPW && more2 && !(DBG & 4)) {
                     unsigned char *dst = as + ((s + 2) % 3) * GBF_A_SLOT;
-                    const int n = wave + GBF_NW * k;
+                    int n = wave + GBF_NW * k;
+                    if (n >= 12) n -= GBF_NW;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (gbf_lptr_t)(dst + n * 1024), 16, 16 * lane, blk_base + (s + 2) * GBF_A_SLOT + n * 1024, 0, 0);
                 }
             } else if (k < 7) {
@@ -223,7 +232,7 @@ gemmbf_kernel(const GemmBfParams p) {
         }
         lx_ok_prev = lx_ok;
         // everything older than this step's own memory operations has completed: the tap fragments of step s + 1 are in LDS
-        if (more2 && !(DBG & 5)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + (XMODE == 0 ? 2 : 8)) : "memory");
+        if (more2 && !(DBG & 5)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GBF_UPW + (XMODE == 0 ? 2 : 8)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(DBG & 8)) lds_barrier();
     }

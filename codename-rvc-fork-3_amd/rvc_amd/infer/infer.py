@@ -154,11 +154,6 @@ class VoiceConverter:
         n_workers = max(1, min(int(inflight), len(audios)))
         if kwargs.get("noise_seed") is not None:
             n_workers = 1   # parity mode replays torch's GLOBAL CPU generator stream: one utterance at a time
-        if n_workers > 1 and getattr(self.hubert_model, "_conv_bf", None):
-            # RVC_HUBERT_CONV=1: a bf16-matrix-instruction workgroup next to the other utterance's fp32 Winograd convs corrupts
-            # them (profiles/r03_mfma_cohabitation.txt) -- that opt-in is for one utterance at a time
-            raise RuntimeError("convert_batch with utterances in flight cannot be combined with RVC_HUBERT_CONV=1 "
-                               "(HuBERT convs on gemmbf.hip): unset it, or pass inflight=1")
         if not hasattr(self, "_batch_streams"):
             self._batch_streams = []
             self._batch_slots = {}

@@ -35,18 +35,17 @@ class HubertModelWithFinalProj:
     def load_state_dict(self, sd, strict: bool = True):
         w = fold_weight_norm(sd)
         self.w = {k: v.to(self.device) for k, v in w.items() if v.is_floating_point()}
-        # feature-extractor convs 1-5 (512 -> 512, 3 / 2 taps, stride 2; 51 k .. 3 k columns for a 30 s clip) CAN run in librvc_amd's
-        # K11 (gemmbf.hip: exact bf16x3 splits on the bf16 matrix cores, GELU in the epilogue): 1.06-1.63x MIOpen's NHWC igemm + its
-        # transposes + the GELU pass (tools/bench_gemmbf.py), 0.5-0.7 ms per 30 s utterance.  OFF by default (RVC_HUBERT_CONV=1
-        # turns it on): a K11 workgroup that shares a CU with a workgroup of the fp32 Winograd kernel (wino.hip: the vocoder's
-        # 3-tap layers and its 32-channel stage) corrupts THAT kernel's results -- measured on MI355X, tools/diag_victim.py: 300 of
-        # 300 runs wrong by up to 2.2 while K11's bf16 matrix instructions are in flight on the same SIMDs, 0 of 300 with them
-        # compiled out or with LDS sizes that keep the two kernels on different CUs -- and with two utterances
-        # in flight one utterance's HuBERT overlaps the other's vocoder.  Safe only when nothing else runs on the GPU.
+        # feature-extractor convs 1-3 (512 -> 512, 3 taps, stride 2; 51 k .. 13 k columns for a 30 s clip) run in librvc_amd's K11
+        # (gemmbf.hip: exact bf16x3 splits on the bf16 matrix cores, GELU in the epilogue): 1.44-1.73x MIOpen's NHWC igemm + its
+        # transposes + the GELU pass (tools/bench_gemmbf.py), 0.55 ms per 30 s utterance; layers 4-6 (6 k columns and fewer) and the
+        # fp32 projections stay on the libraries, which are faster at those sizes.  K11 launches one 8-wave block per CU and asks
+        # for the CU's whole LDS: a workgroup issuing bf16 matrix instructions must not share a CU with the vocoder's fp32
+        # Winograd kernel (profiles/r03_mfma_cohabitation.txt), and with two utterances in flight HuBERT overlaps the other
+        # utterance's vocoder.  RVC_HUBERT_CONV=0: everything through MIOpen.
         self._conv_bf = {}
-        if self.device.type == "cuda" and os.environ.get("RVC_HUBERT_CONV", "0") == "1":
+        if self.device.type == "cuda" and os.environ.get("RVC_HUBERT_CONV", "1") != "0":
             from rvc_amd import _native
-            for i in (1, 2, 3, 4, 5):
+            for i in (1, 2, 3):
                 cw = self.w[f"feature_extractor.conv_layers.{i}.conv.weight"]
                 if cw.shape[0] % 128 == 0 and cw.shape[1] % 16 == 0:
                     self._conv_bf[i] = _native.gemm_bf16x3_pack_weight(cw, self.device)

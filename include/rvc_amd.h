@@ -347,9 +347,9 @@ int rvc_conv1d_winobf_forward(const float *x_dev, const void *u_dev, const float
  * projections (nn.Linear: y = act(x W^T + b) + res, x [n_rows][in] row-major) and the stride-2 convolutions of the feature
  * extractor (nn.Conv1d without padding + GELU, x [batch][C_in][L] channel-major).  Every fp32 operand is split exactly into three
  * bf16 numbers and the six products of order <= 2^-16 are accumulated in fp32 (csrc/gemmbf.hip).
- * CAUTION (measured on MI355X, profiles/r03_mfma_cohabitation.txt): a workgroup of this kernel that shares a CU with a workgroup
- * of the fp32 Winograd kernel behind rvc_decoder_forward / rvc_conv1d_wino_forward corrupts THAT kernel's results.  Do not run
- * these entries on one stream while a vocoder runs on another; one utterance at a time is safe; results agree with float64 as
+ * The kernel launches one 8-wave workgroup per CU and requests the CU's whole LDS: a workgroup issuing bf16 matrix instructions
+ * that shares a CU with a workgroup of the fp32 Winograd kernel behind rvc_decoder_forward corrupts THAT kernel's results
+ * (measured on MI355X, profiles/r03_mfma_cohabitation.txt), so this one never shares; results agree with float64 as
  * closely as an fp32 GEMM does.  act: 0 none, 1 GELU (erf form, what torch.nn.functional.gelu computes).
  * Weights: rvc_gemm_bf16x3_weight_bytes() bytes filled by rvc_gemm_bf16x3_pack_weight from the [out][in] (linear, conv_taps = 1) or
  * [C_out][C_in][taps] (conv, conv_taps = taps, k_total = taps * C_in) host tensor.  out / C_out a multiple of 128, in / C_in of 16. */

@@ -24,19 +24,12 @@ ref_conv = _native.conv1d_bf16x3(x, a, bias, C, 3, 2, 0, "gelu").clone()
 torch.cuda.synchronize()
 bad = {"conv": 0, "dec": 0}
 stop = False
-import ctypes
-lib = ctypes.CDLL(os.path.join(ROOT, "codename-rvc-fork-3_amd/rvc_amd/_lib/librvc_amd.so"))
-lib.rvc_debug_lds_poison.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_int, ctypes.c_void_p]
-MODE = os.environ.get("CORUN", "conv")
 def conv_worker():
     st = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(st):
         while not stop:
-            if MODE == "conv":
-                out = _native.conv1d_bf16x3(x, a, bias, C, 3, 2, 0, "gelu"); st.synchronize()
-                if (out - ref_conv).abs().max().item() > 0: bad["conv"] += 1
-            else:
-                lib.rvc_debug_lds_poison(int(os.environ.get("PBYTES", 61440)), 2048, int(os.environ.get("PATTERN", "0x7fc00000"), 16), 2000, st.cuda_stream); st.synchronize()
+            out = _native.conv1d_bf16x3(x, a, bias, C, 3, 2, 0, "gelu"); st.synchronize()
+            if (out - ref_conv).abs().max().item() > 0: bad["conv"] += 1
 def dec_worker():
     global stop
     st = torch.cuda.Stream(device=dev)
