@@ -335,6 +335,7 @@ static void gemmbf_pack_rows(const float *w, int M, int K, std::vector<uint16_t>
 using namespace rvc;
 
 extern "C" int rvc_gemm_bf16x3_weight_bytes(int m, int k, size_t *bytes) {
+    if (k > 0 && k < 16) k = 16;     // a single-input-channel conv of <= 16 taps (HuBERT's first layer): one zero-padded k16 step
     if (!bytes || m <= 0 || k <= 0 || m % GBF_BM || k % 16) return fail("rvc_gemm_bf16x3_weight_bytes: m must be a multiple of 128, k of 16");
     *bytes = (size_t)m * k * 6;
     return 0;
@@ -346,6 +347,17 @@ extern "C" int rvc_gemm_bf16x3_pack_weight(const float *w_host, int m, int k_tot
     if (rvc_gemm_bf16x3_weight_bytes(m, k_total, &bytes)) return 1;
     std::vector<float> rows;
     const float *w = w_host;
+    if (conv_taps > 1 && k_total == conv_taps && conv_taps <= 16) {   // one input channel: [m][taps] -> [m][16], zero-padded
+        rows.assign((size_t)m * 16, 0.f);
+        for (int r = 0; r < m; ++r)
+            for (int t = 0; t < conv_taps; ++t) rows[(size_t)r * 16 + t] = w_host[(size_t)r * conv_taps + t];
+        std::vector<uint16_t> packed1;
+        gemmbf_pack_rows(rows.data(), m, 16, &packed1);
+        hipError_t e1 = hipMemcpyAsync(a_dev, packed1.data(), bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+        if (e1 == hipSuccess) e1 = hipStreamSynchronize((hipStream_t)stream);
+        if (e1 != hipSuccess) return fail("rvc_gemm_bf16x3_pack_weight: %s", hipGetErrorString(e1));
+        return 0;
+    }
     if (conv_taps > 1) {   // conv weight [m][c_in][taps] -> [m][tap * c_in + ci]
         if (k_total % conv_taps || (k_total / conv_taps) % 16) return fail("rvc_gemm_bf16x3_pack_weight: c_in must be a multiple of 16");
         const int c_in = k_total / conv_taps;
@@ -380,7 +392,10 @@ extern "C" int rvc_linear_bf16x3(const float *x_dev, const void *a_dev, const fl
 extern "C" int rvc_conv1d_bf16x3(const float *x_dev, const void *a_dev, const float *bias_dev, float *y_dev, int batch, int c_in,
                                  int c_out, int64_t l_in, int k, int stride, int padding, int act, void *stream) {
     if (!x_dev || !a_dev || !y_dev) return fail("rvc_conv1d_bf16x3: null pointer");
-    if (c_out % GBF_BM || c_in % 16 || k < 1 || stride < 1 || padding < 0) return fail("rvc_conv1d_bf16x3: c_out must be a multiple of 128, c_in of 16");
+    const bool one_channel = c_in == 1;   // X[k][n] = x[n * stride + k], k < 16: the 16 "channels" are 16 consecutive samples (row pitch 1)
+    if (one_channel && (k > 16 || padding != 0 || batch != 1))
+        return fail("rvc_conv1d_bf16x3: a single input channel takes <= 16 taps, no padding, batch 1 (x followed by 16 - k readable floats)");
+    if (c_out % GBF_BM || (!one_channel && c_in % 16) || k < 1 || stride < 1 || padding < 0) return fail("rvc_conv1d_bf16x3: c_out must be a multiple of 128, c_in of 16");
     if ((int64_t)c_out * c_in * k * 6 >= ((int64_t)1 << 31)) return fail("rvc_conv1d_bf16x3: weight slab exceeds 2 GiB");
     if (act < 0 || act > 1) return fail("rvc_conv1d_bf16x3: act must be 0 (none) or 1 (gelu)");
     const int64_t l_out = (l_in + 2 * padding - k) / stride + 1;
@@ -389,6 +404,7 @@ extern "C" int rvc_conv1d_bf16x3(const float *x_dev, const void *a_dev, const fl
     p.a = a_dev; p.x = x_dev; p.y = y_dev; p.bias = bias_dev;
     p.M = c_out; p.K = k * c_in; p.c_in = c_in; p.N = l_out;
     p.x_mode = 1; p.ldx = l_in; p.l_in = l_in; p.stride = stride; p.dil = 1; p.pad = padding;
+    if (one_channel) { p.K = 16; p.c_in = 16; p.ldx = 1; }   // one tap of 16 pseudo-channels; weights beyond k are zero
     p.y_mode = 1; p.ldy = l_out; p.act = act; p.batch = batch;
     p.x_bstride = (int64_t)c_in * l_in; p.y_bstride = (int64_t)c_out * l_out;
     return gemmbf_launch(p, (hipStream_t)stream);

@@ -35,7 +35,7 @@ class HubertModelWithFinalProj:
     def load_state_dict(self, sd, strict: bool = True):
         w = fold_weight_norm(sd)
         self.w = {k: v.to(self.device) for k, v in w.items() if v.is_floating_point()}
-        # feature-extractor convs 1-3 (512 -> 512, 3 taps, stride 2; 51 k .. 13 k columns for a 30 s clip) run in librvc_amd's K11
+        # feature-extractor convs 0-3 (1 -> 512 with 10 taps, then 512 -> 512, 3 taps, stride 2; 96 k .. 13 k columns for a 30 s clip) run in librvc_amd's K11
         # (gemmbf.hip: exact bf16x3 splits on the bf16 matrix cores, GELU in the epilogue): 1.44-1.73x MIOpen's NHWC igemm + its
         # transposes + the GELU pass (tools/bench_gemmbf.py), 0.55 ms per 30 s utterance; layers 4-6 (6 k columns and fewer) and the
         # fp32 projections stay on the libraries, which are faster at those sizes.  K11 launches one 8-wave block per CU and asks
@@ -45,9 +45,9 @@ class HubertModelWithFinalProj:
         self._conv_bf = {}
         if self.device.type == "cuda" and os.environ.get("RVC_HUBERT_CONV", "1") != "0":
             from rvc_amd import _native
-            for i in (1, 2, 3):
+            for i in (0, 1, 2, 3):    # layer 0: 1 -> 512 channels, 10 taps, stride 5 (MIOpen: im2col + GEMM, 0.43 ms; here one k16 step)
                 cw = self.w[f"feature_extractor.conv_layers.{i}.conv.weight"]
-                if cw.shape[0] % 128 == 0 and cw.shape[1] % 16 == 0:
+                if cw.shape[0] % 128 == 0 and (cw.shape[1] % 16 == 0 or (cw.shape[1] == 1 and cw.shape[2] <= 16)):
                     self._conv_bf[i] = _native.gemm_bf16x3_pack_weight(cw, self.device)
         self._qkv = {}
         for i in range(self.n_layers):
@@ -83,11 +83,13 @@ class HubertModelWithFinalProj:
         x = wav[:, None, :]
         for i, s in enumerate(CONV_STRIDES):
             cw = w[f"feature_extractor.conv_layers.{i}.conv.weight"]
-            if i in self._conv_bf and x.is_cuda:
+            if i in self._conv_bf and x.is_cuda and (i > 0 or x.shape[0] == 1):
                 from rvc_amd import _native
-                x = _native.conv1d_bf16x3(x, self._conv_bf[i], None, cw.shape[0], cw.shape[2], stride=s, act="gelu")
-                continue
-            x = F.conv1d(x, cw, None, stride=s)
+                x = _native.conv1d_bf16x3(x, self._conv_bf[i], None, cw.shape[0], cw.shape[2], stride=s, act="gelu" if i > 0 else "none")
+                if i > 0:
+                    continue
+            else:
+                x = F.conv1d(x, cw, None, stride=s)
             if i == 0:
                 x = F.group_norm(x, x.shape[1], w["feature_extractor.conv_layers.0.layer_norm.weight"],
                                  w["feature_extractor.conv_layers.0.layer_norm.bias"], 1e-5)

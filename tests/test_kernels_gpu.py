@@ -149,6 +149,7 @@ def test_linear_bf16x3_matches_float64(native, dev, n_rows, k, m, act, with_res)
 
 @pytest.mark.parametrize("c_in,c_out,k,stride,length,batch,act", [
     (512, 512, 3, 2, 5119, 1, "gelu"), (512, 512, 2, 2, 640, 2, "gelu"), (64, 128, 3, 1, 300, 1, "none"), (512, 512, 3, 2, 4, 1, "none"),
+    (1, 512, 10, 5, 16000, 1, "none"), (1, 512, 10, 5, 4003, 1, "none"),      # HuBERT's first layer: one input channel, 10 taps, stride 5
 ])
 def test_conv1d_bf16x3_matches_float64(native, dev, c_in, c_out, k, stride, length, batch, act):
     """gemmbf.hip, conv mode: HuBERT's feature-extractor convs (Conv1d(512, 512, k in {3, 2}, stride 2, no padding) + GELU)."""
