@@ -499,6 +499,47 @@ def test_decoder_full_synth_golden(native, dev, ref_inputs):
     assert rms(out - g["o"]) <= 5e-5, rms(out - g["o"])
 
 
+@pytest.mark.parametrize("k,c", [(11, 128), (3, 64), (7, 32)])
+def test_fp32_winograd_next_to_the_bf16_gemm_is_bit_exact(native, dev, k, c):
+    """Regression test of profiles/r03_mfma_cohabitation.txt: while one thread launches gemmbf.hip (bf16 matrix instructions) in
+    a loop on its own stream, the fp32 Winograd kernel on another stream must return bit-identical results every time.  It does
+    because gemmbf asks for a CU's whole LDS and so never shares one; in its first form (two 60 KiB blocks per CU) 300 of 300
+    runs of this loop came back wrong by up to 2.2."""
+    import threading
+    g = torch.Generator().manual_seed(k * 1000 + c)
+    a = native.gemm_bf16x3_pack_weight(torch.randn(512, 512, 3, generator=g) * 0.03, dev)
+    xg = torch.randn(1, 512, 51000, generator=g).to(dev)
+    L = 60000 if c >= 64 else 400000
+    x = torch.randn(1, c, L, generator=g).to(dev)
+    res = torch.randn(1, c, L, generator=g).to(dev)
+    bias = torch.randn(c, generator=g).to(dev)
+    u = native.conv1d_wino_pack_weight(torch.randn(c, c, k, generator=g) * 0.03, dev)
+    ref = native.conv1d_wino_forward(x, u, bias, c, k, 1, 0.1, res=res).clone()
+    torch.cuda.synchronize()
+    state = {"stop": False, "bad": 0}
+
+    def co_runner():
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            while not state["stop"]:
+                native.conv1d_bf16x3(xg, a, None, 512, 3, stride=2, act="gelu")
+                st.synchronize()
+
+    def victim():
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            for _ in range(100):
+                out = native.conv1d_wino_forward(x, u, bias, c, k, 1, 0.1, res=res)
+                st.synchronize()
+                state["bad"] += int((out != ref).any().item())
+        state["stop"] = True
+
+    th = [threading.Thread(target=co_runner), threading.Thread(target=victim)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert state["bad"] == 0, f"{state['bad']} of 100 Winograd launches changed next to the bf16 GEMM kernel"
+
+
 def test_decoder_forwards_on_two_streams_are_bit_exact(native, dev):
     """Two host threads run the same decoder handle on their own streams (what convert_batch does): every output must equal
     its one-at-a-time reference BIT FOR BIT.  This is the regression test of a hardware interaction found in round 3: a
