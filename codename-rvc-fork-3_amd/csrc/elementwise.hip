@@ -2,6 +2,8 @@
 // (ConvBlockRes.forward, rvc/lib/predictors/RMVPE.py:25-64 with eval-mode BatchNorm folded into the conv: bias is the
 // folded shift).  PyTorch runs this as a broadcast add, a ReLU and a residual add -- three launches and three trips
 // through HBM per conv, ~170 small launches per utterance.  HBM-bound: one read of x (and res), one write.
+#include <stdint.h>
+
 #include "common.h"
 
 namespace rvc {
@@ -39,6 +41,57 @@ gate_tanh_sigmoid_kernel(const float *__restrict__ x, float *__restrict__ out, i
         o[t] = tanhf(xa[t]) * (1.f / (1.f + expf(-xb[t])));
 }
 
+
+// ---- per-channel GroupNorm + GELU (HuBERT's first layer) ---------------------------------------------------------------------
+// One block per (batch, channel) row: sum and sum of squares accumulated in float64 (375 elements per thread at 30 s), then the
+// row is re-read, normalised, scaled and passed through the exact (erf) GELU.  Three library launches and two extra passes less.
+__global__ void __launch_bounds__(256)
+rownorm_gelu_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ y,
+                    int channels, int64_t L, float eps) {
+    __shared__ double red[2][4];
+    const int64_t row = blockIdx.x;
+    const int c = (int)(row % channels);
+    const float *xr = x + row * L;
+    float *yr = y + row * L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double s = 0.0, q = 0.0;
+    const int64_t L4 = (L % 4 == 0 && (reinterpret_cast<uintptr_t>(xr) & 15) == 0) ? L / 4 : 0;
+    for (int64_t i = tid; i < L4; i += 256) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(xr)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s += (double)v[e]; q += (double)v[e] * (double)v[e]; }
+    }
+    for (int64_t i = 4 * L4 + tid; i < L; i += 256) { const double v = xr[i]; s += v; q += v * v; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); q += __shfl_xor(q, off); }
+    if (lane == 0) { red[0][wave] = s; red[1][wave] = q; }
+    __syncthreads();
+    s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const double mean = s / (double)L;
+    double var = q / (double)L - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float mu = (float)mean;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    auto f = [&](float v) __attribute__((always_inline)) {
+        const float n = (v - mu) * rstd * g + b;
+        return 0.5f * n * (1.f + erff(n * 0.70710678118654752f));
+    };
+    const bool y4 = L4 && (reinterpret_cast<uintptr_t>(yr) & 15) == 0;
+    if (y4) {
+        for (int64_t i = tid; i < L4; i += 256) {
+            f32x4 v = reinterpret_cast<const f32x4 *>(xr)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = f(v[e]);
+            reinterpret_cast<f32x4 *>(yr)[i] = v;
+        }
+        for (int64_t i = 4 * L4 + tid; i < L; i += 256) yr[i] = f(xr[i]);
+    } else {
+        for (int64_t i = tid; i < L; i += 256) yr[i] = f(xr[i]);
+    }
+}
+
 }  // namespace rvc
 
 using namespace rvc;
@@ -52,6 +105,16 @@ extern "C" int rvc_gate_tanh_sigmoid_f32(const float *x_dev, float *out_dev, int
     if (bx > 16) bx = 16;
     hipLaunchKernelGGL(gate_tanh_sigmoid_kernel, dim3((unsigned)bx, (unsigned)hidden, (unsigned)batch), dim3(256), 0,
                        (hipStream_t)stream, x_dev, out_dev, hidden, length);
+    RVC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rvc_rownorm_gelu_f32(const float *x_dev, const float *gamma_dev, const float *beta_dev, float *out_dev, int batch,
+                                    int channels, int64_t length, float eps, void *stream) {
+    if (!x_dev || !out_dev) return fail("rvc_rownorm_gelu_f32: null pointer");
+    if (batch <= 0 || channels <= 0 || length <= 0 || !(eps >= 0.f)) return fail("rvc_rownorm_gelu_f32: bad shape");
+    hipLaunchKernelGGL(rownorm_gelu_kernel, dim3((unsigned)((int64_t)batch * channels)), dim3(256), 0, (hipStream_t)stream, x_dev,
+                       gamma_dev, beta_dev, out_dev, channels, length, eps);
     RVC_LAUNCH_CHECK();
     return 0;
 }

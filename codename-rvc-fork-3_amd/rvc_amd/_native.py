@@ -77,6 +77,7 @@ SYMBOLS = {
                                       c_void_p, c_size_t, c_void_p]),
     "rvc_bias_relu_add_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p]),
     "rvc_gate_tanh_sigmoid_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "rvc_rownorm_gelu_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, ctypes.c_float, c_void_p]),
     "rvc_set_concurrency_hint": (c_int, [c_int]),
     "rvc_decoder_create": (c_int, [POINTER(DecoderConfig), POINTER(c_void_p)]),
     "rvc_decoder_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]),
@@ -423,6 +424,16 @@ def bias_relu_add_(x: torch.Tensor, bias: torch.Tensor = None, res: torch.Tensor
     _check(_lib.rvc_bias_relu_add_f32(x.data_ptr(), bias.data_ptr() if bias is not None else None,
                                       res.data_ptr() if res is not None else None, x.data_ptr(), b, c, inner, int(relu),
                                       _stream()), "rvc_bias_relu_add_f32")
+    return x
+
+
+def rownorm_gelu_(x: torch.Tensor, gamma: torch.Tensor = None, beta: torch.Tensor = None, eps: float = 1e-5) -> torch.Tensor:
+    """In place: x = gelu(group_norm(x, num_groups = channels)) for x [B, C, L] (fp32, HBM, contiguous)."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3
+    b, c, length = x.shape
+    _check(_lib.rvc_rownorm_gelu_f32(x.data_ptr(), gamma.data_ptr() if gamma is not None else None,
+                                     beta.data_ptr() if beta is not None else None, x.data_ptr(), b, c, length, float(eps), _stream()),
+           "rvc_rownorm_gelu_f32")
     return x
 
 

@@ -90,6 +90,11 @@ class HubertModelWithFinalProj:
                     continue
             else:
                 x = F.conv1d(x, cw, None, stride=s)
+            if i == 0 and x.is_cuda and x.is_contiguous():
+                from rvc_amd import _native      # GroupNorm(512, 512) + GELU in one launch (K8), float64 statistics
+                x = _native.rownorm_gelu_(x, w["feature_extractor.conv_layers.0.layer_norm.weight"],
+                                          w["feature_extractor.conv_layers.0.layer_norm.bias"], 1e-5)
+                continue
             if i == 0:
                 x = F.group_norm(x, x.shape[1], w["feature_extractor.conv_layers.0.layer_norm.weight"],
                                  w["feature_extractor.conv_layers.0.layer_norm.bias"], 1e-5)

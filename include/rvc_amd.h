@@ -184,6 +184,13 @@ int rvc_attention_qkv_f32(const float *qkv_dev, const float *emb_rel_k_dev, cons
 int rvc_bias_relu_add_f32(const float *x_dev, const float *bias_dev, const float *res_dev, float *out_dev, int batch,
                           int channels, int64_t inner, int relu, void *stream);
 
+/* out = gelu(GroupNorm(num_groups = channels)(x)) -- the normalisation + activation behind the first feature-extractor conv of
+ * `transformers`' HubertModel (pipeline.py:450; HubertGroupNormConvLayer: Conv1d -> GroupNorm(512, 512) -> GELU): per (batch,
+ * channel) row mean / variance over `length` (float64 accumulation, biased variance, eps inside the square root), affine
+ * gamma / beta [channels] (NULL: 1 / 0), exact erf GELU.  x_dev / out_dev [batch][channels][length]; out_dev may alias x_dev. */
+int rvc_rownorm_gelu_f32(const float *x_dev, const float *gamma_dev, const float *beta_dev, float *out_dev, int batch, int channels,
+                         int64_t length, float eps, void *stream);
+
 /* WaveNet gate of the flow (rvc/lib/algorithm/commons.py:142-157, modules.py:93-97): acts = tanh(x[:H]) * sigmoid(x[H:]).
  * x_dev [batch][2*hidden][length] (the conditioning is already inside: the producing conv adds it as its bias),
  * out_dev [batch][hidden][length]. */

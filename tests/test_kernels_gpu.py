@@ -576,6 +576,20 @@ def test_decoder_forwards_on_two_streams_are_bit_exact(native, dev):
     assert bad == [0, 0], f"decoder outputs changed under concurrency in {bad} of 25 runs per thread"
 
 
+@pytest.mark.parametrize("b,c,length", [(1, 512, 95999), (2, 64, 1003), (1, 8, 4)])
+def test_rownorm_gelu_matches_float64(native, dev, b, c, length):
+    """rvc_rownorm_gelu_f32 vs float64 GroupNorm(num_groups = channels) + exact GELU (HuBERT's first layer, pipeline.py:450)."""
+    g = torch.Generator().manual_seed(b * 7 + c + length)
+    x = torch.randn(b, c, length, generator=g) * 3.0 + 0.7
+    gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    ref = F.gelu(F.group_norm(x.double(), c, gamma.double(), beta.double(), 1e-5))
+    got = native.rownorm_gelu_(x.to(dev).clone(), gamma.to(dev), beta.to(dev), 1e-5).cpu()
+    lib = F.gelu(F.group_norm(x.to(dev), c, gamma.to(dev), beta.to(dev), 1e-5)).cpu()
+    err, err_lib = (got.double() - ref).abs().max().item(), (lib.double() - ref).abs().max().item()
+    print(f"rownorm + gelu [{b}, {c}, {length}]: max abs error vs float64 {err:.2e} (torch fp32: {err_lib:.2e})")
+    assert err <= 2e-6 * max(1.0, ref.abs().max().item())
+
+
 # ---- K5 BiGRU ----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("multi_cu", [False, True])
 @pytest.mark.parametrize("batch,steps", [(1, 96), (2, 333), (1, 3232)])
