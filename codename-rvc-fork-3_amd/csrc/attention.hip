@@ -300,7 +300,7 @@ attention_combine_kernel(const float *__restrict__ part_o, const float *__restri
 // 1/splits of the keys each.  Pick the split count that minimises rounds / splits (fewer splits on a tie: each one
 // re-loads the query fragment and adds a partial to combine).
 static int choose_splits(int64_t n_frames, int n_heads, int batch) {
-    static const int forced = getenv("RVC_ATT_SPLITS") ? atoi(getenv("RVC_ATT_SPLITS")) : 0;
+    static const int forced = knob("RVC_ATT_SPLITS", 0);
     const int64_t nt = ceil_div(n_frames, 32);
     const int64_t pairs = nt * n_heads * batch;
     int best = 1;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -29,6 +30,20 @@ int fail(const char *fmt, ...);  // sets the error, returns 1
         if (_e != hipSuccess) return ::rvc::fail("kernel launch failed: %s (%s:%d)",          \
                                                  hipGetErrorString(_e), __FILE__, __LINE__);  \
     } while (0)
+
+// ---- tuning / ablation switches --------------------------------------------------------------------
+// The product library reads NO environment variable to pick a kernel: knob() folds to its default.  Only the ablation build
+// (-DRVC_ABLATE: __graft_entry__.build_ablate() -> _lib/librvc_amd_ablate.so, loaded when RVC_AMD_LIB names it) reads the
+// RVC_* switches the tools/ scripts set, and only that build contains the kernel instantiations that leave work out and
+// therefore compute wrong results on purpose ("where does the time go" runs).
+#ifdef RVC_ABLATE
+static inline int knob(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+#else
+static inline constexpr int knob(const char *, int dflt) { return dflt; }
+#endif
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

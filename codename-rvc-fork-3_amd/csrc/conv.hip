@@ -358,22 +358,25 @@ static int launch_cfg(const ConvParams &p, hipStream_t stream) {
     return 0;
 }
 
-// tuning knobs for experiments (tools/bench_conv.py): RVC_CONV_CIC=4|8 overrides the chunk depth
-static int env_int(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
+// tuning knobs for experiments (tools/bench_conv.py, ablation build only): RVC_CONV_CIC=4|8 overrides the chunk depth
 
 template <int KW, int MT, int NT, int WM, int WN>
 static int launch_cic(const ConvParams &p, hipStream_t stream, int cic) {
     // 16-channel chunks were measured too (RVC_CONV_CIC=16 in an earlier build): slower everywhere (LDS per block, spills)
+#ifdef RVC_ABLATE
     if (cic == 4) return launch_cfg<KW, MT, NT, WM, WN, 4>(p, stream);
     return launch_cfg<KW, MT, NT, WM, WN, 8>(p, stream);
+#else
+    // the product build instantiates only the depth launch_kw picks: 4 for 7 / 11 taps, 8 below (the other pairing misses
+    // its register target: "desired occupancy was 3, final occupancy is 1")
+    (void)cic;
+    return launch_cfg<KW, MT, NT, WM, WN, (KW >= 7 ? 4 : 8)>(p, stream);
+#endif
 }
 
 template <int KW>
 static int launch_kw(const ConvParams &p, hipStream_t stream) {
-    static const int cic_env = env_int("RVC_CONV_CIC", 0);
+    static const int cic_env = knob("RVC_CONV_CIC", 0);
     // chunk depth: deep kernels (7, 11 taps) stage 4 channels per chunk (staging registers, 3 blocks/CU);
     // shallow ones amortise the barrier over more channels
     int cic = KW >= 7 ? 4 : 8;
@@ -384,7 +387,7 @@ static int launch_kw(const ConvParams &p, hipStream_t stream) {
         // on the others) -> halve the tile width so the CUs finish together
         // ... unless the caller keeps several utterances in flight (rvc_set_concurrency_hint): other streams fill the idle
         // block slots, and the wide tile streams each weight slab through L2 half as often (-0.4 ms per utterance)
-        static const int narrow_env = env_int("RVC_CONV_NARROW", 1);
+        static const int narrow_env = knob("RVC_CONV_NARROW", 1);
         const int64_t tiles = ceil_div(p.n_cols, 128) * (p.m_total / 128) * p.batch;
         if (narrow_env && tiles < 1536 && concurrency_hint() <= 1) return launch_cic<KW, 2, 1, 2, 2>(p, stream, cic);   // 128 x 64
         return launch_cic<KW, 2, 2, 2, 2>(p, stream, cic);                                   // 128 x 128
@@ -398,7 +401,7 @@ static int launch_kw(const ConvParams &p, hipStream_t stream) {
 // direct implicit GEMM on every one of the 24 (C, K, dilation) shapes of the 48 kHz vocoders (tools/bench_conv.py,
 // profiles/r02_conv_shapes.txt).  RVC_WINO=0 switches it off (A/B runs, and the direct form's own tests).
 bool wino_enabled() {
-    static const int mode = env_int("RVC_WINO", 1);
+    static const int mode = knob("RVC_WINO", 1);
     return mode != 0;
 }
 
@@ -406,7 +409,7 @@ bool wino_enabled() {
 // exactly into three bf16 (winobf.hip): 1.06-1.36x the fp32-matrix-instruction form on every such shape of the 48 kHz
 // vocoders (tools/bench_convbf.py, profiles/r03_convbf_shapes.txt).  RVC_WINOBF=0 switches it off.
 bool winobf_enabled() {
-    static const int mode = env_int("RVC_WINOBF", 1);
+    static const int mode = knob("RVC_WINOBF", 1);
     return mode != 0;
 }
 
@@ -426,7 +429,7 @@ int launch_conv(const ConvParams &p_in, hipStream_t stream) {
         wino_enabled() && wino_supported(p_in.kw, p_in.dil) && wino_fits(p_in.c1, p_in.m_total, p_in.l_in))
         return launch_wino_conv(p_in.x1, p_in.w_wino16 ? (const void *)p_in.w_wino16 : (const void *)p_in.w_wino, p_in.w_wino16 != nullptr, p_in.bias, p_in.res, p_in.accin, p_in.y, p_in.batch, p_in.c1, p_in.m_total, p_in.l_out,
                                 p_in.kw, p_in.dil, p_in.slope1, p_in.out_scale, stream);
-    static const int dbg = env_int("RVC_CONV_DEBUG", 0);
+    static const int dbg = knob("RVC_CONV_DEBUG", 0);
     ConvParams p = p_in;
     p.debug = dbg;
     if ((p.c1 % CONV_CH_ALIGN) || (p.c2 % CONV_CH_ALIGN) || p.c1 + p.c2 <= 0)

@@ -307,7 +307,7 @@ size_t conv2d_workspace_bytes(int batch, int c_in, int c_out, int H, int W, int 
     (void)taps;
     const int m_pad = (c_out + 31) / 32 * 32;
     int split = conv2d_split(c_in, m_pad, H, W, conv2d_bn(m_pad, W));
-    if (getenv("RVC_C2_SPLIT")) split = 64;   // experiments: room for any override
+    if (knob("RVC_C2_SPLIT", 0)) split = 64;   // experiments: room for any override
     return split > 1 ? (size_t)split * batch * c_out * H * W * sizeof(float) : 0;
 }
 
@@ -322,8 +322,8 @@ int launch_conv2d(const float *x, const float *w, const float *bias, const float
     Conv2dParams p;
     p.x = x; p.w = w; p.bias = bias; p.res = res; p.y = y;
     p.c_in = c_in; p.c_out = c_out; p.m_pad = (c_out + 31) / 32 * 32; p.H = H; p.W = W; p.taps = taps; p.relu = relu; p.batch = batch;
-    static const int dbg = getenv("RVC_C2_DEBUG") ? atoi(getenv("RVC_C2_DEBUG")) : 0;
-    static const int split_env = getenv("RVC_C2_SPLIT") ? atoi(getenv("RVC_C2_SPLIT")) : 0;
+    static const int dbg = knob("RVC_C2_DEBUG", 0);
+    static const int split_env = knob("RVC_C2_SPLIT", 0);
     p.debug = dbg;
     const int bn = conv2d_bn(p.m_pad, W);
     p.split = conv2d_split(c_in, p.m_pad, H, W, bn);

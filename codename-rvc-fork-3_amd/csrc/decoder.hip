@@ -501,7 +501,7 @@ extern "C" int rvc_decoder_finalize(rvc_decoder *d) {
         s.vk_rows = (s.vk + 7) / 8 * 8;
         s.S = (int64_t)s.rate * s.nc_stride;
         s.P = (int64_t)s.pad * s.nc_stride + s.nc_pad;
-        static const int nc_sep_env = getenv("RVC_NC_SEPARATE") ? atoi(getenv("RVC_NC_SEPARATE")) : 1;
+        static const int nc_sep_env = knob("RVC_NC_SEPARATE", 1);
         const bool nc_separate = nc_sep_env && s.vk_rows * 2 >= s.c_in;   // folding would at least 1.5x the upsampler's GEMM
         if (nc_separate) {
             s.nc_rows = (s.nc_k + 7) / 8 * 8;

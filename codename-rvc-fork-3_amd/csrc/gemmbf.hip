@@ -286,7 +286,8 @@ static int gemmbf_launch(GemmBfParams p, hipStream_t stream) {
     p.n_col_blocks = (int)ceil_div(p.N, GBF_BN);
     const int n_m = p.M / GBF_BM;
     dim3 grid((unsigned)(ceil_div(p.n_col_blocks, 8) * 8 * n_m), 1, (unsigned)p.batch);
-    static const int dbg = getenv("RVC_GBF_DBG") ? atoi(getenv("RVC_GBF_DBG")) : 0;
+#ifdef RVC_ABLATE
+    static const int dbg = knob("RVC_GBF_DBG", 0);
     if (dbg && p.x_mode == 1) {
         auto go = [&](auto k) { (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, GBF_LDS); hipLaunchKernelGGL(k, grid, dim3(GBF_NTH), GBF_LDS, stream, p); };
         switch (dbg) {
@@ -301,6 +302,7 @@ static int gemmbf_launch(GemmBfParams p, hipStream_t stream) {
         RVC_LAUNCH_CHECK();
         return 0;
     }
+#endif
     if (p.x_mode == 0) hipLaunchKernelGGL(gemmbf_kernel<0>, grid, dim3(GBF_NTH), GBF_LDS, stream, p);
     else hipLaunchKernelGGL(gemmbf_kernel<1>, grid, dim3(GBF_NTH), GBF_LDS, stream, p);
     RVC_LAUNCH_CHECK();

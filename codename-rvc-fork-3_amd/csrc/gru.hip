@@ -323,16 +323,18 @@ extern "C" int rvc_bigru_forward(const float *gi_dev, const float *whhT_dev, con
     if (batch * 2 * GRU_NWG > 128) return fail("rvc_bigru_forward: batch %d needs %d co-resident workgroups (max 128)", batch, batch * 2 * GRU_NWG);
     RVC_HIP(hipMemsetAsync(workspace_dev, 0, need, (hipStream_t)stream));  // tags must start below epoch 1 on every call; status = 0
     int *status = (int *)((char *)workspace_dev + bigru_xchg_bytes(batch));
-    static const int dbg = getenv("RVC_GRU_DBG") ? atoi(getenv("RVC_GRU_DBG")) : 0;     // ablations, tools/bench_gru.py
+    static const int dbg = knob("RVC_GRU_DBG", 0);     // ablations, tools/bench_gru.py
     const unsigned spin = g_spin_limit.load(std::memory_order_relaxed);
     hipStream_t st = (hipStream_t)stream;
     u64 *xg = (u64 *)workspace_dev;
     const int Ti = (int)n_steps;
     switch (dbg) {
+#ifdef RVC_ABLATE
         case 1: bigru_x_launch<GRU_NWG, 1>(gi_dev, whhT_dev, bhh_dev, out_dev, xg, status, Ti, batch, spin, st); break;
         case 2: bigru_x_launch<GRU_NWG, 2>(gi_dev, whhT_dev, bhh_dev, out_dev, xg, status, Ti, batch, spin, st); break;
         case 4: bigru_x_launch<GRU_NWG, 4>(gi_dev, whhT_dev, bhh_dev, out_dev, xg, status, Ti, batch, spin, st); break;
         case 5: bigru_x_launch<GRU_NWG, 5>(gi_dev, whhT_dev, bhh_dev, out_dev, xg, status, Ti, batch, spin, st); break;
+#endif
         default: bigru_x_launch<GRU_NWG, 0>(gi_dev, whhT_dev, bhh_dev, out_dev, xg, status, Ti, batch, spin, st); break;
     }
     RVC_LAUNCH_CHECK();

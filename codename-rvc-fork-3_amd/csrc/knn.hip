@@ -543,7 +543,7 @@ struct KnnPlan {
 };
 
 static KnnPlan knn_plan(int64_t n_rows, int64_t n_queries, int dim = 768) {
-    static const int force_batch = getenv("RVC_KNN_NO_STREAM") ? atoi(getenv("RVC_KNN_NO_STREAM")) : 0;
+    static const int force_batch = knob("RVC_KNN_NO_STREAM", 0);
     KnnPlan p;
     p.stream = n_queries <= KNN_STREAM_MAX_Q && !force_batch;
     p.q_tile = p.stream ? KNS_BQ : KNN_BQ;
@@ -551,8 +551,8 @@ static KnnPlan knn_plan(int64_t n_rows, int64_t n_queries, int dim = 768) {
     const int64_t q_tiles = ceil_div(n_queries, p.q_tile);
     // batch kernel: >= 6 blocks per CU, stripes of >= 4 row tiles; streaming kernel: 2 blocks per CU (longer stripes
     // amortise the per-block prologue and merge: 4.0 TB/s vs 3.4 TB/s at 8 per CU on a 2 M-row index)
-    static const int bpc_env = getenv("RVC_KNN_STREAM_BPC") ? atoi(getenv("RVC_KNN_STREAM_BPC")) : 0;
-    static const int old_stream = getenv("RVC_KNN_STREAM_OLD") ? atoi(getenv("RVC_KNN_STREAM_OLD")) : 0;
+    static const int bpc_env = knob("RVC_KNN_STREAM_BPC", 0);
+    static const int old_stream = knob("RVC_KNN_STREAM_OLD", 0);
     p.direct = p.stream && !old_stream && dim >= 256 && dim % 32 == 0;
     // direct form: the query tile's LDS footprint decides how many blocks share a CU (1 at dim 768, 4 at dim 256)
     int bpc = p.direct ? (int)((size_t)(160 * 1024) / knd_lds_bytes(dim)) : 2;
@@ -615,7 +615,7 @@ extern "C" int rvc_knn_search(const float *index_dev, const void *aux_dev, int64
     float *part_d = (float *)workspace_dev;
     int *part_id = (int *)((char *)workspace_dev + align_up((size_t)n_queries * n_slots * KNN_K * sizeof(float), 256));
     dim3 grid((unsigned)ceil_div(n_queries, plan.q_tile), (unsigned)plan.stripes);
-    static const int pf = getenv("RVC_KNN_STREAM_PF") ? atoi(getenv("RVC_KNN_STREAM_PF")) : 3;
+    static const int pf = knob("RVC_KNN_STREAM_PF", 3);
     if (plan.direct) {
         const size_t lds = knd_lds_bytes(dim);
         static std::mutex lds_mutex;               // several host threads search concurrently (convert_batch)
@@ -628,7 +628,7 @@ extern "C" int rvc_knn_search(const float *index_dev, const void *aux_dev, int64
                 lds_set = lds;
             }
         }
-        static const int waves_env = getenv("RVC_KNN_DIRECT_WAVES") ? atoi(getenv("RVC_KNN_DIRECT_WAVES")) : 0;
+        static const int waves_env = knob("RVC_KNN_DIRECT_WAVES", 0);
         if (waves_env == 84) {   // RVC_KNN_DIRECT_WAVES=84: 4 line groups in flight (+1.5 % on a 2 M-row index)
             static std::once_flag set84;
             std::call_once(set84, [lds] {

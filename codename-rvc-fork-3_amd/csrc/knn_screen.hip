@@ -674,16 +674,11 @@ struct ScreenPlan {
     size_t qh, qstat, mins, thr, cnt, cand, total;   // workspace offsets
 };
 
-static int env_i(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 static ScreenPlan screen_plan(int64_t n_rows, int64_t n_queries, int dim) {
     ScreenPlan s;
     // measured at 1599 x 100 k / 2 M (ms per search): WM 2 BK 64 0.541 / 8.77; WM 2 BK 32 0.557; WM 1 BK 32 (two blocks per CU)
     // 0.607 / 11.9; WM 1 BK 64 spills (1.13).  Both operands stream at ~11 B/clk/CU: the large tile's lower traffic per flop wins.
-    static const int tile_env = env_i("RVC_KNN_TILE", 0);      // 264 = WM 2 / BK 64 (default), 132 = WM 1 / BK 32
+    static const int tile_env = knob("RVC_KNN_TILE", 0);      // 264 = WM 2 / BK 64 (default), 132 = WM 1 / BK 32
     const int tile = tile_env == 132 ? 132 : 264;
     s.wm = tile / 100;
     s.bk = tile % 100;
@@ -692,7 +687,7 @@ static ScreenPlan screen_plan(int64_t n_rows, int64_t n_queries, int dim) {
     s.n_tiles = (int)ceil_div(n_rows, s.bm);
     s.n_qtiles = (int)ceil_div(n_queries, KS_BN);
     // sample size ~ sqrt(2560 N) rows balances the sample pass against the exact re-scoring of ~8 N / sample survivors
-    static const int sample_env = env_i("RVC_KNN_SAMPLE_TILES", 0);
+    static const int sample_env = knob("RVC_KNN_SAMPLE_TILES", 0);
     int64_t want = 1;
     while (want * want * s.bm * s.bm < 2560 * n_rows) ++want;
     // One block per (sampled tile, query tile), one block per CU: between one and two rounds of the 256 CUs the second round
@@ -705,14 +700,14 @@ static ScreenPlan screen_plan(int64_t n_rows, int64_t n_queries, int dim) {
     if (want > s.n_tiles) want = s.n_tiles;
     s.sample_step = s.n_tiles / (int)want;
     s.sample_tiles = (int)want;
-    static const int bpc_env = env_i("RVC_KNN_SCREEN_BLOCKS", 0);
+    static const int bpc_env = knob("RVC_KNN_SCREEN_BLOCKS", 0);
     // one (row tile, query tile) pair per block up to 16384 blocks: 1599 x 100 k 0.459 -> 0.444 ms, 1599 x 2 M 8.62 -> 7.54 ms
     // against 1024 longer blocks (finer blocks balance the XCDs and hide each other's prologue)
     const int64_t blocks_want = bpc_env ? bpc_env : 16384;
     s.tiles_per_block = (int)ceil_div((int64_t)s.n_tiles * s.n_qtiles, blocks_want);
     if (s.tiles_per_block < 1) s.tiles_per_block = 1;
     s.n_stripes = (int)ceil_div(s.n_tiles, s.tiles_per_block);
-    static const int cap_env = env_i("RVC_KNN_CAP", 0);
+    static const int cap_env = knob("RVC_KNN_CAP", 0);
     s.cap = cap_env ? cap_env : 8192;   // candidates per query; survivors are a few dozen on spread-out data, thousands when
                                         // thousands of rows are equidistant from a query to within the fp16 error bound
     size_t off = 0;
@@ -806,12 +801,13 @@ int knn_screened_search(const float *index, const void *aux_dev, int64_t n_rows,
 #define RVC_SCREEN(AP, W, K)                                                                                               \
     hipLaunchKernelGGL((knn_screen_kernel<AP, W, K>), dim3(nblocks), dim3((ScreenTile<W, K>::THREADS)),                   \
                        (ScreenTile<W, K>::LDS_BYTES), stream, p)
-        static const int glds_env = env_i("RVC_KNN_GLDS", 0);   // 1: the LDS-DMA staged variant (measured equal: 0.555 vs 0.545 ms)
+        static const int glds_env = knob("RVC_KNN_GLDS", 0);   // 1: the LDS-DMA staged variant (measured equal: 0.555 vs 0.545 ms)
         if (s.wm == 2 && s.bk == 64 && glds_env) {
             if (append) hipLaunchKernelGGL(knn_screen_glds_kernel<true>, dim3(nblocks), dim3(512), (ScreenTile<2, 64>::LDS_BYTES), stream, p);
             else hipLaunchKernelGGL(knn_screen_glds_kernel<false>, dim3(nblocks), dim3(512), (ScreenTile<2, 64>::LDS_BYTES), stream, p);
         } else if (s.wm == 2 && s.bk == 64) {
-            static const int dbg = env_i("RVC_KNN_DBG", 0);
+#ifdef RVC_ABLATE
+            static const int dbg = knob("RVC_KNN_DBG", 0);
             if (append && dbg) {
 #define RVC_SCREEN_DBG(D) hipLaunchKernelGGL((knn_screen_kernel<true, 2, 64, D>), dim3(nblocks), dim3(512), (ScreenTile<2, 64>::LDS_BYTES), stream, p)
                 auto res = [](const void *fn) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ScreenTile<2, 64>::LDS_BYTES); };
@@ -822,7 +818,9 @@ int knn_screened_search(const float *index, const void *aux_dev, int64_t n_rows,
                     default: RVC_SCREEN(true, 2, 64); break;
                 }
 #undef RVC_SCREEN_DBG
-            } else if (append) RVC_SCREEN(true, 2, 64); else RVC_SCREEN(false, 2, 64);
+            } else
+#endif
+            if (append) RVC_SCREEN(true, 2, 64); else RVC_SCREEN(false, 2, 64);
         }
         else { if (append) RVC_SCREEN(true, 1, 32); else RVC_SCREEN(false, 1, 32); }
 #undef RVC_SCREEN

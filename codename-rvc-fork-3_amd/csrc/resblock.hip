@@ -252,10 +252,10 @@ static int launch_fused(const float *x, const float *w1, const float *b1, const 
 }
 
 bool resblock_layer_supported(int c, int k) {
-    static const int off = getenv("RVC_NO_FUSED_RESBLOCK") ? atoi(getenv("RVC_NO_FUSED_RESBLOCK")) : 0;
+    static const int off = knob("RVC_NO_FUSED_RESBLOCK", 0);
     // measured on MI355X (profiles/r01_decoder_kernels.txt): fused beats two launches for every k at C = 32 (238 vs 2 x 187 us at
     // k = 3, 453 vs 2 x 272 at k = 7, 676 vs 2 x 356 at k = 11); at C = 64 the wider unfused tiles win (k = 3: 464 vs 2 x 211 us)
-    static const int c64 = getenv("RVC_FUSED_C64") ? atoi(getenv("RVC_FUSED_C64")) : 0;
+    static const int c64 = knob("RVC_FUSED_C64", 0);
     // Against the fast (Winograd) form of the unfused convs (wino.hip) the fusion only still pays at k = 3: 238 us vs 128 + 139;
     // k = 7: 453 vs 181 + 186, k = 11: 676 vs 214 + 231.
     const bool fast = wino_enabled();
@@ -268,7 +268,7 @@ int launch_resblock_layer(const float *x, const float *w1, const float *b1, cons
     if (x == y) return fail("resblock_layer: in-place operation is not supported");
     if (dil < 1 || dil > 5) return fail("resblock_layer: dilation %d out of range", dil);
     if ((int64_t)c * L >= ((int64_t)1 << 30)) return fail("resblock_layer: a %d x %lld slab exceeds the 4 GB the kernel addresses", c, (long long)L);
-    static const int wide64 = getenv("RVC_FUSED_C64_WIDE") ? atoi(getenv("RVC_FUSED_C64_WIDE")) : 0;
+    static const int wide64 = knob("RVC_FUSED_C64_WIDE", 0);
 #define RVC_FUSED_CASE(KW, CC, NN, WMM) if (k == KW && c == CC) return launch_fused<KW, CC, NN, WMM>(x, w1, b1, w2, b2, accin, y, batch, L, dil, slope, out_scale, stream)
     RVC_FUSED_CASE(3, 32, 128, 1); RVC_FUSED_CASE(7, 32, 128, 1); RVC_FUSED_CASE(11, 32, 128, 1);
     if (wide64) { RVC_FUSED_CASE(3, 64, 128, 1); RVC_FUSED_CASE(7, 64, 128, 1); RVC_FUSED_CASE(11, 64, 128, 1); }

@@ -500,8 +500,9 @@ template <int KW>
 static int wino_launch_kw(const WinoParams &p, hipStream_t stream) {
     constexpr int CIC = 8;
     if (p.c_in % CIC) return fail("wino conv: c_in %d is not a multiple of %d", p.c_in, CIC);
+#ifdef RVC_ABLATE
     if (KW == 11 && p.c_out % 64 == 0) {   // ablations (wrong results): where does the time go (tools/ablate_wino.sh)
-        static const int dbg = getenv("RVC_WINO_DBG") ? atoi(getenv("RVC_WINO_DBG")) : 0;
+        static const int dbg = knob("RVC_WINO_DBG", 0);
         switch (dbg) {
             case 1: return wino_launch_cfg<11, 2, 2, 8, 1>(p, stream);
             case 2: return wino_launch_cfg<11, 2, 2, 8, 2>(p, stream);
@@ -513,10 +514,11 @@ static int wino_launch_kw(const WinoParams &p, hipStream_t stream) {
             default: break;
         }
     }
+#endif
     // taps per group: F(4,4) for the kernel sizes in RVC_WINO_R4's mask (1: 7 taps, 2: 11 taps; default both).  Measured
     // against F(4,3) (tools/bench_conv.py): 7 taps 0.86-0.93 of the time on every shape (530 -> 463 us at C = 128),
     // 11 taps 0.94-0.98 (678 -> 641 us).
-    static const int r4_mask = getenv("RVC_WINO_R4") ? atoi(getenv("RVC_WINO_R4")) : 3;
+    static const int r4_mask = knob("RVC_WINO_R4", 3);
     if constexpr (KW == 7 || KW == 11) {
         if (r4_mask & (KW == 7 ? 1 : 2)) {
             if (p.u_bf16) {
@@ -527,13 +529,19 @@ static int wino_launch_kw(const WinoParams &p, hipStream_t stream) {
             if (p.c_out % 32 == 0) return wino_launch_cfg<KW, 1, 4, CIC, 0, false, 4>(p, stream);
         }
     }
-    if (p.u_bf16) {
-        if (p.c_out % 64 == 0) return wino_launch_cfg<KW, 2, 2, CIC, 0, true>(p, stream);
-        if (p.c_out % 32 == 0) return wino_launch_cfg<KW, 1, 4, CIC, 0, true>(p, stream);
+#ifndef RVC_ABLATE
+    if constexpr (KW != 3) return fail("wino conv: c_out %d is not a multiple of 32", p.c_out);   // F(4,3) on 7 / 11 taps: ablation build only
+    else
+#endif
+    {
+        if (p.u_bf16) {
+            if (p.c_out % 64 == 0) return wino_launch_cfg<KW, 2, 2, CIC, 0, true>(p, stream);
+            if (p.c_out % 32 == 0) return wino_launch_cfg<KW, 1, 4, CIC, 0, true>(p, stream);
+        }
+        if (p.c_out % 64 == 0) return wino_launch_cfg<KW, 2, 2, CIC>(p, stream);
+        if (p.c_out % 32 == 0) return wino_launch_cfg<KW, 1, 4, CIC>(p, stream);
+        return fail("wino conv: c_out %d is not a multiple of 32", p.c_out);
     }
-    if (p.c_out % 64 == 0) return wino_launch_cfg<KW, 2, 2, CIC>(p, stream);
-    if (p.c_out % 32 == 0) return wino_launch_cfg<KW, 1, 4, CIC>(p, stream);
-    return fail("wino conv: c_out %d is not a multiple of 32", p.c_out);
 }
 
 // the staging streams address one batch item's input and the weight slab with 32-bit byte offsets

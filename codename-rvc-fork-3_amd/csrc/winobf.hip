@@ -584,7 +584,7 @@ static int winobf_launch(WinoBfParams p, hipStream_t stream) {
 // measured (profiles/r03_convbf_shapes.txt) it wins 12-17 % on the 7-tap layers and 7 % on 256-channel 11-tap ones, and is
 // level (+5 .. -3 %) on 128-channel 11-tap ones, which keep 64 x 128.  RVC_WBF_BM128=0 forces 64 x 128 everywhere.
 int winobf_block_rows(int c_out, int k) {
-    static const int wide = getenv("RVC_WBF_BM128") ? atoi(getenv("RVC_WBF_BM128")) : 1;
+    static const int wide = knob("RVC_WBF_BM128", 1);
     if (!wide || c_out % 128) return 64;
     return (k == 7 || c_out >= 256 || wide == 2) ? 128 : 64;
 }
@@ -608,8 +608,9 @@ int launch_winobf_conv(const float *x, const void *u, const float *bias, const f
     WinoBfParams p;
     p.x = x; p.u = u; p.bias = bias; p.res = res; p.accin = accin; p.y = y;
     p.c_in = c_in; p.c_out = c_out; p.L = L; p.dil = dil; p.slope = slope; p.out_scale = out_scale; p.batch = batch;
+#ifdef RVC_ABLATE
     if (k == 11 && winobf_block_rows(c_out, k) == 64) {   // ablations (wrong results): where does the time go
-        static const int dbg = getenv("RVC_WBF_DBG") ? atoi(getenv("RVC_WBF_DBG")) : 0;
+        static const int dbg = knob("RVC_WBF_DBG", 0);
         switch (dbg) {
             case 1: return winobf_launch<11, 1>(p, stream);
             case 2: return winobf_launch<11, 2>(p, stream);
@@ -627,6 +628,7 @@ int launch_winobf_conv(const float *x, const void *u, const float *bias, const f
             default: break;
         }
     }
+#endif
     if (winobf_block_rows(c_out, k) == 128) return k == 7 ? winobf_launch<7, 0, 128, 64>(p, stream) : winobf_launch<11, 0, 128, 64>(p, stream);
     return k == 7 ? winobf_launch<7>(p, stream) : winobf_launch<11>(p, stream);
 }

@@ -16,6 +16,11 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "librvc_amd.so")
+# The ablation build (same sources with -DRVC_ABLATE: the RVC_* tuning switches and the kernels that leave work out) is only
+# ever loaded when RVC_AMD_LIB names it -- tools/ablate_*.sh and the F(4,3) test's child process do.
+if os.environ.get("RVC_AMD_LIB"):
+    LIB_PATH = os.path.abspath(os.environ["RVC_AMD_LIB"])
+    print(f"[rvc_amd] RVC_AMD_LIB: loading {LIB_PATH} instead of the product library", flush=True)
 
 
 class NativeError(RuntimeError):

@@ -178,7 +178,10 @@ def test_conv1d_winograd_f43_groups_still_pass():
     import sys
     if os.environ.get("RVC_WINO_R4") == "0":
         pytest.skip("already the child")
-    env = dict(os.environ, RVC_WINO_R4="0")
+    import __graft_entry__ as G
+    if not os.path.isfile(G.LIB_ABLATE):
+        pytest.skip("ablation library not built (the F(4,3) form of the 7- / 11-tap layers exists only there)")
+    env = dict(os.environ, RVC_WINO_R4="0", RVC_AMD_LIB=G.LIB_ABLATE)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "test_conv1d_winograd_matches_float64",
                         os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -4,6 +4,7 @@ prints the main-pass-dominated search time.  Results are wrong under a non-zero 
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "codename-rvc-fork-3_amd")]
+os.environ.setdefault("RVC_AMD_LIB", os.path.join(ROOT, "codename-rvc-fork-3_amd", "rvc_amd", "_lib", "librvc_amd_ablate.so"))   # RVC_KNN_DBG exists only there
 import torch
 from rvc_amd import _native
 dev = "cuda:0"

@@ -1,4 +1,6 @@
 #!/bin/bash
+# the RVC_* switches below exist only in the ablation build of the library (-DRVC_ABLATE, __graft_entry__.build_ablate())
+export RVC_AMD_LIB=${RVC_AMD_LIB:-$(cd "$(dirname "$0")/.." && pwd)/codename-rvc-fork-3_amd/rvc_amd/_lib/librvc_amd_ablate.so}
 # shader clock during the kNN main pass under each ablation: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / kernel duration
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 export N=${N:-2000000}

@@ -1,4 +1,6 @@
 #!/bin/bash
+# the RVC_* switches below exist only in the ablation build of the library (-DRVC_ABLATE, __graft_entry__.build_ablate())
+export RVC_AMD_LIB=${RVC_AMD_LIB:-$(cd "$(dirname "$0")/.." && pwd)/codename-rvc-fork-3_amd/rvc_amd/_lib/librvc_amd_ablate.so}
 # effective clock + matrix-pipe occupancy of the Winograd conv and its ablations (RVC_WINO_DBG), C=128 K=11
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 export BENCH_C=${BENCH_C:-128} BENCH_K=11
