@@ -124,6 +124,11 @@ gemmbf_kernel(const GemmBfParams p) {
         if constexpr (XMODE == 0) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(lx_src + 4 * e);
             xv[4 * e] = v.x; xv[4 * e + 1] = v.y; xv[4 * e + 2] = v.z; xv[4 * e + 3] = v.w;
+        } else if (p.ldx == 1) {
+            // one input channel: the step's 16 pseudo-channels are consecutive samples; the taps beyond k carry zero weights, so
+            // the last columns' tail is clamped into x instead of being read past its end
+            const int64_t at = (lx_src - x) + e;
+            xv[e] = x[at < p.l_in ? at : p.l_in - 1];
         } else {
             xv[e] = lx_src[(int64_t)e * p.ldx];
         }
@@ -337,7 +342,9 @@ static void gemmbf_pack_rows(const float *w, int M, int K, std::vector<uint16_t>
 using namespace rvc;
 
 extern "C" int rvc_gemm_bf16x3_weight_bytes(int m, int k, size_t *bytes) {
-    if (k > 0 && k < 16) k = 16;     // a single-input-channel conv of <= 16 taps (HuBERT's first layer): one zero-padded k16 step
+    // k < 16 is ONLY the single-input-channel conv of <= 16 taps (HuBERT's first layer), packed as one zero-padded k16 step;
+    // rvc_gemm_bf16x3_pack_weight rejects any other use of a short k
+    if (k > 0 && k < 16) k = 16;
     if (!bytes || m <= 0 || k <= 0 || m % GBF_BM || k % 16) return fail("rvc_gemm_bf16x3_weight_bytes: m must be a multiple of 128, k of 16");
     *bytes = (size_t)m * k * 6;
     return 0;
@@ -355,6 +362,7 @@ extern "C" int rvc_gemm_bf16x3_pack_weight(const float *w_host, int m, int k_tot
             for (int t = 0; t < conv_taps; ++t) rows[(size_t)r * 16 + t] = w_host[(size_t)r * conv_taps + t];
         std::vector<uint16_t> packed1;
         gemmbf_pack_rows(rows.data(), m, 16, &packed1);
+        if (packed1.size() * sizeof(uint16_t) != bytes) return fail("rvc_gemm_bf16x3_pack_weight: internal size mismatch");
         hipError_t e1 = hipMemcpyAsync(a_dev, packed1.data(), bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
         if (e1 == hipSuccess) e1 = hipStreamSynchronize((hipStream_t)stream);
         if (e1 != hipSuccess) return fail("rvc_gemm_bf16x3_pack_weight: %s", hipGetErrorString(e1));
@@ -369,8 +377,10 @@ extern "C" int rvc_gemm_bf16x3_pack_weight(const float *w_host, int m, int k_tot
                 for (int t = 0; t < conv_taps; ++t) rows[(size_t)r * k_total + (size_t)t * c_in + ci] = w_host[((size_t)r * c_in + ci) * conv_taps + t];
         w = rows.data();
     }
+    if (k_total % 16) return fail("rvc_gemm_bf16x3_pack_weight: k %d is not a multiple of 16 (a short k is the one-input-channel conv only: conv_taps == k_total)", k_total);
     std::vector<uint16_t> packed;
     gemmbf_pack_rows(w, m, k_total, &packed);
+    if (packed.size() * sizeof(uint16_t) != bytes) return fail("rvc_gemm_bf16x3_pack_weight: internal size mismatch");
     hipError_t e = hipMemcpyAsync(a_dev, packed.data(), bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return fail("rvc_gemm_bf16x3_pack_weight: %s", hipGetErrorString(e));
@@ -396,7 +406,7 @@ extern "C" int rvc_conv1d_bf16x3(const float *x_dev, const void *a_dev, const fl
     if (!x_dev || !a_dev || !y_dev) return fail("rvc_conv1d_bf16x3: null pointer");
     const bool one_channel = c_in == 1;   // X[k][n] = x[n * stride + k], k < 16: the 16 "channels" are 16 consecutive samples (row pitch 1)
     if (one_channel && (k > 16 || padding != 0 || batch != 1))
-        return fail("rvc_conv1d_bf16x3: a single input channel takes <= 16 taps, no padding, batch 1 (x followed by 16 - k readable floats)");
+        return fail("rvc_conv1d_bf16x3: a single input channel takes <= 16 taps, no padding, batch 1");
     if (c_out % GBF_BM || (!one_channel && c_in % 16) || k < 1 || stride < 1 || padding < 0) return fail("rvc_conv1d_bf16x3: c_out must be a multiple of 128, c_in of 16");
     if ((int64_t)c_out * c_in * k * 6 >= ((int64_t)1 << 31)) return fail("rvc_conv1d_bf16x3: weight slab exceeds 2 GiB");
     if (act < 0 || act > 1) return fail("rvc_conv1d_bf16x3: act must be 0 (none) or 1 (gelu)");

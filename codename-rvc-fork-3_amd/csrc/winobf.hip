@@ -221,6 +221,7 @@ winobf_conv_kernel(const WinoBfParams p) {
             for (int j = 0; j < NJ; ++j) xr[cp * NJ + j] = wbf_f32x2{wbf_buf_load(xrs, goff[j], s0), wbf_buf_load(xrs, goff[j], s0 + L4)};
         }
     };
+    static_assert(NJ <= 2, "the zero-padding mask below holds one keep word for j = 0 and one for j = 1");
     const unsigned keep0 = (!edge || (inb & 1)) ? 0xffffffffu : 0u, keep1 = (!edge || (inb & 2)) ? 0xffffffffu : 0u;   // conv zero padding
     auto store_x1 = [&](int c, int h, int cp) __attribute__((always_inline)) {   // one channel pair of the half
         wbf_f32x2 *const dst = xs + (c & 1) * XRAW + (h * HP + cp) * 4 * XTS;

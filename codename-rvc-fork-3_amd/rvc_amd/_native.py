@@ -606,8 +606,6 @@ def conv1d_bf16x3(x: torch.Tensor, a_packed: torch.Tensor, bias, c_out: int, k: 
     x = _dev_f32(x, "x")
     b, c_in, l_in = x.shape
     l_out = (l_in + 2 * padding - k) // stride + 1
-    if c_in == 1:   # single input channel (HuBERT's first layer): the kernel reads 16 samples per column, the last ones past the end
-        x = torch.nn.functional.pad(x, (0, 16))
     y = torch.empty((b, c_out, l_out), dtype=torch.float32, device=x.device)
     _check(_lib.rvc_conv1d_bf16x3(x.data_ptr(), a_packed.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(), b,
                                   c_in, c_out, l_in, k, stride, padding, {"none": 0, "gelu": 1}[act], _stream()), "rvc_conv1d_bf16x3")

@@ -170,6 +170,8 @@ class VoiceConverter:
             # per-utterance stream synchronise, so the stream never drains between utterances.
             # (the page-locked buffers belong to the stream, not to the call: allocating them costs milliseconds)
             slots = self._batch_slots.setdefault(tid, [dict(inp=None, out=None, up=None, done=None, idx=None, n=0) for _ in range(2)])
+            for slot in slots:
+                slot["idx"] = None   # a previous call that raised mid-batch may have left a result pending: it is not this call's
 
             def finish(slot):
                 if slot["idx"] is not None:

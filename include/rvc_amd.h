@@ -359,8 +359,8 @@ int rvc_conv1d_winobf_forward(const float *x_dev, const void *u_dev, const float
  * (measured on MI355X, profiles/r03_mfma_cohabitation.txt), so this one never shares; results agree with float64 as
  * closely as an fp32 GEMM does.  act: 0 none, 1 GELU (erf form, what torch.nn.functional.gelu computes).
  * Weights: rvc_gemm_bf16x3_weight_bytes() bytes filled by rvc_gemm_bf16x3_pack_weight from the [out][in] (linear, conv_taps = 1) or
- * [C_out][C_in][taps] (conv, conv_taps = taps, k_total = taps * C_in) host tensor.  out / C_out a multiple of 128, in / C_in of 16. * rvc_conv1d_bf16x3 also takes c_in = 1 with k <= 16, no padding, batch 1 (HuBERT's first layer: Conv1d(1, 512, 10, stride 5)); x must
- * then be followed by 16 - k readable floats.  rvc_gemm_bf16x3_weight_bytes / _pack_weight pad such a weight to one k16 step.
+ * [C_out][C_in][taps] (conv, conv_taps = taps, k_total = taps * C_in) host tensor.  out / C_out a multiple of 128, in / C_in of 16. * rvc_conv1d_bf16x3 also takes c_in = 1 with k <= 16, no padding, batch 1 (HuBERT's first layer: Conv1d(1, 512, 10, stride 5)); the
+ * kernel reads nothing beyond x[l_in - 1].  rvc_gemm_bf16x3_weight_bytes / _pack_weight pad such a weight to one k16 step.
  */
 int rvc_gemm_bf16x3_weight_bytes(int m, int k_total, size_t *bytes);
 int rvc_gemm_bf16x3_pack_weight(const float *w_host, int m, int k_total, int conv_taps, void *a_dev, void *stream);
