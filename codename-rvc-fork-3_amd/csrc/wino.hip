@@ -216,14 +216,33 @@ wino_conv_kernel(const WinoParams p) {
                 for (int j = 0; j < NJ; ++j) dst[cp * 4 * XTS + loff[j]] = lrelu2(xr[cp * NJ + j], slope);
         }
     };
+    // DBG & 64 (ablation build; correct results): the taps by plain loads into registers and ds_write instead of LDS-DMA
+    f32x4 ureg[(DBG & 64) ? UPW : 1];
     auto dma_u = [&](int buf, int c) __attribute__((always_inline)) {
         const int s0 = (c * CP * c_out + m0) * UPAIR;     // byte offset of the chunk's first weight row, this block's channels
         char *dst = reinterpret_cast<char *>(us + buf * UTOT);
 #pragma unroll
         for (int i = 0; i < UPW; ++i) {
             const int n = wave + NW * i;
-            if (n < UINSTR) __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, (wino_lptr_t)(dst + n * 1024), 16, (int)woff[i], s0, 0, 0);
+            if constexpr (DBG & 64) {
+                if (n < UINSTR) ureg[i] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(p.u) + s0 + woff[i]);
+            } else {
+                if (n < UINSTR) __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, (wino_lptr_t)(dst + n * 1024), 16, (int)woff[i], s0, 0, 0);
+            }
         }
+    };
+    auto store_u = [&](int buf) __attribute__((always_inline)) {
+        if constexpr (DBG & 64) {
+            char *dst = reinterpret_cast<char *>(us + buf * UTOT);
+#pragma unroll
+            for (int i = 0; i < UPW; ++i) {
+                const int n = wave + NW * i;
+                if (n < UINSTR) *reinterpret_cast<f32x4 *>(dst + n * 1024 + 16 * lane) = ureg[i];
+            }
+        }
+    };
+    auto block_barrier = [&]() __attribute__((always_inline)) {
+        if constexpr (DBG & 128) __syncthreads(); else lds_barrier();
     };
 
     f32x16 acc[NP];
@@ -235,9 +254,10 @@ wino_conv_kernel(const WinoParams p) {
     load_x(0);
     dma_u(0, 0);
     store_x(0);
+    store_u(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (n_chunks > 1) load_x(1);
-    lds_barrier();
+    block_barrier();
     const int col = wn * 32 + l31;                       // this lane's tile column inside the block
     for (int c = 0; c < n_chunks; ++c) {
         const int buf = c & 1;
@@ -332,15 +352,20 @@ wino_conv_kernel(const WinoParams p) {
             for (int q = 0; q < NP; ++q) acc[q] = mfma32(aq[q].x, xq[q].x, acc[q]);
 #pragma unroll
             for (int q = 0; q < NP; ++q) acc[q] = mfma32(aq[q].y, xq[q].y, acc[q]);
+            if constexpr (DBG & 256) {   // ablation: nothing may overwrite a matrix instruction's source registers for 80 cycles
+#pragma unroll
+                for (int z = 0; z < 5; ++z) asm volatile("s_nop 15");
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (c + 1 < n_chunks) {
             if (!(DBG & 4)) {
                 store_x(buf ^ 1);                                   // chunk c + 1's rows, loaded a whole chunk ago
+                store_u(buf ^ 1);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's DMA pieces of chunk c + 1 have landed
                 if (c + 2 < n_chunks) load_x(c + 2);
             }
-            if (!(DBG & 8)) lds_barrier();   // chunk c + 2's rows stay in flight across it
+            if (!(DBG & 8)) block_barrier();   // chunk c + 2's rows stay in flight across it
         }
     }
 
@@ -529,7 +554,18 @@ static int wino_launch_kw(const WinoParams &p, hipStream_t stream) {
             if (p.c_out % 32 == 0) return wino_launch_cfg<KW, 1, 4, CIC, 0, false, 4>(p, stream);
         }
     }
-#ifndef RVC_ABLATE
+#ifdef RVC_ABLATE
+    if constexpr (KW == 3) {   // bisection of profiles/r03_mfma_cohabitation.txt (correct results): 64 no LDS-DMA, 128 __syncthreads, 256 s_nop behind the matrix instructions
+        static const int fix = knob("RVC_WINO_FIX", 0);
+        if (p.c_out % 64 == 0 && !p.u_bf16) switch (fix) {
+            case 64: return wino_launch_cfg<3, 2, 2, CIC, 64>(p, stream);
+            case 128: return wino_launch_cfg<3, 2, 2, CIC, 128>(p, stream);
+            case 192: return wino_launch_cfg<3, 2, 2, CIC, 192>(p, stream);
+            case 256: return wino_launch_cfg<3, 2, 2, CIC, 256>(p, stream);
+            default: break;
+        }
+    }
+#else
     if constexpr (KW != 3) return fail("wino conv: c_out %d is not a multiple of 32", p.c_out);   // F(4,3) on 7 / 11 taps: ablation build only
     else
 #endif

@@ -149,7 +149,20 @@ def test_baseline_config_full_length_vs_oracle(S, hubert, sds, cfg):
     assert info["coarse_flips"] <= 0.002 * info["n_frames"], info
 
 
-@pytest.mark.parametrize("case", ["cfg2", "cfg1", "45s"])
+def _synth_index_device(n_rows, seed=0, n_centres=512, jitter=0.05, dim=768):
+    """synthetic.synth_index's recipe (cluster centres + jitter) drawn on the device, as bench.py does for cfg 5: 2 M rows
+    are 6.1 GB, too slow to draw with NumPy inside a test."""
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    centres = torch.randn(n_centres, dim, device=DEV, generator=g) * 0.35
+    out = torch.empty(n_rows, dim, device=DEV)
+    for s in range(0, n_rows, 1 << 18):
+        e = min(n_rows, s + (1 << 18))
+        which = torch.randint(0, n_centres, (e - s,), device=DEV, generator=g)
+        out[s:e] = centres[which] + jitter * torch.randn(e - s, dim, device=DEV, generator=g)
+    return out
+
+
+@pytest.mark.parametrize("case", ["cfg2", "cfg1", "45s", "cfg4", "cfg5"])
 def test_full_length_plain_peaked_rmvpe(S, hubert, case):
     """The north_star gate with NOTHING conditional: product vs oracle at the benchmarked lengths, each side on its OWN
     f0 contour (no f0_override, no tie certificates on f0), waveform <= 1e-3 RMS, f0 <= 2e-5 relative on EVERY frame.
@@ -162,27 +175,40 @@ def test_full_length_plain_peaked_rmvpe(S, hubert, case):
     above stay tie-aware.  The synthesizer checkpoint uses the smooth pitch embedding (synthetic: smooth_pitch=True): the
     coarse pitch (pipeline.py:401-408) rounds a continuous value, so two contours equal to 1e-6 still round apart at a
     .5 boundary on ~1 frame in 10^4; such frames must be certified rounding near-ties and are counted, every other
-    coarse integer is bit-exact."""
+    coarse integer is bit-exact.
+
+    cfg4 / cfg5 are BASELINE configs 4 and 5 at the length bench.py times them: the MRF vocoder with bf16 weight storage
+    (oracle: fp32 math on the same bf16-valued weights) over the 100 k index, and RefineGAN over the 2 M-row index (drawn on
+    the device as bench.py draws it; the oracle searches a host copy of the same rows)."""
     from oracle import rvc_oracle as O
-    secs, sr, rows, rate, aseed, seed = {"cfg2": (30, 48000, 100_000, 0.75, 0, 1234), "cfg1": (10, 40000, 0, 0.0, 0, 1234),
-                                         "45s": (45, 48000, 0, 0.0, 45, 99)}[case]
+    secs, sr, rows, rate, aseed, seed, voc, bf16 = {
+        "cfg2": (30, 48000, 100_000, 0.75, 0, 1234, "HiFi-GAN", False), "cfg1": (10, 40000, 0, 0.0, 0, 1234, "HiFi-GAN", False),
+        "45s": (45, 48000, 0, 0.0, 45, 99, "HiFi-GAN", False), "cfg4": (30, 48000, 100_000, 0.75, 0, 1234, "MRF HiFi-GAN", True),
+        "cfg5": (30, 48000, 2_000_000, 0.75, 0, 1234, "RefineGAN", False)}[case]
     rm_sd = S.make_rmvpe_state_dict(0, peaked=True)
     hub_sd = S.make_hubert_state_dict(1)
-    cpt = S.make_synth_checkpoint(sr, "HiFi-GAN", seed=0, smooth_pitch=True)
+    cpt = S.make_synth_checkpoint(sr, voc, seed=0, smooth_pitch=True)
     from rvc_amd.infer.infer import VoiceConverter
     vc = VoiceConverter(device=DEV)
+    if bf16:
+        vc.dec_weight_dtype = "bf16"
     vc.load_checkpoint_dict(cpt)
     vc.hubert_model = hubert
     vc.vc.load_rmvpe_state_dict(rm_sd)
-    big = S.synth_index(rows, seed=0) if rows else None
-    if rows:
+    big = None
+    if rows > 200_000:
+        index_dev = _synth_index_device(rows)
+        big = index_dev.cpu().numpy()
+        vc.vc.set_index(index_dev)
+    elif rows:
+        big = S.synth_index(rows, seed=0)
         vc.vc.set_index(big)
     audio = S.synth_audio(16000 * secs, seed=aseed)
     taps = {}
     t0 = time.time()
     torch.manual_seed(seed)
     want = O.pipeline(hub_sd, rm_sd, cpt, audio.copy(), sid=0, pitch=0, big_npy=big, index_rate=rate, protect=0.5, taps=taps,
-                      knn_dtype=np.float32)
+                      knn_dtype=np.float32, **({"dec_bf16": True} if bf16 else {}))
     t_oracle = time.time() - t0
     vc.vc.debug_taps = {}
     got = vc.vc.pipeline(hubert, vc.net_g, 0, audio.copy(), 0, "rmvpe", "", rate, True, 3, 1, "v2", 0.5, 128, False, 1, None,
@@ -255,50 +281,133 @@ def test_45s_two_segments_vs_oracle(S, hubert, sds):
     assert info["coarse_flips"] <= 0.002 * info["n_frames"], info
 
 
-@pytest.mark.parametrize("hint", [1, 2])
-def test_decoder_T3198_stage_by_stage_vs_oracle(S, hint):
-    """The vocoder at the benchmarked shape (T = 3198 -> 1 535 040 samples) with a tap after every stage, under both tile
-    selections of the short first stage (rvc_set_concurrency_hint 1: 128x64 tiles, 2: 128x128).
-    Reference: hifigan_nsf.py:173-207."""
+class _SeededNoise:
+    """The oracle's noise interface (rand / randn in draw order) on a seeded CPU generator: the product side replays the
+    same generator tensor by tensor, so RefineGAN's 24 AdaIN draws (3.8 GB at T = 3198) never sit in one Python list."""
+
+    def __init__(self, seed):
+        self.g = torch.Generator().manual_seed(seed)
+
+    def randn(self, *shape):
+        return torch.randn(*shape, generator=self.g)
+
+    def rand(self, *shape):
+        return torch.rand(*shape, generator=self.g)
+
+
+@pytest.mark.parametrize("case", ["nsf-hint1", "nsf-hint2", "mrf", "mrf-bf16", "refine"])
+def test_decoder_T3198_stage_by_stage_vs_oracle(S, case):
+    """Every vocoder at the benchmarked shape (T = 3198 -> 1 535 040 samples) with a tap on the source signal and after every
+    stage: NSF under both tile selections of the short first stage (rvc_set_concurrency_hint 1: 128x64 tiles, 2: 128x128);
+    MRF (BASELINE cfg 4) with fp32 and with bf16 weight storage -- its 9-harmonic source integrates 1.5 M phase increments
+    with wrap compensation (hifigan_mrf.py:129-175), which the product evaluates in closed form per frame; RefineGAN
+    (cfg 5) with its 24 AdaIN noise tensors drawn stage by stage from a seeded CPU generator (refinegan.py:220-263, 368-405).
+    Reference: hifigan_nsf.py:173-207, hifigan_mrf.py:339-366, refinegan.py:368-405."""
     from oracle import rvc_oracle as O
     from rvc_amd import _native
     from rvc_amd.lib.algorithm.weights import fold_weight_norm
     T = 3198
-    cpt = S.make_synth_checkpoint(48000, "HiFi-GAN", seed=0)
+    voc = {"nsf": "HiFi-GAN", "mrf": "MRF HiFi-GAN", "refine": "RefineGAN"}[case.split("-")[0]]
+    hint = 2 if case.endswith("hint2") else 1
+    bf16 = case.endswith("bf16")
+    cpt = S.make_synth_checkpoint(48000, voc, seed=0)
     w = O.fold_weight_norm(cpt["weight"])
+    if bf16:   # what a bf16 copy of the vocoder holds; the oracle computes in fp32 on the same values (SURVEY 8d)
+        w = {k: (v.float().bfloat16().float() if k.startswith("dec.") else v) for k, v in w.items()}
     rates, ksizes = cpt["config"][12], cpt["config"][14]
+    upp = int(np.prod(rates))
     gen = torch.Generator().manual_seed(17)
     z = torch.randn(1, 192, T, generator=gen)
     g = torch.randn(1, 256, 1, generator=gen)
     t = torch.arange(T) / 100.0
     f0 = (180.0 + 40.0 * torch.sin(2 * np.pi * 0.5 * t)).float().unsqueeze(0)
     f0[:, 500:600] = 0.0                                   # an unvoiced stretch: noise-only source, phase carry restarts
-    src_randn = torch.randn(1, T * 480, 1, generator=gen)
     taps = {}
-    ref = O.decoder_nsf(w, z, f0, g, rates, ksizes, 48000, O.ListNoise([torch.zeros(1, 1, 1), src_randn]), taps=taps).numpy()
-    folded = {k[4:]: v for k, v in fold_weight_norm(cpt["weight"]).items() if k.startswith("dec.")}
-    dec = _native.Decoder("HiFi-GAN", 48000, folded)
+    t0 = time.time()
+    if voc == "HiFi-GAN":
+        src_rand = None
+        src_randn = torch.randn(1, T * upp, 1, generator=gen)
+        ref = O.decoder_nsf(w, z, f0, g, rates, ksizes, 48000, O.ListNoise([torch.zeros(1, 1, 1), src_randn]), taps=taps).numpy()
+        adain_dev = None
+    elif voc == "MRF HiFi-GAN":
+        ref = O.decoder_mrf(w, z, f0, g, rates, ksizes, 48000, _SeededNoise(23), taps=taps).numpy()
+        rep = _SeededNoise(23)
+        src_rand, src_randn = rep.rand(1, 9), rep.randn(1, T * upp, 9)
+        adain_dev = None
+    else:
+        ref = O.decoder_refine(w, z, f0, g, rates, 48000, _SeededNoise(23), taps=taps).numpy()
+        rep = _SeededNoise(23)
+        src_rand, src_randn = rep.rand(1, 1), rep.randn(1, T * upp, 1)
+        shapes, length, ch = [], T, 512
+        for r in rates:
+            length, ch = length * r, ch // 2
+            shapes += [(1, ch, length)] * 6
+        adain_dev = torch.empty(sum(int(np.prod(sh)) for sh in shapes), device=DEV)
+        at = 0
+        for sh in shapes:                                  # the same generator, tensor by tensor, straight into the flat device buffer
+            n = int(np.prod(sh))
+            adain_dev[at:at + n] = rep.randn(*sh).reshape(-1).to(DEV)
+            at += n
+    t_oracle = time.time() - t0
+    folded = {k[4:]: v for k, v in (w if bf16 else fold_weight_norm(cpt["weight"])).items() if k.startswith("dec.")}
+    dec = _native.Decoder(voc, 48000, folded, upsample_rates=rates, upsample_kernel_sizes=ksizes, **({"weight_storage": "bf16"} if bf16 else {}))
     _native.set_concurrency_hint(hint)
+    kw = dict(src_randn=src_randn.to(DEV), src_rand=src_rand.to(DEV) if src_rand is not None else None, adain_randn=adain_dev)
     try:
         chans, length = 512, T
-        for stage in range(-1, 4):
+        for stage in range(-1, len(rates)):
             if stage >= 0:
                 chans, length = chans // 2, length * rates[stage]
-            shape = (1, T * 480) if stage < 0 else (1, chans, length)
+            shape = (1, T * upp) if stage < 0 else (1, chans, length)
             tap = torch.zeros(shape, device=DEV)
             dec.set_tap(stage, tap)
-            out = dec.forward(z.to(DEV), f0.to(DEV), g[:, :, 0].to(DEV), src_randn=src_randn.to(DEV))
+            out = dec.forward(z.to(DEV), f0.to(DEV), g[:, :, 0].to(DEV), **kw)
             torch.cuda.synchronize()
             dec.set_tap(stage, None)
             want = taps["har_source"].reshape(1, -1) if stage < 0 else taps[f"stage{stage}"]
             e = rms(tap.cpu().numpy() - want.numpy())
-            print(f"hint {hint} stage {stage}: rms err {e:.3e} (oracle rms {rms(want.numpy()):.3f})")
-            assert e <= 1e-4 * max(1.0, rms(want.numpy())), (stage, e)
+            print(f"{case} stage {stage}: rms err {e:.3e} (oracle rms {rms(want.numpy()):.3f})")
+            assert e <= 1e-4 * max(1.0, rms(want.numpy())), (case, stage, e)
     finally:
         _native.set_concurrency_hint(1)
     err = rms(out.cpu().numpy() - ref)
-    print(f"hint {hint} waveform: rms err {err:.3e}")
+    print(f"{case} waveform: rms err {err:.3e} (oracle rms {rms(ref):.3f}, oracle {t_oracle:.0f} s)")
+    assert rms(ref) > 0.02
     assert err <= 5e-5, err
+
+
+def test_convert_batch_full_length_inflight2_equals_sequential(S, hubert, monkeypatch):
+    """The benchmarked MODE at the benchmarked LENGTH: four 30 s utterances through convert_batch with two in flight (cfg 2:
+    48 k NSF vocoder, 100 k index, index_rate 0.75) against the same four converted one at a time.  The synthesizer's random
+    draws are zeroed so that both runs are deterministic; every kernel of one utterance (vocoder included) then runs next to
+    the other utterance's HuBERT / retrieval / vocoder kernels for the whole 30 s, which the 3-6 s clips of
+    test_convert_batch_inflight_equals_sequential do not give.  Gate 1e-5: the library GEMMs are not bit-stable run to run."""
+    from rvc_amd.infer.infer import VoiceConverter
+    from rvc_amd.lib.algorithm.synthesizers import Synthesizer
+    real_draw = Synthesizer._draw
+
+    def zero_draw(self, noise, b, t, t_dec=None):
+        return {k: (torch.zeros_like(v) if v is not None else None) for k, v in real_draw(self, noise, b, t, t_dec).items()}
+
+    monkeypatch.setattr(Synthesizer, "_draw", zero_draw)
+    vc = VoiceConverter(device=DEV)
+    vc.load_checkpoint_dict(S.make_synth_checkpoint(48000, "HiFi-GAN", seed=0, smooth_pitch=True))
+    vc.hubert_model = hubert
+    vc.vc.load_rmvpe_state_dict(S.make_rmvpe_state_dict(0, peaked=True))
+    vc.vc.set_index(S.synth_index(100_000, seed=0))
+    audios = [torch.from_numpy(S.synth_audio(16000 * 30, seed=50 + i)).to(DEV) for i in range(4)]
+    seq = [vc.convert_array(a, index_rate=0.75).clone() for a in audios]
+    torch.cuda.synchronize()
+    worst = 0.0
+    for rep in range(2):
+        par = vc.convert_batch(audios, inflight=2, index_rate=0.75)
+        torch.cuda.synchronize()
+        for a, b_ in zip(seq, par):
+            assert a.shape == b_.shape == (1_439_040,)
+            assert bool(torch.isfinite(b_).all())
+            worst = max(worst, rms((a - b_).cpu().numpy()))
+    print(f"4 x 30 s, two in flight vs one at a time (zero noise): worst waveform rms difference {worst:.3e} (signal rms {rms(seq[0].cpu().numpy()):.3f})")
+    assert worst <= 1e-5, worst
 
 
 def test_convert_array_caller_vs_oracle(S, hubert, sds, tmp_path):

@@ -1,0 +1,322 @@
+// Minimal reproducer hunt for profiles/r03_mfma_cohabitation.txt: does a wave issuing bf16 matrix instructions corrupt a
+// co-resident wave's fp32 matrix work -- in BARE kernels (no LDS-DMA, no inline asm), or only in wino.hip's structure?
+//
+//   victims   V1  bare: A / B fragments by plain global loads -> ds_write -> __syncthreads -> ds_read -> 7 accumulators of
+//                 v_mfma_f32_32x32x2_f32 (the register / LDS footprint of wino_conv_kernel: 4 waves, 66 KB LDS, ~230 VGPRs)
+//             V2  V1 + packed-fp32 transforms writing the matrix instructions' source registers right behind them
+//             V3  V2 with the tap operand staged by LDS-DMA (buffer_load ... lds) + s_waitcnt vmcnt(0) + LDS-only barrier,
+//                 double-buffered, one barrier per chunk: wino.hip's loop skeleton
+//             W   the library's own wino_conv_kernel (rvc_conv1d_wino_forward, 3 taps, C = 64 and 11 taps, C = 128)
+//   co-runners  bf16 32x32x16 matrix loop | fp32 32x32x2 matrix loop | packed-fp32 vector loop, each with a dynamic LDS
+//               request that either lets one of its blocks share a CU with a victim block (60 KB) or not (100 KB)
+//
+// Every victim launch is compared BIT FOR BIT with the same launch made while nothing else runs.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include tools/micro/mfma_cohab.hip -o tools/micro/mfma_cohab \
+//        -L codename-rvc-fork-3_amd/rvc_amd/_lib -lrvc_amd -Wl,-rpath,'$ORIGIN/../../codename-rvc-fork-3_amd/rvc_amd/_lib'
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <functional>
+#include <vector>
+
+#include "rvc_amd.h"
+
+#define CK(e)                                                                                  \
+    do {                                                                                       \
+        hipError_t _e = (e);                                                                   \
+        if (_e != hipSuccess) { fprintf(stderr, "%s: %s (%s:%d)\n", #e, hipGetErrorString(_e), __FILE__, __LINE__); exit(1); } \
+    } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef void __attribute__((address_space(3))) *lptr_t;
+
+// ---- co-runners -----------------------------------------------------------------------------------------------------------
+// MODE 0: v_mfma_f32_32x32x16_bf16, 1: v_mfma_f32_32x32x2_f32, 2: v_pk_fma_f32 only.  NWAVES waves, operands in registers.
+template <int MODE, int NWAVES>
+__global__ void __launch_bounds__(64 * NWAVES) corunner(float *out, int iters) {
+    extern __shared__ float co_lds[];
+    const int lane = threadIdx.x & 63;
+    if (iters < 0) co_lds[threadIdx.x] = 1.f;   // never: keeps the LDS request alive
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    bf16x8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(0.001f * (lane + e)); b[e] = (__bf16)(0.002f * (lane - e)); }
+    float fa = 0.001f * lane, fb = 0.002f * lane;
+    f32x2 va = {fa, fb}, vb = {fb, fa}, vc[8];
+    for (int i = 0; i < 8; ++i) vc[i] = f32x2{0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+        } else if constexpr (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[i], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vc[i] = __builtin_elementwise_fma(va, vb, vc[i]);
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    for (int i = 0; i < 8; ++i) s += vc[i].x + vc[i].y;
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
+// ---- micro victims --------------------------------------------------------------------------------------------------------
+// Block = 4 waves (2 x 2), 64 "channels" x 64 columns; K walked in chunks of 8 channel pairs; per chunk and pair three "tap"
+// planes U[3][8 pairs][64 rows] (float2) and six "window" planes X[6][8 pairs][64 cols] (float2) in LDS; per double k-step the
+// wave reads 3 + 6 float2, (V2+: transforms them as wino.hip's F(4,3) does) and issues 12 matrix instructions on 6 accumulators.
+constexpr int MV_CP = 4;                       // channel pairs per chunk (CIC = 8)
+constexpr int MV_U = 3 * MV_CP * 64;           // float2 per tap buffer (6 KiB)
+constexpr int MV_X = 6 * MV_CP * 64;           // float2 per window buffer (12 KiB)
+template <int V>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+micro_victim(const f32x2 *__restrict__ U, const f32x2 *__restrict__ X, float *__restrict__ out, int n_chunks) {
+    extern __shared__ __attribute__((aligned(16))) float mv_smem[];
+    f32x2 *us = reinterpret_cast<f32x2 *>(mv_smem);    // [2][MV_U]
+    f32x2 *xs = us + 2 * MV_U;                         // [2][MV_X]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    const int blk = blockIdx.x;
+    // per block a different slice of the operand streams (so that a stale / foreign operand shows)
+    const f32x2 *Ub = U + (size_t)(blk & 63) * n_chunks * MV_U;
+    const f32x2 *Xb = X + (size_t)(blk & 63) * n_chunks * MV_X;
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc((void *)Ub, 0, n_chunks * MV_U * 8, 0x00020000);
+    f32x2 xr[MV_X / 256], ur[MV_U / 256];
+    auto load_x = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < MV_X / 256; ++j) xr[j] = Xb[(size_t)c * MV_X + tid + 256 * j];
+    };
+    auto store_x = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < MV_X / 256; ++j) xs[buf * MV_X + tid + 256 * j] = xr[j] * 1.0001f;
+    };
+    auto stage_u = [&](int buf, int c) {
+        if constexpr (V >= 3) {   // LDS-DMA: MV_U * 8 = 6144 bytes = 6 wave-instructions of 1 KiB
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int n = wave + 4 * i;
+                if (n < 6) __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, (lptr_t)((char *)(us + buf * MV_U) + n * 1024), 16, 16 * lane, c * MV_U * 8 + n * 1024, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < MV_U / 256; ++j) ur[j] = Ub[(size_t)c * MV_U + tid + 256 * j];
+#pragma unroll
+            for (int j = 0; j < MV_U / 256; ++j) us[buf * MV_U + tid + 256 * j] = ur[j];
+        }
+    };
+    f32x16 acc[6];
+    for (int q = 0; q < 6; ++q)
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    load_x(0);
+    stage_u(0, 0);
+    store_x(0);
+    if constexpr (V >= 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (n_chunks > 1) load_x(1);
+    if constexpr (V >= 3) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); else __syncthreads();
+    for (int c = 0; c < n_chunks; ++c) {
+        const int buf = c & 1;
+        if (V >= 3 && c + 1 < n_chunks) stage_u(buf ^ 1, c + 1);
+        const f32x2 *ua = us + buf * MV_U + wm * 32 + l31;
+        const f32x2 *xb = xs + buf * MV_X + wn * 32 + l31;
+#pragma unroll
+        for (int st = 0; st < MV_CP / 2; ++st) {
+            const int cpi = 2 * st + half;
+            f32x2 w[3], d[6], aq[6], xq[6];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) w[k] = ua[(k * MV_CP + cpi) * 64];
+#pragma unroll
+            for (int n = 0; n < 6; ++n) d[n] = xb[(n * MV_CP + cpi) * 64];
+            if constexpr (V >= 2) {   // wino.hip's F(4,3) transforms (packed fp32)
+                const f32x2 ts = w[0] + w[2], tv = __builtin_elementwise_fma(f32x2{4.f, 4.f}, w[2], w[0]);
+                aq[0] = w[0]; aq[1] = ts + w[1]; aq[2] = ts - w[1];
+                aq[3] = __builtin_elementwise_fma(f32x2{2.f, 2.f}, w[1], tv); aq[4] = __builtin_elementwise_fma(f32x2{-2.f, -2.f}, w[1], tv); aq[5] = w[2];
+                xq[0] = __builtin_elementwise_fma(f32x2{4.f, 4.f}, d[0], __builtin_elementwise_fma(f32x2{-5.f, -5.f}, d[2], d[4]));
+                const f32x2 t1 = __builtin_elementwise_fma(f32x2{-4.f, -4.f}, d[2], d[4]), t2 = __builtin_elementwise_fma(f32x2{-4.f, -4.f}, d[1], d[3]);
+                xq[1] = t1 + t2; xq[2] = t1 - t2;
+                const f32x2 t3 = d[4] - d[2], t4 = d[3] - d[1];
+                xq[3] = __builtin_elementwise_fma(f32x2{2.f, 2.f}, t4, t3); xq[4] = __builtin_elementwise_fma(f32x2{-2.f, -2.f}, t4, t3);
+                xq[5] = __builtin_elementwise_fma(f32x2{4.f, 4.f}, d[1], __builtin_elementwise_fma(f32x2{-5.f, -5.f}, d[3], d[5]));
+            } else {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) { aq[q] = w[q % 3]; xq[q] = d[q]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[q].x, xq[q].x, acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[q].y, xq[q].y, acc[q], 0, 0, 0);
+        }
+        if (c + 1 < n_chunks) {
+            if constexpr (V >= 3) {
+                store_x(buf ^ 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (c + 2 < n_chunks) load_x(c + 2);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            } else {
+                __syncthreads();           // everyone is done reading buf ^ 1 (chunk c - 1) ... it is chunk c they just read; see below
+                stage_u(buf ^ 1, c + 1);
+                store_x(buf ^ 1);
+                if (c + 2 < n_chunks) load_x(c + 2);
+                __syncthreads();
+            }
+        }
+    }
+    float *o = out + ((size_t)blk * 256 + tid) * 96;
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) *reinterpret_cast<f32x4 *>(o + q * 16 + r) = f32x4{acc[q][r], acc[q][r + 1], acc[q][r + 2], acc[q][r + 3]};
+}
+
+__global__ void count_diff(const uint32_t *a, const uint32_t *b, size_t n, unsigned long long *count) {
+    unsigned long long local = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) local += a[i] != b[i];
+    if (local) atomicAdd(count, local);
+}
+
+struct CoRunner {
+    const char *name;
+    void (*launch)(float *, int, size_t, int, hipStream_t);
+};
+template <int MODE, int NW>
+static void launch_co(float *out, int iters, size_t lds, int blocks, hipStream_t st) {
+    static bool set = false;
+    if (!set) { CK(hipFuncSetAttribute((const void *)corunner<MODE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)); set = true; }
+    hipLaunchKernelGGL((corunner<MODE, NW>), dim3(blocks), dim3(64 * NW), lds, st, out, iters);
+}
+
+int main(int argc, char **argv) {
+    const int reps = argc > 1 ? atoi(argv[1]) : 200;
+    hipStream_t sa, sb;
+    CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    float *co_out;
+    CK(hipMalloc(&co_out, 4096));
+    unsigned long long *count;
+    CK(hipMalloc(&count, 8));
+
+    // ---- victims ----
+    struct Victim {
+        const char *name;
+        std::function<void(hipStream_t)> run;
+        float *out;
+        size_t n_out;
+    };
+    std::vector<Victim> victims;
+    // micro victims
+    const int n_chunks = 16, mv_blocks = 4096;
+    const size_t mv_lds = 66 * 1024;
+    std::vector<float> hu((size_t)64 * n_chunks * MV_U * 2), hx((size_t)64 * n_chunks * MV_X * 2);
+    srand(1);
+    for (auto &v : hu) v = (rand() / (float)RAND_MAX - 0.5f) * 0.25f;
+    for (auto &v : hx) v = (rand() / (float)RAND_MAX - 0.5f) * 2.f;
+    f32x2 *dU, *dX;
+    CK(hipMalloc(&dU, hu.size() * 4)); CK(hipMalloc(&dX, hx.size() * 4));
+    CK(hipMemcpy(dU, hu.data(), hu.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dX, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+    const size_t mv_n = (size_t)mv_blocks * 256 * 96;
+    auto add_micro = [&](const char *name, auto kern) {
+        float *o;
+        CK(hipMalloc(&o, mv_n * 4));
+        CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mv_lds));
+        victims.push_back({name, [=](hipStream_t st) { hipLaunchKernelGGL(kern, dim3(mv_blocks), dim3(256), mv_lds, st, dU, dX, o, n_chunks); }, o, mv_n});
+    };
+    add_micro("V1 bare fp32 matrix loop from LDS (plain loads, __syncthreads)", micro_victim<1>);
+    add_micro("V2 V1 + packed-fp32 transforms behind the matrix instructions", micro_victim<2>);
+    add_micro("V3 V2 + LDS-DMA taps, vmcnt(0) + LDS-only barrier (wino.hip's skeleton)", micro_victim<3>);
+    // the library's wino kernel
+    auto add_wino = [&](const char *name, int C, int K, int64_t L) {
+        std::vector<float> w((size_t)C * C * K), x((size_t)C * L), bias(C);
+        for (auto &v : w) v = (rand() / (float)RAND_MAX - 0.5f) * 0.1f;
+        for (auto &v : x) v = (rand() / (float)RAND_MAX - 0.5f) * 2.f;
+        for (auto &v : bias) v = (rand() / (float)RAND_MAX - 0.5f);
+        float *u, *dx, *db, *dres, *y;
+        const size_t ub = (size_t)3 * ((K + 2) / 3) * C * C * 4;
+        CK(hipMalloc(&u, ub)); CK(hipMalloc(&dx, x.size() * 4)); CK(hipMalloc(&db, C * 4)); CK(hipMalloc(&dres, x.size() * 4)); CK(hipMalloc(&y, x.size() * 4));
+        CK(hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dres, x.data(), x.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(db, bias.data(), C * 4, hipMemcpyHostToDevice));
+        if (rvc_conv1d_wino_pack_weight(w.data(), C, C, K, u, nullptr)) { fprintf(stderr, "pack: %s\n", rvc_last_error()); exit(1); }
+        victims.push_back({name, [=](hipStream_t st) {
+            if (rvc_conv1d_wino_forward(dx, u, db, dres, nullptr, y, 1, C, C, L, K, 1, 0.1f, 1.f, st)) { fprintf(stderr, "wino: %s\n", rvc_last_error()); exit(1); }
+        }, y, (size_t)C * L});
+    };
+    add_wino("W3 library wino_conv_kernel, 3 taps, C = 64", 64, 3, 200000);
+    add_wino("W11 library wino_conv_kernel, 11 taps, C = 128", 128, 11, 60000);
+
+    const CoRunner cos[] = {
+        {"bf16 32x32x16 matrix loop, 4 waves, 60 KB LDS (can share a CU)", launch_co<0, 4>},
+        {"bf16 32x32x16 matrix loop, 4 waves, 100 KB LDS (cannot share)", launch_co<0, 4>},
+        {"fp32 32x32x2 matrix loop, 4 waves, 60 KB LDS (can share)", launch_co<1, 4>},
+        {"packed-fp32 vector loop, 4 waves, 60 KB LDS (can share)", launch_co<2, 4>},
+        {"bf16 32x32x16 matrix loop, 8 waves, 60 KB LDS (can share)", launch_co<0, 8>},
+    };
+    const size_t co_lds[] = {60 * 1024, 100 * 1024, 60 * 1024, 60 * 1024, 60 * 1024};
+    const int co_iters[] = {40000, 40000, 20000, 40000, 40000};
+
+    printf("%d victim launches per cell, compared bit for bit with the same launch made alone; cell = launches with a differing word / words that differ in the worst launch\n", reps);
+    const char *only = argc > 2 ? argv[2] : nullptr;   // run only the victims whose name starts with this
+    for (auto &v : victims) {
+        if (only && strncmp(v.name, only, strlen(only))) continue;
+        float *ref;
+        CK(hipMalloc(&ref, v.n_out * 4));
+        v.run(sb);
+        CK(hipStreamSynchronize(sb));
+        CK(hipMemcpy(ref, v.out, v.n_out * 4, hipMemcpyDeviceToDevice));
+        // self-consistency alone
+        int bad_alone = 0;
+        float t_alone = 0.f;
+        hipEvent_t a0, a1;
+        CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1));
+        for (int r = 0; r < 20; ++r) {
+            CK(hipMemset(count, 0, 8));
+            CK(hipEventRecord(a0, sb));
+            v.run(sb);
+            CK(hipEventRecord(a1, sb));
+            hipLaunchKernelGGL(count_diff, dim3(1024), dim3(256), 0, sb, (const uint32_t *)v.out, (const uint32_t *)ref, v.n_out, count);
+            unsigned long long h;
+            CK(hipMemcpyAsync(&h, count, 8, hipMemcpyDeviceToHost, sb));
+            CK(hipStreamSynchronize(sb));
+            bad_alone += h != 0;
+            float ms;
+            CK(hipEventElapsedTime(&ms, a0, a1));
+            t_alone += ms;
+        }
+        printf("\n%s\n  alone: %d of 20 launches differ from the first, %.3f ms per launch\n", v.name, bad_alone, t_alone / 20);
+        for (int ci = 0; ci < (int)(sizeof(cos) / sizeof(cos[0])); ++ci) {
+            int bad = 0;
+            unsigned long long worst = 0;
+            float t_with = 0.f;
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            for (int r = 0; r < reps; ++r) {
+                // keep the co-runner in flight for the whole victim launch: two long grids queued ahead on stream A
+                if (r % 4 == 0) for (int k = 0; k < 6; ++k) cos[ci].launch(co_out, co_iters[ci], co_lds[ci], 256, sa);   // one block per CU
+                CK(hipMemsetAsync(count, 0, 8, sb));
+                CK(hipEventRecord(e0, sb));
+                v.run(sb);
+                CK(hipEventRecord(e1, sb));
+                hipLaunchKernelGGL(count_diff, dim3(1024), dim3(256), 0, sb, (const uint32_t *)v.out, (const uint32_t *)ref, v.n_out, count);
+                unsigned long long h;
+                CK(hipMemcpyAsync(&h, count, 8, hipMemcpyDeviceToHost, sb));
+                CK(hipStreamSynchronize(sb));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                t_with += ms;
+                bad += h != 0;
+                if (h > worst) worst = h;
+            }
+            CK(hipStreamSynchronize(sa));
+            printf("  next to [%s]: %d of %d differ (worst: %llu words), victim %.3f ms per launch\n", cos[ci].name, bad, reps, worst, t_with / reps);
+            fflush(stdout);
+        }
+        CK(hipFree(ref));
+    }
+    return 0;
+}
