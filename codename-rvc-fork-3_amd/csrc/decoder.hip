@@ -390,6 +390,16 @@ int build_conv(const rvc_decoder *d, const std::string &prefix, int c_out, int c
             std::vector<uint16_t> halves(words.size() * 2);
             memcpy(halves.data(), words.data(), words.size() * 4);
             if (out->wu16.upload(halves)) return 1;
+            if (winobf_enabled() && winobf_supported(c_in, c_out, k, 1)) {   // the bf16-matrix-core form on the bf16-VALUED taps: a transformed
+                std::vector<float> vals((size_t)c_out * c_in * k);           // tap is a sum of four of them and needs its three-way split like any other
+                for (size_t i = 0; i < vals.size(); ++i) {
+                    const uint32_t bits = (uint32_t)bf16_rne(w->data[i]) << 16;
+                    memcpy(&vals[i], &bits, 4);
+                }
+                std::vector<uint16_t> frags;
+                winobf_pack_host(vals.data(), c_out, c_in, k, &frags);
+                if (out->wx.upload(frags)) return 1;
+            }
         } else {
             wino_pack_host(w->data.data(), c_out, c_in, k, &packed);
             if (out->wu.upload(packed)) return 1;

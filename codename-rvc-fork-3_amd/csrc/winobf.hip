@@ -584,7 +584,13 @@ static int winobf_launch(WinoBfParams p, hipStream_t stream) {
 // transforms and raw-row staging per product but loses (G - 1) d of 64 columns instead of 128 to the tap-group overlap:
 // measured (profiles/r03_convbf_shapes.txt) it wins 12-17 % on the 7-tap layers and 7 % on 256-channel 11-tap ones, and is
 // level (+5 .. -3 %) on 128-channel 11-tap ones, which keep 64 x 128.  RVC_WBF_BM128=0 forces 64 x 128 everywhere.
+bool winobf2_enabled() {
+    static const int on = knob("RVC_WBF_V2", 1);
+    return on != 0;
+}
+
 int winobf_block_rows(int c_out, int k) {
+    if (winobf2_enabled()) return winobf2_block_rows(c_out);   // the fragments are packed for the kernel that will read them
     static const int wide = knob("RVC_WBF_BM128", 1);
     if (!wide || c_out % 128) return 64;
     return (k == 7 || c_out >= 256 || wide == 2) ? 128 : 64;
@@ -606,6 +612,7 @@ int launch_winobf_conv(const float *x, const void *u, const float *bias, const f
     if (!(slope >= 0.f && slope <= 1.f)) return fail("winobf conv: leaky slope %g outside [0, 1]", (double)slope);
     if (!winobf_fits(c_in, c_out, L)) return fail("winobf conv: %d x %lld samples exceed the 2 GiB buffer addressing", c_in, (long long)L);
     if (L <= 0 || batch <= 0) return 0;
+    if (winobf2_enabled()) return launch_winobf2_conv(x, u, bias, res, accin, y, batch, c_in, c_out, L, k, dil, slope, out_scale, stream);
     WinoBfParams p;
     p.x = x; p.u = u; p.bias = bias; p.res = res; p.accin = accin; p.y = y;
     p.c_in = c_in; p.c_out = c_out; p.L = L; p.dil = dil; p.slope = slope; p.out_scale = out_scale; p.batch = batch;

@@ -1,0 +1,542 @@
+// K3y -- winobf.hip's arithmetic (Winograd F(4,4) on the bf16 matrix cores, fp32 operands split exactly into bf16) with the
+// work laid out the other way round: ONE TRANSFORM POINT PER WAVE.
+//
+// winobf.hip gives each of its 8 waves one 32 x 32 output tile and walks the 7 points inside the K loop: every matrix
+// instruction needs a fresh tap fragment AND a fresh window fragment from LDS (1 KiB of LDS reads per instruction, the LDS
+// as busy as the matrix pipe), the six products of a (point, group) form one dependent chain, and a step ends in a barrier
+// (seven per 16-channel chunk).  Measured there (profiles/r03_winobf_ablation.txt): two thirds of a launch is NOT matrix work.
+//
+// Here wave w < 7 owns point w for the WHOLE block (BM output channels x 64 window columns = BM / 32 x 2 accumulator tiles):
+//   * its tap fragments U_w are nobody else's: they go HBM/L2 -> registers (buffer_load_dwordx4, one 1 KiB fragment per
+//     instruction, loaded one 24-instruction group ahead) and never touch LDS;
+//   * its window fragments X_w are nobody else's either: the wave transforms the chunk's 64 windows for ITS point (one lane per
+//     window, all 16 channels), splits them and writes them to a PRIVATE LDS area it alone reads back (shifted by g d for tap
+//     group g) -- no block barrier between transform and product, only the wave's own program order;
+//   * a tap fragment serves 2 column tiles and a window fragment BM / 32 row blocks: 0.375 fragments per matrix instruction
+//     instead of 1, a quarter of the LDS reads per product;
+//   * 8 (BM = 128) or 4 independent accumulator chains per wave: a matrix instruction never waits for its predecessor;
+//   * wave 7 is the LOADER: it alone stages the raw input rows (global -> leaky ReLU -> de-interleaved LDS rows), two chunks
+//     ahead of the products, so the compute waves issue nothing but tap loads, LDS traffic of their own point and matrix
+//     instructions;
+//   * ONE block barrier per 16-channel chunk (the raw-row hand-over), not seven.
+// The price: the 7 points of an output element sit in 7 waves, so the output transform goes through LDS once per block
+// (epilogue: accumulators -> LDS -> A^T -> bias / residual / running sum -> HBM), and 7 compute waves on 4 SIMDs leave one
+// SIMD's matrix pipe half used (7 / 8 of the pipe at best).
+//
+// bf16-valued taps (BASELINE cfg 4) take the same path with fragments built from those values: a TRANSFORMED tap
+// u = sum_k a_p^k w_k is a sum of up to four bf16 numbers at different exponents and needs up to 24 significand bits like
+// any fp32 tap, so the three-way split stays (a one-term tap split exists only for the direct form, whose 16 / 16 multiply-adds
+// x 3 products = 3.0 cost more matrix work than this form's 0.477 x 6 = 2.86).
+#include <stdlib.h>
+
+#include <mutex>
+#include <type_traits>
+#include <vector>
+
+#include "conv.h"
+
+namespace rvc {
+
+struct Wbf2Params {
+    const float *x = nullptr;        // [batch][c_in][L]
+    const void *u = nullptr;         // winobf_pack_host's slab at winobf2_block_rows(c_out) rows per block
+    const float *bias = nullptr;     // [c_out]
+    const float *res = nullptr;      // [batch][c_out][L] or null
+    const float *accin = nullptr;    // [batch][c_out][L] or null
+    float *y = nullptr;              // [batch][c_out][L]
+    int c_in = 0, c_out = 0;
+    int64_t L = 0;
+    int dil = 1;
+    int sb_per_block = 0;            // super-blocks (of d tiles) per block
+    int n_tile_blocks = 0;           // blocks along time
+    float slope = 1.f, out_scale = 1.f;
+    int batch = 1;
+};
+
+constexpr int W2_MAX_DIL = 5;
+constexpr int W2_NTH = 512, W2_BNT = 64, W2_CIC = 16, W2_CP = 8, W2_NP = 7, W2_R = 4;
+
+typedef float w2_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 w2_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 w2_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned w2_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned w2_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ w2_f32x2 w2_lrelu2(w2_f32x2 v, float slope) {
+    const w2_f32x2 sv = v * slope;
+    return w2_f32x2{__builtin_fmaxf(v.x, sv.x), __builtin_fmaxf(v.y, sv.y)};
+}
+constexpr int W2_RSRC_FLAGS = 0x00020000;
+
+// rows of the F(4,4) input transform B^T for the points 0, 1, -1, 1/2, -1/2, 2, inf (the expressions of wino.hip / winobf.hip
+// multiplied out; every entry is exact in fp32): X_p = sum_n W2_BT[p][n] * x[n]
+__constant__ float W2_BT[7][8] = {
+    {-0.5f, 0.25f, 2.5f, -1.25f, -2.f, 1.f, 0.f, 0.f},
+    {0.f, 0.5f, 0.25f, -2.25f, -1.f, 1.f, 0.f, 0.f},
+    {0.f, -0.5f, 0.75f, 1.75f, -3.f, 1.f, 0.f, 0.f},
+    {0.f, 1.f, 1.5f, -2.f, -1.5f, 1.f, 0.f, 0.f},
+    {0.f, -1.f, 2.5f, 0.f, -2.5f, 1.f, 0.f, 0.f},
+    {0.f, 0.25f, 0.f, -1.25f, 0.f, 1.f, 0.f, 0.f},
+    {0.f, -0.5f, 0.25f, 2.5f, -1.25f, -2.f, 1.f, 0.f},
+};
+
+template <int KW, int BM>
+struct W2Geom {
+    static constexpr int G = (KW + W2_R - 1) / W2_R;
+    static constexpr int C0 = (KW - 1) / 2;
+    // one window's samples sit at offsets (n - C0) d, n = 0..6: super-block steps MLO .. 0
+    static constexpr int MLO = -((C0 + 3) / 4);
+    static_assert(6 - C0 < 4 && 6 - C0 >= 0, "the window's last sample lies in its own super-block");
+    static constexpr int WM = BM / 32, WN = W2_BNT / 32;
+    static constexpr int XT = W2_BNT + (-MLO) * W2_MAX_DIL;             // raw tiles per row: 64 windows + the -MLO d tiles in front
+    static constexpr int XTS = ((XT - 12 + 31) / 32) * 32 + 12;          // row stride in float2, == 12 mod 32 (ds_write_b64 of 4 rows: 4 bank groups)
+    static_assert(XTS >= XT + 2, "");
+    static constexpr int RAW_BYTES = W2_CP * 4 * XTS * 8;               // one raw chunk; two buffers
+    static constexpr int XB = W2_BNT + (G - 1) * W2_MAX_DIL;             // window fragments per (split, k half): the products read up to here
+    static constexpr int B_PLANE = XB * 16;
+    static constexpr int B_WAVE = 3 * 2 * B_PLANE;                      // [split][k half][window][8 bf16], one chunk of one point
+    static constexpr int B_BYTES = W2_NP * 2 * B_WAVE;                  // every compute wave: two chunks
+    static constexpr int LOOP_BYTES = 2 * RAW_BYTES + B_BYTES;
+    static constexpr int NJ = (4 * XT + 63) / 64;                       // staged samples per loader lane per channel row
+    // epilogue, per pass of one row-block pair (64 channels x 64 columns): the 7 points' accumulators, then the output tile
+    static constexpr int RED_BYTES = W2_NP * 4 * 4096;
+    static constexpr int YS = 4 * W2_BNT + 4;
+    static constexpr int OUT_BYTES = 64 * YS * 4;
+    static constexpr int EPI_BYTES = RED_BYTES > OUT_BYTES ? RED_BYTES : OUT_BYTES;
+    static constexpr int LDS_BYTES = LOOP_BYTES > EPI_BYTES ? LOOP_BYTES : EPI_BYTES;
+    static_assert(LDS_BYTES <= 163840, "LDS budget");
+};
+
+template <int KW, int BM>
+__global__ void __launch_bounds__(W2_NTH) __attribute__((amdgpu_waves_per_eu(2, 2)))
+winobf2_conv_kernel(const Wbf2Params p) {
+    using GM = W2Geom<KW, BM>;
+    constexpr int NP = W2_NP, G = GM::G, C0 = GM::C0, MLO = GM::MLO, WM = GM::WM, CP = W2_CP, CIC = W2_CIC;
+    constexpr int XT = GM::XT, XTS = GM::XTS, NJ = GM::NJ, BNT = W2_BNT;
+    constexpr int NPAIR = WM / 2;                         // row-block pairs (two 32-channel blocks each)
+    constexpr int NSA = 3;                                // bf16 numbers per transformed tap (exact split of an fp32 value)
+    constexpr int NPROD = 6;                              // products per (tap group, accumulator tile): all of order <= 2^-16
+
+    extern __shared__ __attribute__((aligned(16))) float w2_smem[];
+    unsigned char *const smem = reinterpret_cast<unsigned char *>(w2_smem);
+    w2_f32x2 *const xs = reinterpret_cast<w2_f32x2 *>(smem);              // raw chunks [2][CP][4][XTS]
+    constexpr int XRAW = CP * 4 * XTS;                                     // float2 per raw buffer
+    unsigned char *const bs_all = smem + 2 * GM::RAW_BYTES;                // [point][2][B_WAVE]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __builtin_assume(wave >= 0 && wave < 8);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z;
+    const int n_m = p.c_out / BM;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int tile_blk = (seq / n_m) * 8 + xcd;               // the n_m channel blocks of one time tile: ids 8 apart, same XCD
+    if (tile_blk >= p.n_tile_blocks) return;
+    const int mblk = seq % n_m;
+    const int m0 = mblk * BM;
+    const int d = p.dil;
+    const int64_t sb0 = (int64_t)tile_blk * p.sb_per_block;
+    const int n_tiles_blk = p.sb_per_block * d;               // valid output tiles (columns) of this block
+    const int64_t L = p.L;
+    const int c_in = p.c_in, c_out = p.c_out;
+    const int n_chunks = c_in / CIC;
+    const bool loader = wave == NP;
+
+    f32x16 acc[WM][2];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (loader) {
+        // ================================ wave 7: raw input rows, two chunks ahead =========================================
+        const float *const px = p.x + (int64_t)b * c_in * L;
+        const float slope = p.slope;
+        const int xt_used = (p.sb_per_block + G - 1 - MLO) * d;      // valid tiles + the (G - 1) d windows behind them + the -MLO d in front
+        const int64_t t_start = (sb0 + MLO) * 4 * d;
+        const int span = 4 * xt_used;
+        const bool edge = t_start < 0 || t_start + span > L;
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)px, 0, (int)((int64_t)c_in * L * 4), W2_RSRC_FLAGS);
+        const int L4 = (int)(L * 4);
+        unsigned goff[NJ];
+        int loff[NJ];
+        unsigned keep[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int tl = lane + j * 64;
+            const bool have = tl < span;
+            const int tlc = have ? tl : 0;
+            const int64_t t = t_start + tlc;
+            const int64_t tc = t < 0 ? 0 : (t >= L ? L - 1 : t);
+            goff[j] = (unsigned)tc * 4u;
+            const int sbl = tlc / (4 * d);
+            const int r = tlc - sbl * 4 * d;
+            const int ii = r / d;
+            const int phi = r - ii * d;
+            loff[j] = have ? ii * XTS + sbl * d + phi : XT + (lane & 1);   // columns >= XT of a row are never read
+            keep[j] = (!edge || (t >= 0 && t < L)) ? 0xffffffffu : 0u;      // conv zero padding
+        }
+        auto stage = [&](int c) __attribute__((always_inline)) {
+            w2_f32x2 *const dst0 = xs + (c & 1) * XRAW;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                 // four channel pairs at a time: 40 loads in flight
+                w2_f32x2 xr[4 * NJ];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int s0 = (c * CIC + 2 * (h * 4 + q)) * L4;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        xr[q * NJ + j] = w2_f32x2{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)goff[j], s0, 0)),
+                                                  __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)goff[j], s0 + L4, 0))};
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    w2_f32x2 *const dst = dst0 + (h * 4 + q) * 4 * XTS;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const w2_f32x2 v = w2_lrelu2(xr[q * NJ + j], slope);
+                        dst[loff[j]] = w2_f32x2{__uint_as_float(__float_as_uint(v.x) & keep[j]), __uint_as_float(__float_as_uint(v.y) & keep[j])};
+                    }
+                }
+            }
+        };
+        stage(0);
+        lds_barrier();                                    // (P1) chunk 0's rows are in LDS
+        if (n_chunks > 1) stage(1);
+        lds_barrier();                                    // (P2) chunk 1's rows; the compute waves have transformed chunk 0
+        for (int c = 0; c < n_chunks; ++c) {
+            if (c + 2 < n_chunks) stage(c + 2);           // into buffer c & 1: chunk c was transformed before the last barrier
+            lds_barrier();
+        }
+    } else {
+        // ================================ waves 0..6: point `wave` of every output tile =====================================
+        const int pt = wave;
+        unsigned char *const bs = bs_all + pt * 2 * GM::B_WAVE;
+        // input transform coefficients of this point (wave-uniform: scalar registers)
+        float bt[7];
+#pragma unroll
+        for (int n = 0; n < 7; ++n) bt[n] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, W2_BT[pt][n])));
+        // tap fragments: [c_out / BM][chunk][point][group][row block][split][lane][8 bf16], 1 KiB each
+        const __amdgpu_buffer_rsrc_t urs =
+            __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, (int)((int64_t)c_in * c_out * NP * G * NSA * 2), W2_RSRC_FLAGS);
+        const int a_chunk_stride = NP * G * WM * NSA * 1024;
+        const int a_base = mblk * n_chunks * a_chunk_stride + pt * G * WM * NSA * 1024;
+        w2_bf16x8 fa[2][2][NSA];                           // [buffer][row block of the pair][split]
+        auto load_a = [&](int buf, int c, int g, int pr) __attribute__((always_inline)) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int sp = 0; sp < NSA; ++sp) {
+                    const int soff = a_base + c * a_chunk_stride + ((g * WM + pr * 2 + rb) * NSA + sp) * 1024;
+                    fa[buf][rb][sp] = __builtin_bit_cast(w2_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(urs, 16 * lane, soff, 0));
+                }
+        };
+        // window fragments of one tap group: [column tile][split]; single-buffered -- the products of a group are ordered so that
+        // split 2 dies first, then split 1, and each is re-read for the next group while the current one finishes
+        w2_bf16x8 fb[2][3];
+        const int b_lane = half * GM::B_PLANE + l31 * 16;
+        auto read_b = [&](int c, int g, int sp) __attribute__((always_inline)) {
+            const unsigned char *bb = bs + (c & 1) * GM::B_WAVE + sp * 2 * GM::B_PLANE + b_lane + g * d * 16;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) fb[cb][sp] = __builtin_bit_cast(w2_bf16x8, *reinterpret_cast<const w2_u32x4 *>(bb + cb * 32 * 16));
+        };
+        // ---- input transform of chunk c for this point: lane = window, unit u = channel pairs 2u, 2u + 1 -------------------
+        const int t_src = -MLO * d + lane;                 // raw tile of the window's own super-block
+        w2_f32x2 tq[2][7];
+        w2_f32x2 tv[2];
+        unsigned tw[3][2];
+        auto t_read = [&](int c, int u) __attribute__((always_inline)) {
+            const w2_f32x2 *const raw = xs + (c & 1) * XRAW + t_src;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int n = 0; n < 7; ++n) {
+                    const int sh = n - C0;
+                    tq[e][n] = raw[((2 * u + e) * 4 + (sh & 3)) * XTS + (sh >> 2) * d];
+                }
+        };
+        auto t_xform = [&](int e) __attribute__((always_inline)) {
+            w2_f32x2 a = tq[e][0] * bt[0];
+#pragma unroll
+            for (int n = 1; n < 7; ++n) a = __builtin_elementwise_fma(w2_f32x2{bt[n], bt[n]}, tq[e][n], a);
+            tv[e] = a;
+        };
+        auto t_split = [&](int e, int level) __attribute__((always_inline)) {
+            const unsigned w = __builtin_bit_cast(unsigned, __builtin_convertvector(tv[e], w2_bf16x2));
+            tw[level][e] = w;
+            if (level < 2) tv[e] = tv[e] - w2_f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+        };
+        auto t_write = [&](int c, int u) __attribute__((always_inline)) {
+            unsigned char *o = bs + (c & 1) * GM::B_WAVE + (u >> 1) * GM::B_PLANE + lane * 16 + (u & 1) * 8;
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) *reinterpret_cast<w2_u32x2 *>(o + sp * 2 * GM::B_PLANE) = w2_u32x2{tw[sp][0], tw[sp][1]};
+        };
+        auto transform_unit = [&](int c, int u) __attribute__((always_inline)) {
+            t_read(c, u);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) { t_xform(e); t_split(e, 0); t_split(e, 1); t_split(e, 2); }
+            t_write(c, u);
+        };
+
+        // ---- prologue ------------------------------------------------------------------------------------------------------
+        load_a(0, 0, 0, 0);
+        lds_barrier();                                    // (P1)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) transform_unit(0, u);
+        if (NPAIR > 1 || G > 1) load_a(1, 0, NPAIR > 1 ? 0 : 1, NPAIR > 1 ? 1 : 0);
+        read_b(0, 0, 2); read_b(0, 0, 1); read_b(0, 0, 0);
+        lds_barrier();                                    // (P2)
+
+        // ---- main loop: one phase per chunk ---------------------------------------------------------------------------------
+        // group q = (tap group g, row-block pair pr), q = g * NPAIR + pr: 24 matrix instructions on four independent accumulators
+        // (product i, row block rb, column tile cb).  Its tap fragments sit in fa[(q + parity) & 1] (parity: NQ may be odd, so the
+        // buffer of "group q" alternates from chunk to chunk); those of the next group are in flight into the other buffer, and when
+        // the group has issued its last product the loads of group q + 2 are issued into its own buffer.
+        // Behind matrix instruction k of a group come, pinned by sched_barrier:
+        //   * the NEXT chunk's input transform, in four units of two channel pairs, spread over the first NQ - 1 groups (the last
+        //     group of a chunk re-reads window fragments of the next chunk, so every unit must have been written before it);
+        //   * the window fragments of the next tap group, split by split, as soon as the last product on a split has been issued;
+        //   * the tap loads of group q + 2.
+        constexpr int NQ = G * NPAIR;
+        constexpr int ia6[6] = {0, 1, 0, 2, 1, 0}, ib6[6] = {2, 1, 1, 0, 0, 0};
+        auto phase = [&](int c, auto PAR) __attribute__((always_inline)) {
+            constexpr int par = decltype(PAR)::value;
+            const int cn = c + 1 < n_chunks ? c + 1 : c;  // the last phase re-transforms its own chunk (same bits, never needed): no branch in the body
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int g = q / NPAIR, pr = q % NPAIR;
+                const int bufq = (q + par) & 1;
+                // group q + 2 (wrapping into the next chunk): where its tap fragments come from
+                const int q2 = (q + 2) % NQ, c2raw = c + (q + 2) / NQ;
+                const int c2 = c2raw < n_chunks ? c2raw : n_chunks - 1;
+                const int g2 = q2 / NPAIR, pr2 = q2 % NPAIR;
+                // the window fragments the NEXT group needs: a new tap group's (g + 1, or group 0 of the next chunk) when pr is the last pair
+                const bool b_turn = pr == NPAIR - 1;
+                const int gb = (g + 1) % G, cb_c = g + 1 < G ? c : c + 1;
+#pragma unroll
+                for (int i = 0; i < NPROD; ++i) {
+                    const int ia = ia6[i], ib = ib6[i];
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb) {
+                            acc[pr * 2 + rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[bufq][rb][ia], fb[cb][ib], acc[pr * 2 + rb][cb], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            const int k = (i * 2 + rb) * 2 + cb;            // 0 .. 23: fillers behind this matrix instruction
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {                   // transform unit u lives in group u (NQ - 1) / 4, six slots each
+                                if (u * (NQ - 1) / 4 != q) continue;
+                                int first = u;                              // its rank among the units of this group
+                                while (first > 0 && (first - 1) * (NQ - 1) / 4 == q) --first;
+                                const int k0 = (u - first) * 6;
+                                if (k == k0) t_read(cn, u);
+                                if (k == k0 + 1) { t_xform(0); t_split(0, 0); }
+                                if (k == k0 + 2) { t_split(0, 1); t_split(0, 2); }
+                                if (k == k0 + 3) { t_xform(1); t_split(1, 0); }
+                                if (k == k0 + 4) { t_split(1, 1); t_split(1, 2); }
+                                if (k == k0 + 5) t_write(cn, u);
+                            }
+                            if (b_turn) {
+                                if (k == 3) read_b(cb_c, gb, 2);            // split 2: product 0 only
+                                if (k == 11) read_b(cb_c, gb, 1);           // split 1: products 1, 2
+                                if (k == 23) read_b(cb_c, gb, 0);           // split 0: products 3..5
+                            }
+                            if (k == 4 * NPROD - 1) load_a(bufq, c2, g2, pr2);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                }
+            }
+            lds_barrier();                                // the raw rows of chunk c + 2 are in LDS; B of chunk c + 1 is this wave's own
+        };
+        for (int c = 0; c < n_chunks; c += 2) {
+            phase(c, std::integral_constant<int, 0>{});
+            if (c + 1 < n_chunks) phase(c + 1, std::integral_constant<int, NQ & 1>{});
+        }
+    }
+
+    // ================================ epilogue: output transform across the 7 waves ========================================
+    // Per row-block pair (64 channels x 64 columns): the compute waves park their four accumulator tiles in LDS
+    // red[point][tile = rb * 2 + cb][r >> 2][lane][r & 3]; every thread then takes two (tile, r >> 2, lane) groups, reads the 7
+    // points' float4 (4 consecutive channels of one column), applies A^T diag(1 / N_j) exactly as winobf.hip does, and either
+    // stores the 4 outputs of a column straight to HBM (d = 1, L % 4 == 0: 16 contiguous bytes) or parks them in the
+    // transposed tile yt[channel][t - t_blk0] for whole-row stores.
+    const float *bias = p.bias;
+    const float *res = p.res ? p.res + (int64_t)b * c_out * L : nullptr;
+    const float *accin = p.accin ? p.accin + (int64_t)b * c_out * L : nullptr;
+    float *y = p.y + (int64_t)b * c_out * L;
+    const float out_scale = p.out_scale;
+    f32x4 *const red = reinterpret_cast<f32x4 *>(smem);
+    float *const yt = w2_smem;
+    constexpr int YS = GM::YS;
+    const bool l4 = (L & 3) == 0;
+    const bool direct = d == 1 && l4;
+    const int64_t t_blk0 = sb0 * 4 * d;
+    const int64_t left = L - t_blk0;
+    const int n_t = (int)(left < 4 * n_tiles_blk ? left : 4 * n_tiles_blk);   // valid outputs per row in this block
+#pragma unroll
+    for (int pr = 0; pr < NPAIR; ++pr) {
+        if (pr > 0) lds_barrier();                        // the previous pass's tile has been copied out
+        if (!loader) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq)
+                        red[((wave * 4 + rb * 2 + cb) * 4 + rq) * 64 + lane] =
+                            f32x4{acc[pr * 2 + rb][cb][4 * rq], acc[pr * 2 + rb][cb][4 * rq + 1], acc[pr * 2 + rb][cb][4 * rq + 2], acc[pr * 2 + rb][cb][4 * rq + 3]};
+        }
+        lds_barrier();
+        f32x4 o[2][4];                                    // [group][channel of the quad] -> 4 outputs
+        int g_row[2], g_col[2];
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int grp = tid + gi * W2_NTH;            // (tile, rq, lane'): 4 * 4 * 64 = 1024 groups
+            const int ln = grp & 63, rq = (grp >> 6) & 3, tile = grp >> 8;
+            const int rb = tile >> 1, cb = tile & 1;
+            f32x4 v[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) v[q] = red[((q * 4 + tile) * 4 + rq) * 64 + ln];
+            const int row0 = rb * 32 + 8 * rq + 4 * (ln >> 5);           // + comp: channel inside the pair's 64
+            g_row[gi] = row0;
+            g_col[gi] = cb * 32 + (ln & 31);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float bv = bias ? bias[m0 + pr * 64 + row0 + e] : 0.f;
+                const float t0 = v[0][e] * -2.f, t1 = v[1][e] * (-2.f / 3.f), t2 = v[2][e] * (-2.f / 9.f), t3 = v[3][e] * (16.f / 9.f),
+                            t4 = v[4][e] * (16.f / 15.f), t5 = v[5][e] * (2.f / 45.f), t6 = v[6][e];
+                const float s12 = t1 + t2, m12 = t1 - t2, s34 = t3 + t4, m34 = t3 - t4;
+                o[gi][e].x = (t0 + s12) + (s34 + t5) + bv;
+                o[gi][e].y = fmaf(0.5f, m34, m12) + fmaf(2.f, t5, bv);
+                o[gi][e].z = fmaf(0.25f, s34, s12) + fmaf(4.f, t5, bv);
+                o[gi][e].w = fmaf(0.125f, m34, m12) + fmaf(8.f, t5, t6) + bv;
+            }
+        }
+        if (direct) {
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) {
+                const int col = g_col[gi];
+                const int64_t t0 = (sb0 + col) * 4;
+                if (col < n_tiles_blk && t0 < L) {
+                    const int64_t base = (int64_t)(m0 + pr * 64 + g_row[gi]) * L + t0;
+                    if (res) {
+                        f32x4 rv[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) rv[e] = *reinterpret_cast<const f32x4 *>(res + base + (int64_t)e * L);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[gi][e] += rv[e];
+                    }
+                    if (accin) {
+                        f32x4 av[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) av[e] = *reinterpret_cast<const f32x4 *>(accin + base + (int64_t)e * L);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[gi][e] += av[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x4 *>(y + base + (int64_t)e * L) = o[gi][e] * out_scale;
+                }
+            }
+            continue;
+        }
+        lds_barrier();                                    // every thread has read its points: the tile may overlay them
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int col = g_col[gi];
+            const int sbl = col / d;
+            const int tl0 = sbl * 4 * d + (col - sbl * d);
+            if (col < n_tiles_blk) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float *dst = yt + (g_row[gi] + e) * YS + tl0;
+                    dst[0] = o[gi][e].x; dst[d] = o[gi][e].y; dst[2 * d] = o[gi][e].z; dst[3 * d] = o[gi][e].w;
+                }
+            }
+        }
+        lds_barrier();
+        if (l4) {   // 16-byte pieces: 64 threads per row, 8 rows per pass
+            constexpr int RPP = W2_NTH / BNT, PASSES = 64 / RPP;
+            const int tq4 = (tid % BNT) * 4, rq = tid / BNT;
+            if (tq4 < n_t) {
+                const int64_t base = (int64_t)(m0 + pr * 64 + rq) * L + t_blk0 + tq4;
+                f32x4 v[PASSES];
+#pragma unroll
+                for (int k = 0; k < PASSES; ++k) v[k] = *reinterpret_cast<const f32x4 *>(yt + (rq + k * RPP) * YS + tq4);
+                if (res) {
+                    f32x4 rv[PASSES];
+#pragma unroll
+                    for (int k = 0; k < PASSES; ++k) rv[k] = *reinterpret_cast<const f32x4 *>(res + base + (int64_t)k * RPP * L);
+#pragma unroll
+                    for (int k = 0; k < PASSES; ++k) v[k] += rv[k];
+                }
+                if (accin) {
+                    f32x4 av[PASSES];
+#pragma unroll
+                    for (int k = 0; k < PASSES; ++k) av[k] = *reinterpret_cast<const f32x4 *>(accin + base + (int64_t)k * RPP * L);
+#pragma unroll
+                    for (int k = 0; k < PASSES; ++k) v[k] += av[k];
+                }
+#pragma unroll
+                for (int k = 0; k < PASSES; ++k) *reinterpret_cast<f32x4 *>(y + base + (int64_t)k * RPP * L) = v[k] * out_scale;
+            }
+        } else {
+            for (int e = tid; e < 64 * 4 * BNT; e += W2_NTH) {
+                const int rq = e / (4 * BNT), tq1 = e - rq * (4 * BNT);
+                if (tq1 >= n_t) continue;
+                const int64_t at = (int64_t)(m0 + pr * 64 + rq) * L + t_blk0 + tq1;
+                float v = yt[rq * YS + tq1];
+                if (res) v += res[at];
+                if (accin) v += accin[at];
+                y[at] = v * out_scale;
+            }
+        }
+    }
+}
+
+template <int KW, int BM>
+static int winobf2_launch(Wbf2Params p, hipStream_t stream) {
+    using GM = W2Geom<KW, BM>;
+    p.sb_per_block = (W2_BNT - (GM::G - 1) * p.dil) / p.dil;   // valid tiles + the (G - 1) d windows behind them <= 64 transformed windows
+    const int64_t n_sb = ceil_div(p.L, (int64_t)4 * p.dil);
+    static std::once_flag once;
+    static hipError_t err = hipSuccess;
+    std::call_once(once, [] {
+        err = hipFuncSetAttribute((const void *)winobf2_conv_kernel<KW, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, GM::LDS_BYTES);
+    });
+    if (err != hipSuccess) return fail("winobf2 conv: cannot reserve %d bytes of LDS: %s", GM::LDS_BYTES, hipGetErrorString(err));
+    p.n_tile_blocks = (int)ceil_div(n_sb, p.sb_per_block);
+    const int n_m = p.c_out / BM;
+    dim3 grid((unsigned)(ceil_div(p.n_tile_blocks, 8) * 8 * n_m), 1, (unsigned)p.batch);
+    hipLaunchKernelGGL((winobf2_conv_kernel<KW, BM>), grid, dim3(W2_NTH), GM::LDS_BYTES, stream, p);
+    RVC_LAUNCH_CHECK();
+    return 0;
+}
+
+// the block rows a layer runs with (its tap fragments are packed for it): 128 where c_out allows, else 64
+int winobf2_block_rows(int c_out) { return c_out % 128 == 0 ? 128 : 64; }
+
+bool winobf2_supported(int c_in, int c_out, int k, int dil) {
+    return (k == 7 || k == 11) && dil >= 1 && dil <= W2_MAX_DIL && c_in % W2_CIC == 0 && c_out % 64 == 0;
+}
+
+bool winobf2_fits(int c_in, int c_out, int64_t L) {
+    return (int64_t)c_in * L < ((int64_t)1 << 29) && (int64_t)c_in * c_out * W2_NP * 3 * 6 < ((int64_t)1 << 31);
+}
+
+int launch_winobf2_conv(const float *x, const void *u, const float *bias, const float *res, const float *accin, float *y, int batch,
+                        int c_in, int c_out, int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream) {
+    if (!winobf2_supported(c_in, c_out, k, dil)) return fail("winobf2 conv: unsupported shape (%d -> %d channels, %d taps, dilation %d)", c_in, c_out, k, dil);
+    if (!(slope >= 0.f && slope <= 1.f)) return fail("winobf2 conv: leaky slope %g outside [0, 1]", (double)slope);
+    if (!winobf2_fits(c_in, c_out, L)) return fail("winobf2 conv: %d x %lld samples exceed the 2 GiB buffer addressing", c_in, (long long)L);
+    if (L <= 0 || batch <= 0) return 0;
+    Wbf2Params p;
+    p.x = x; p.u = u; p.bias = bias; p.res = res; p.accin = accin; p.y = y;
+    p.c_in = c_in; p.c_out = c_out; p.L = L; p.dil = dil; p.slope = slope; p.out_scale = out_scale; p.batch = batch;
+    const bool wide = winobf2_block_rows(c_out) == 128;
+    if (k == 7) return wide ? winobf2_launch<7, 128>(p, stream) : winobf2_launch<7, 64>(p, stream);
+    return wide ? winobf2_launch<11, 128>(p, stream) : winobf2_launch<11, 64>(p, stream);
+}
+
+}  // namespace rvc

@@ -4,6 +4,6 @@
 set -e
 cd "$(dirname "$0")/../.."
 L=codename-rvc-fork-3_amd/rvc_amd/_lib
-F="--offload-arch=gfx950 -O3 -std=c++17 -I include tools/micro/mfma_cohab.hip -L $L -Wl,-rpath,\$ORIGIN/../../$L"
+F="--offload-arch=gfx950 -O3 -std=c++17 -I include -I codename-rvc-fork-3_amd/csrc tools/micro/mfma_cohab.hip -L $L -Wl,-rpath,\$ORIGIN/../../$L"
 /opt/rocm/bin/hipcc $F -lrvc_amd -o tools/micro/mfma_cohab
 /opt/rocm/bin/hipcc $F -l:librvc_amd_ablate.so -o tools/micro/mfma_cohab_ablate

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "rvc_amd.h"
+#include "gemmbf_r03_two_per_cu.inc"   // round 3's first gemmbf_kernel: the original aggressor
 
 #define CK(e)                                                                                  \
     do {                                                                                       \
@@ -43,6 +44,10 @@ __global__ void __launch_bounds__(64 * NWAVES) corunner(float *out, int iters) {
     extern __shared__ float co_lds[];
     const int lane = threadIdx.x & 63;
     if (iters < 0) co_lds[threadIdx.x] = 1.f;   // never: keeps the LDS request alive
+    if (MODE == 3) {
+        for (int i = threadIdx.x; i < 8192; i += blockDim.x) co_lds[i] = 0.001f * (i & 255);
+        __syncthreads();
+    }
     f32x16 acc[4];
     for (int i = 0; i < 4; ++i)
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
@@ -55,6 +60,15 @@ __global__ void __launch_bounds__(64 * NWAVES) corunner(float *out, int iters) {
         if constexpr (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+        } else if constexpr (MODE == 3) {   // gemmbf's inner shape without its memory streams: fragments from LDS, a barrier per 24
+            const unsigned char *l = reinterpret_cast<const unsigned char *>(co_lds) + lane * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x8 la = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(l + ((it + i) & 15) * 1024));
+                const bf16x8 lb = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(l + 16384 + ((it + i) & 15) * 1024));
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la, lb, acc[i], 0, 0, 0);
+            }
+            if ((it % 6) == 5) __syncthreads();
         } else if constexpr (MODE == 1) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[i], 0, 0, 0);
@@ -182,10 +196,6 @@ __global__ void count_diff(const uint32_t *a, const uint32_t *b, size_t n, unsig
     if (local) atomicAdd(count, local);
 }
 
-struct CoRunner {
-    const char *name;
-    void (*launch)(float *, int, size_t, int, hipStream_t);
-};
 template <int MODE, int NW>
 static void launch_co(float *out, int iters, size_t lds, int blocks, hipStream_t st) {
     static bool set = false;
@@ -250,15 +260,47 @@ int main(int argc, char **argv) {
     add_wino("W3 library wino_conv_kernel, 3 taps, C = 64", 64, 3, 200000);
     add_wino("W11 library wino_conv_kernel, 11 taps, C = 128", 128, 11, 60000);
 
-    const CoRunner cos[] = {
-        {"bf16 32x32x16 matrix loop, 4 waves, 60 KB LDS (can share a CU)", launch_co<0, 4>},
-        {"bf16 32x32x16 matrix loop, 4 waves, 100 KB LDS (cannot share)", launch_co<0, 4>},
-        {"fp32 32x32x2 matrix loop, 4 waves, 60 KB LDS (can share)", launch_co<1, 4>},
-        {"packed-fp32 vector loop, 4 waves, 60 KB LDS (can share)", launch_co<2, 4>},
-        {"bf16 32x32x16 matrix loop, 8 waves, 60 KB LDS (can share)", launch_co<0, 8>},
+    // round 3's gemmbf_kernel<1, DBG> (HuBERT conv layer 1: 512 -> 512 channels, 3 taps, stride 2, 51 000 samples in)
+    rvc_r03::GemmBfParams gp;
+    {
+        const int M = 512, Cin = 512, taps = 3;
+        const int64_t Lin = 51000, N = (Lin - taps) / 2 + 1;
+        std::vector<uint16_t> ha((size_t)M * Cin * taps * 3);
+        for (auto &v : ha) { float f = (rand() / (float)RAND_MAX - 0.5f) * 0.06f; uint32_t u; memcpy(&u, &f, 4); v = (uint16_t)(u >> 16); }
+        std::vector<float> hxg((size_t)Cin * Lin);
+        for (auto &v : hxg) v = (rand() / (float)RAND_MAX - 0.5f) * 2.f;
+        void *da; float *dxg, *dyg, *dbg;
+        CK(hipMalloc(&da, ha.size() * 2)); CK(hipMalloc(&dxg, hxg.size() * 4)); CK(hipMalloc(&dyg, (size_t)M * N * 4)); CK(hipMalloc(&dbg, M * 4));
+        CK(hipMemcpy(da, ha.data(), ha.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dxg, hxg.data(), hxg.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemset(dbg, 0, M * 4));
+        gp.a = da; gp.x = dxg; gp.y = dyg; gp.bias = dbg; gp.M = M; gp.K = taps * Cin; gp.c_in = Cin; gp.N = N;
+        gp.x_mode = 1; gp.ldx = Lin; gp.l_in = Lin; gp.stride = 2; gp.dil = 1; gp.pad = 0; gp.y_mode = 1; gp.ldy = N; gp.act = 1; gp.batch = 1;
+        gp.x_bstride = (int64_t)Cin * Lin; gp.y_bstride = (int64_t)M * N;
+        gp.n_col_blocks = (int)((N + rvc_r03::GBF_BN - 1) / rvc_r03::GBF_BN);
+    }
+    auto gemm_co = [&](auto kern, size_t lds) {
+        CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        const int n_m = gp.M / rvc_r03::GBF_BM;
+        const dim3 grid((unsigned)((gp.n_col_blocks + 7) / 8 * 8 * n_m));
+        return std::function<void(hipStream_t)>([=](hipStream_t st) { hipLaunchKernelGGL(kern, grid, dim3(rvc_r03::GBF_NTH), lds, st, gp); });
     };
-    const size_t co_lds[] = {60 * 1024, 100 * 1024, 60 * 1024, 60 * 1024, 60 * 1024};
-    const int co_iters[] = {40000, 40000, 20000, 40000, 40000};
+    auto bare_co = [&](auto launch, int iters, size_t lds) {
+        return std::function<void(hipStream_t)>([=](hipStream_t st) { launch(co_out, iters, lds, 256, st); });   // one block per CU
+    };
+    struct Co { const char *name; std::function<void(hipStream_t)> run; int per4; };
+    const size_t G = rvc_r03::GBF_LDS;
+    const Co cos[] = {
+        {"round-3 gemmbf_kernel<1> (bf16 matrix + LDS-DMA taps + staged activations + barriers), 60 KiB: two per CU or one + a victim block", gemm_co(rvc_r03::gemmbf_kernel<1, 0>, G), 8},
+        {"the same kernel, 100 KB of LDS requested: cannot share a CU with a victim block", gemm_co(rvc_r03::gemmbf_kernel<1, 0>, 100 * 1024), 8},
+        {"the same kernel without its matrix instructions (DBG 2)", gemm_co(rvc_r03::gemmbf_kernel<1, 2>, G), 16},
+        {"the same kernel without tap LDS-DMA (DBG 4)", gemm_co(rvc_r03::gemmbf_kernel<1, 4>, G), 8},
+        {"the same kernel without activation staging (DBG 1)", gemm_co(rvc_r03::gemmbf_kernel<1, 1>, G), 8},
+        {"the same kernel without barriers (DBG 8)", gemm_co(rvc_r03::gemmbf_kernel<1, 8>, G), 8},
+        {"bare bf16 32x32x16 matrix loop, registers only, 4 waves, 60 KB LDS", bare_co(launch_co<0, 4>, 40000, 60 * 1024), 6},
+        {"bare bf16 matrix loop with both fragments re-read from LDS + a barrier per 24 instructions, 4 waves, 60 KB", bare_co(launch_co<3, 4>, 40000, 60 * 1024), 6},
+        {"bare fp32 32x32x2 matrix loop, 4 waves, 60 KB LDS", bare_co(launch_co<1, 4>, 20000, 60 * 1024), 6},
+        {"packed-fp32 vector loop, 4 waves, 60 KB LDS", bare_co(launch_co<2, 4>, 40000, 60 * 1024), 6},
+    };
 
     printf("%d victim launches per cell, compared bit for bit with the same launch made alone; cell = launches with a differing word / words that differ in the worst launch\n", reps);
     const char *only = argc > 2 ? argv[2] : nullptr;   // run only the victims whose name starts with this
@@ -297,7 +339,7 @@ int main(int argc, char **argv) {
             CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
             for (int r = 0; r < reps; ++r) {
                 // keep the co-runner in flight for the whole victim launch: two long grids queued ahead on stream A
-                if (r % 4 == 0) for (int k = 0; k < 6; ++k) cos[ci].launch(co_out, co_iters[ci], co_lds[ci], 256, sa);   // one block per CU
+                if (r % 4 == 0) for (int k = 0; k < cos[ci].per4; ++k) cos[ci].run(sa);
                 CK(hipMemsetAsync(count, 0, 8, sb));
                 CK(hipEventRecord(e0, sb));
                 v.run(sb);
