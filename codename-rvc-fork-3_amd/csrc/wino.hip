@@ -122,6 +122,7 @@ wino_conv_kernel(const WinoParams p) {
     constexpr int NJ = (4 * XT + NTH - 1) / NTH;          // staged samples per thread per channel
 
     extern __shared__ __attribute__((aligned(16))) float wino_smem[];
+    if constexpr (DBG & 1024) __builtin_amdgcn_s_setprio(3);   // ablation: this kernel's waves win every issue arbitration
     f32x2 *us = reinterpret_cast<f32x2 *>(wino_smem);     // [2][UTOT]
     f32x2 *xs = us + 2 * UTOT;                            // [2][XTOT]
 
@@ -369,6 +370,7 @@ wino_conv_kernel(const WinoParams p) {
         }
     }
 
+    if constexpr (DBG & 512) __builtin_amdgcn_s_sleep(20);   // ablation: ~1300 cycles between the last matrix instruction and the first read of an accumulator
     // ---- epilogue: y_i = AT diag(s) D, + bias, + residual, + running sum, * scale ----------------------------------
     const float *bias = p.bias;
     const float *res = p.res ? p.res + (int64_t)b * c_out * L : nullptr;
@@ -555,13 +557,16 @@ static int wino_launch_kw(const WinoParams &p, hipStream_t stream) {
         }
     }
 #ifdef RVC_ABLATE
-    if constexpr (KW == 3) {   // bisection of profiles/r03_mfma_cohabitation.txt (correct results): 64 no LDS-DMA, 128 __syncthreads, 256 s_nop behind the matrix instructions
+    if constexpr (KW == 3) {   // bisection of profiles/r03_mfma_cohabitation.txt (correct results): 64 no LDS-DMA, 128 __syncthreads, 256 s_nop behind the matrix instructions, 512 s_sleep before the epilogue, 1024 s_setprio 3
         static const int fix = knob("RVC_WINO_FIX", 0);
         if (p.c_out % 64 == 0 && !p.u_bf16) switch (fix) {
             case 64: return wino_launch_cfg<3, 2, 2, CIC, 64>(p, stream);
             case 128: return wino_launch_cfg<3, 2, 2, CIC, 128>(p, stream);
             case 192: return wino_launch_cfg<3, 2, 2, CIC, 192>(p, stream);
             case 256: return wino_launch_cfg<3, 2, 2, CIC, 256>(p, stream);
+            case 512: return wino_launch_cfg<3, 2, 2, CIC, 512>(p, stream);
+            case 1024: return wino_launch_cfg<3, 2, 2, CIC, 1024>(p, stream);
+            case 768: return wino_launch_cfg<3, 2, 2, CIC, 768>(p, stream);
             default: break;
         }
     }

@@ -39,10 +39,13 @@ typedef void __attribute__((address_space(3))) *lptr_t;
 
 // ---- co-runners -----------------------------------------------------------------------------------------------------------
 // MODE 0: v_mfma_f32_32x32x16_bf16, 1: v_mfma_f32_32x32x2_f32, 2: v_pk_fma_f32 only.  NWAVES waves, operands in registers.
-template <int MODE, int NWAVES>
+// PAD: 1 touches v143, 2 touches v231 -- the kernel is then allocated 144 / 232 registers per lane like gemmbf / wino
+template <int MODE, int NWAVES, int PAD = 0>
 __global__ void __launch_bounds__(64 * NWAVES) corunner(float *out, int iters) {
     extern __shared__ float co_lds[];
     const int lane = threadIdx.x & 63;
+    if (PAD == 1) asm volatile("v_mov_b32 v143, 0" ::: "v143");
+    if (PAD == 2) asm volatile("v_mov_b32 v231, 0" ::: "v231");
     if (iters < 0) co_lds[threadIdx.x] = 1.f;   // never: keeps the LDS request alive
     if (MODE == 3) {
         for (int i = threadIdx.x; i < 8192; i += blockDim.x) co_lds[i] = 0.001f * (i & 255);
@@ -91,10 +94,11 @@ __global__ void __launch_bounds__(64 * NWAVES) corunner(float *out, int iters) {
 constexpr int MV_CP = 4;                       // channel pairs per chunk (CIC = 8)
 constexpr int MV_U = 3 * MV_CP * 64;           // float2 per tap buffer (6 KiB)
 constexpr int MV_X = 6 * MV_CP * 64;           // float2 per window buffer (12 KiB)
-template <int V>
+template <int V, int PAD = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 micro_victim(const f32x2 *__restrict__ U, const f32x2 *__restrict__ X, float *__restrict__ out, int n_chunks) {
     extern __shared__ __attribute__((aligned(16))) float mv_smem[];
+    if (PAD == 2) asm volatile("v_mov_b32 v231, 0" ::: "v231");   // allocated 232 registers per lane, like wino_conv_kernel
     f32x2 *us = reinterpret_cast<f32x2 *>(mv_smem);    // [2][MV_U]
     f32x2 *xs = us + 2 * MV_U;                         // [2][MV_X]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -196,11 +200,11 @@ __global__ void count_diff(const uint32_t *a, const uint32_t *b, size_t n, unsig
     if (local) atomicAdd(count, local);
 }
 
-template <int MODE, int NW>
+template <int MODE, int NW, int PAD = 0>
 static void launch_co(float *out, int iters, size_t lds, int blocks, hipStream_t st) {
     static bool set = false;
-    if (!set) { CK(hipFuncSetAttribute((const void *)corunner<MODE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)); set = true; }
-    hipLaunchKernelGGL((corunner<MODE, NW>), dim3(blocks), dim3(64 * NW), lds, st, out, iters);
+    if (!set) { CK(hipFuncSetAttribute((const void *)corunner<MODE, NW, PAD>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)); set = true; }
+    hipLaunchKernelGGL((corunner<MODE, NW, PAD>), dim3(blocks), dim3(64 * NW), lds, st, out, iters);
 }
 
 int main(int argc, char **argv) {
@@ -219,6 +223,7 @@ int main(int argc, char **argv) {
         std::function<void(hipStream_t)> run;
         float *out;
         size_t n_out;
+        int rows = 0;     // library victims: output is [rows][n_out / rows]
     };
     std::vector<Victim> victims;
     // micro victims
@@ -241,6 +246,7 @@ int main(int argc, char **argv) {
     add_micro("V1 bare fp32 matrix loop from LDS (plain loads, __syncthreads)", micro_victim<1>);
     add_micro("V2 V1 + packed-fp32 transforms behind the matrix instructions", micro_victim<2>);
     add_micro("V3 V2 + LDS-DMA taps, vmcnt(0) + LDS-only barrier (wino.hip's skeleton)", micro_victim<3>);
+    add_micro("V4 V3 allocated 232 registers per lane (wino_conv_kernel's count)", micro_victim<3, 2>);
     // the library's wino kernel
     auto add_wino = [&](const char *name, int C, int K, int64_t L) {
         std::vector<float> w((size_t)C * C * K), x((size_t)C * L), bias(C);
@@ -255,7 +261,7 @@ int main(int argc, char **argv) {
         if (rvc_conv1d_wino_pack_weight(w.data(), C, C, K, u, nullptr)) { fprintf(stderr, "pack: %s\n", rvc_last_error()); exit(1); }
         victims.push_back({name, [=](hipStream_t st) {
             if (rvc_conv1d_wino_forward(dx, u, db, dres, nullptr, y, 1, C, C, L, K, 1, 0.1f, 1.f, st)) { fprintf(stderr, "wino: %s\n", rvc_last_error()); exit(1); }
-        }, y, (size_t)C * L});
+        }, y, (size_t)C * L, C});
     };
     add_wino("W3 library wino_conv_kernel, 3 taps, C = 64", 64, 3, 200000);
     add_wino("W11 library wino_conv_kernel, 11 taps, C = 128", 128, 11, 60000);
@@ -297,6 +303,9 @@ int main(int argc, char **argv) {
         {"the same kernel without activation staging (DBG 1)", gemm_co(rvc_r03::gemmbf_kernel<1, 1>, G), 8},
         {"the same kernel without barriers (DBG 8)", gemm_co(rvc_r03::gemmbf_kernel<1, 8>, G), 8},
         {"bare bf16 32x32x16 matrix loop, registers only, 4 waves, 60 KB LDS", bare_co(launch_co<0, 4>, 40000, 60 * 1024), 6},
+        {"the same bare bf16 matrix loop allocated 144 registers per lane (gemmbf's count)", bare_co(launch_co<0, 4, 1>, 40000, 60 * 1024), 6},
+        {"the same bare bf16 matrix loop allocated 232 registers per lane", bare_co(launch_co<0, 4, 2>, 40000, 60 * 1024), 6},
+        {"packed-fp32 vector loop allocated 144 registers per lane", bare_co(launch_co<2, 4, 1>, 40000, 60 * 1024), 6},
         {"bare bf16 matrix loop with both fragments re-read from LDS + a barrier per 24 instructions, 4 waves, 60 KB", bare_co(launch_co<3, 4>, 40000, 60 * 1024), 6},
         {"bare fp32 32x32x2 matrix loop, 4 waves, 60 KB LDS", bare_co(launch_co<1, 4>, 20000, 60 * 1024), 6},
         {"packed-fp32 vector loop, 4 waves, 60 KB LDS", bare_co(launch_co<2, 4>, 40000, 60 * 1024), 6},
@@ -351,6 +360,32 @@ int main(int argc, char **argv) {
                 float ms;
                 CK(hipEventElapsedTime(&ms, e0, e1));
                 t_with += ms;
+                if (h != 0 && bad == 0 && v.rows > 0) {   // first differing launch of a library victim: where are the wrong words?
+                    std::vector<float> ho(v.n_out), hr(v.n_out);
+                    CK(hipMemcpy(ho.data(), v.out, v.n_out * 4, hipMemcpyDeviceToHost));
+                    CK(hipMemcpy(hr.data(), ref, v.n_out * 4, hipMemcpyDeviceToHost));
+                    const size_t L = v.n_out / v.rows;
+                    size_t n_bad = 0, t_lo = L, t_hi = 0;
+                    int r_lo = v.rows, r_hi = -1;
+                    std::vector<int> per_row(v.rows, 0);
+                    for (int r = 0; r < v.rows; ++r)
+                        for (size_t t = 0; t < L; ++t)
+                            if (memcmp(&ho[r * L + t], &hr[r * L + t], 4)) {
+                                ++n_bad; ++per_row[r];
+                                if (t < t_lo) t_lo = t;
+                                if (t > t_hi) t_hi = t;
+                                if (r < r_lo) r_lo = r;
+                                if (r > r_hi) r_hi = r;
+                            }
+                    printf("    first differing launch: %zu words in rows %d..%d, t %zu..%zu; per row:", n_bad, r_lo, r_hi, t_lo, t_hi);
+                    for (int r = r_lo; r <= r_hi && r < r_lo + 70; ++r) printf(" %d", per_row[r]);
+                    printf("\n    samples (row, t, got, want):");
+                    int shown = 0;
+                    for (int r = r_lo; r <= r_hi && shown < 12; ++r)
+                        for (size_t t = t_lo; t <= t_hi && shown < 12; ++t)
+                            if (memcmp(&ho[r * L + t], &hr[r * L + t], 4)) { printf(" (%d, %zu, %.6g, %.6g)", r, t, ho[r * L + t], hr[r * L + t]); ++shown; t += 37; }
+                    printf("\n");
+                }
                 bad += h != 0;
                 if (h > worst) worst = h;
             }
