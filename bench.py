@@ -46,15 +46,20 @@ for p in (ROOT, os.path.join(ROOT, "codename-rvc-fork-3_amd")):
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = FP32 vector peak
 PEAK_F16_MFMA_TFLOPS = 2500.0   # dense fp16/bf16 MFMA
 PEAK_HBM_GBS = 8000.0           # HBM3E spec
-PMC_BF_BYTES = 467.2e6          # profiles/r03_pmc_winobf.txt
-# average HBM bytes per launch of the roofline kernel symbol at the cfg-2 shape, from the PMC passes committed under
-# profiles/ (cannot be collected inside bench.py: it needs rocprofv3)
-PMC_TRAFFIC = {
-    "bf16x3": (PMC_BF_BYTES, "profiles/r03_pmc_winobf.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
-               "tools/pmc_conv.py (this same 18-launch mix of winobf_conv_kernel<11,0,*,*>, tools/pmc_wino.sh), average per launch; "
-               "FETCH_SIZE calibrated per access width on launches with known byte counts"),
-    "fp32": (446.9e6, "profiles/r02_pmc_wino.txt (round 2, wino_conv_kernel<11,2,2,8,0,false>: same bytes by construction as <...,false,4>)"),
-}
+
+
+def pmc_traffic(symbol_key):
+    """Average HBM bytes per launch of the roofline kernel symbol at the cfg-2 shape, from the rocprofv3 PMC passes committed
+    under profiles/ (they cannot be collected inside bench.py: that needs rocprofv3).  The figure lives in a JSON file next to
+    the raw CSVs, written by tools/summarize_pmc.py -- not in this script."""
+    path = os.path.join(ROOT, "profiles", f"pmc_{symbol_key}.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        return float(d["bytes_per_launch"]), f"profiles/pmc_{symbol_key}.json: " + d.get("source", "")
+    except (OSError, ValueError, KeyError):
+        return None, None
+
 
 CONFIGS = {
     1: dict(seconds=10.0, sr=40000, vocoder="HiFi-GAN", index_rows=0, index_rate=0.0, weights="f32",
@@ -108,36 +113,34 @@ def cpu_model_string():
 
 
 # ---- roofline legs ----------------------------------------------------------------------------------------------------
-def roofline_mix(torch, native, dev, T, rates, k=11):
-    """Every launch of the dominant kernel symbol in one utterance's vocoder forward: the 11-tap ResBlock of stages 0-2
-    (C = 256, 128, 64; the C = 32 stage takes the fp32 1 x 4-wave symbol), per stage and for each dilation d: conv1
-    (dilation d) then conv2 (dilation 1, + residual; the last one also + running sum, x 1/3) -- 18 launches, the same
-    population rocprofv3 --stats averages over for that kernel.  The kernel is winobf_conv_kernel<11,0,BM,BNT> (Winograd F(4,4)
-    on the bf16 matrix cores, fp32 operands split exactly into three bf16; two block shapes = two symbols in a trace:
-    <11,0,128,64> for the six C = 256 launches, <11,0,64,128> for the twelve C = 128 / 64 ones) unless RVC_WINOBF=0 / RVC_WINO=0 selects the round-2
-    form wino_conv_kernel<11,2,2,8,0,false,4> (fp32 matrix instruction).
-    Returns (callable, algorithmic flops per call, launches per call, algorithmic HBM bytes per call, executed flops, form)."""
+def roofline_mix(torch, native, dev, T, rates, weights, k=11):
+    """Every launch of the dominant kernel symbol in one utterance's vocoder forward: rvc::winobf2_conv_kernel<11,128,0>
+    (winobf2.hip: Winograd F(4,4) on the bf16 matrix cores, fp32 operands split exactly into three bf16, one transform point per
+    wave), i.e. the 11-tap ResBlock convs of vocoder stages 0 and 1 (C = 256, 128; the C = 64 stage runs winobf.hip's 64 x 128
+    blocks, the C = 32 stage the fp32 kernels), per stage and for each dilation d: conv1 (dilation d) then conv2 (dilation 1,
+    + residual; the last one also + running sum, x 1/3) -- 12 launches, the population rocprofv3 --stats averages over for that
+    symbol.  `weights` = "bf16" (BASELINE cfg 4) rounds the taps to bf16 first, as the decoder handle with bf16 weight storage
+    does: the transformed taps are then fragments of bf16-VALUED taps, the kernel and its arithmetic are the same.
+    Returns (callable, algorithmic flops per call, launches per call, algorithmic HBM bytes per call, executed flops)."""
     gen = torch.Generator().manual_seed(1)
     stages, flops, executed, alg_bytes = [], 0.0, 0.0, 0.0
-    form = "bf16x3" if os.environ.get("RVC_WINOBF", "1") != "0" and os.environ.get("RVC_WINO", "1") != "0" else "fp32"
-    # multiply-adds executed per 4 outputs and (c_in, c_out) pair: F(4,4) -- 7 points per group of four taps; the bf16x3 form
-    # spends six bf16 products on each
-    points = 7 * ((k + 3) // 4)
-    per_mac = 6 if form == "bf16x3" else 1
-    pack = native.conv1d_winobf_pack_weight if form == "bf16x3" else native.conv1d_wino_pack_weight
-    fwd = native.conv1d_winobf_forward if form == "bf16x3" else native.conv1d_wino_forward
+    points = 7 * ((k + 3) // 4)     # multiply-adds executed per 4 outputs and (c_in, c_out) pair: 7 points per group of four taps
+    per_mac = 6                     # bf16 products per fp32 multiply-add of the split form
     L = T
-    for i in range(3):
+    for i in range(2):
         C, L = 512 >> (i + 1), L * rates[i]
         x = torch.randn(1, C, L, device=dev)
+        w1, w2 = torch.randn(C, C, k, generator=gen) * 0.02, torch.randn(C, C, k, generator=gen) * 0.02
+        if weights == "bf16":
+            w1, w2 = w1.bfloat16().float(), w2.bfloat16().float()
         st = dict(C=C, x=x, t1=torch.empty_like(x), y=torch.randn(1, C, L, device=dev), acc=torch.randn(1, C, L, device=dev),
-                  w1=pack(torch.randn(C, C, k, generator=gen) * 0.02, dev), w2=pack(torch.randn(C, C, k, generator=gen) * 0.02, dev),
-                  bias=torch.zeros(C, device=dev))
+                  w1=native.conv1d_winobf_pack_weight(w1, dev), w2=native.conv1d_winobf_pack_weight(w2, dev), bias=torch.zeros(C, device=dev))
         stages.append(st)
         flops += 6 * 2.0 * C * C * k * L                          # SURVEY 8d: 2 x MACs of the conv as the reference computes it
         executed += 6 * 2.0 * C * C * points * (L / 4.0) * per_mac
         tensor = C * L * 4.0
         alg_bytes += 3 * (2 * tensor) + 2 * (3 * tensor) + 1 * (4 * tensor)   # conv1: r+w; conv2: r+res+w (+acc)
+    fwd = native.conv1d_winobf_forward
 
     def run():
         for st in stages:
@@ -148,7 +151,7 @@ def roofline_mix(torch, native, dev, T, rates, k=11):
                     fwd(st["t1"], st["w2"], st["bias"], C, k, 1, 0.1, res=st["x"], out=st["y"])
                 else:
                     fwd(st["t1"], st["w2"], st["bias"], C, k, 1, 0.1, res=st["x"], acc=st["acc"], out_scale=1 / 3, out=st["y"])
-    return run, flops, 18, alg_bytes, executed, form
+    return run, flops, 12, alg_bytes, executed
 
 
 def decoder_flops(T, rates, ksizes, c0=512, cin=192, res_k=(3, 7, 11), n_dil=3):
@@ -319,7 +322,10 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32 (vocoder 7/11-tap convs: fp32 operands as exact bf16x3 splits on the bf16 matrix cores, fp32 accumulate)" if os.environ.get("RVC_WINOBF", "1") != "0" else "f32",
+        "dtype": ("f32 activations x bf16-stored vocoder taps (7/11-tap convs: bf16x3 Winograd fragments of the bf16-valued taps on the bf16 "
+                  "matrix cores, fp32 accumulate; 3-tap and 32-channel layers: fp32 matrix instruction on taps widened from bf16)")
+                 if cfg["weights"] == "bf16" else
+                 "f32 (vocoder 7/11-tap convs: fp32 operands as exact bf16x3 splits on the bf16 matrix cores, fp32 accumulate)",
         "data": "synthetic (seeded random-init weights, FM-tone utterances, clustered index)",
         "rtf": round(value / sr, 2),
         "headline_is": "inputs resident in HBM, waveform left in HBM (the bench contract's definition of `value`); `host_io` is the "
@@ -409,7 +415,7 @@ def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev, utterance):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     # ---- dominant kernel symbol: the 11-tap ResBlock convs of stages 0-2 ----
-    run_mix, mix_flops, mix_launches, mix_alg_bytes, mix_executed, form = roofline_mix(torch, _native, dev, T, rates)
+    run_mix, mix_flops, mix_launches, mix_alg_bytes, mix_executed = roofline_mix(torch, _native, dev, T, rates, cfg["weights"])
     for _ in range(2):
         run_mix()
     reps = 5
@@ -420,39 +426,29 @@ def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev, utterance):
     torch.cuda.synchronize()
     t_launch = e0.elapsed_time(e1) / (reps * mix_launches) * 1e-3
     flops_launch = mix_flops / mix_launches
-    cfg2 = T == 3198 and list(rates[:3]) == [12, 10, 2]
+    cfg2 = T == 3198 and list(rates[:2]) == [12, 10]
     exe_launch = mix_executed / mix_launches
-    shapes = (f"the 11-tap ResBlock convs of vocoder stages 0-2 (C=256/128/64 at {T * rates[0]}/{T * rates[0] * rates[1]}/"
-              f"{T * rates[0] * rates[1] * rates[2]} columns), in the decoder's own mix (dilations 1/3/5, residual on every second "
-              "one); per-launch figures are averages over the 18")
-    traffic, traffic_src = PMC_TRAFFIC[form] if cfg2 else (None, None)
-    common = {"traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(mix_alg_bytes / mix_launches),
-              "algorithmic_flops_per_launch": flops_launch, "executed_flops_per_launch": exe_launch,
-              "algorithmic_tflops": round(flops_launch / t_launch / 1e12, 2),
-              "algorithmic_vs_fp32_mfma_peak": round(flops_launch / t_launch / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-              "avg_launch_ms": round(t_launch * 1e3, 4), "launches_per_utterance": mix_launches,
-              "timing": "HIP events around the isolated launch mix on the launch stream (nothing else running); rocprofv3 --stats "
-                        "agrees for a sequential run (profiles/); with two utterances in flight a kernel's traced duration also "
-                        "contains the time it shares the chip"}
-    if form == "bf16x3":
-        res["roofline"] = {
-            "kernel": "rvc::winobf_conv_kernel<11,0,BM,BNT>: ALL 18 launches per utterance of this kernel (block shape 128 x 64 for the 6 "
-                      "C=256 launches, 64 x 128 for the 12 C=128/64 ones: two symbols in a trace) -- " + shapes,
-            "bound": "mfma", "achieved": round(exe_launch / t_launch / 1e12, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(exe_launch / t_launch / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
-            "achieved_is": "bf16 matrix flops the kernel EXECUTES / launch time, against the dense bf16 MFMA peak: the pipe's own "
-                           "occupancy.  One fp32 multiply-add of the Winograd F(4,4) form (7 * 3 / (4 * 11) = 0.477 of the conv's "
-                           "multiply-adds) costs six bf16 products (fp32 operands split exactly into three bf16, fp32 accumulate); "
-                           "the SURVEY 8d ALGORITHMIC rate (2 x MACs of the 11-tap conv / time) is algorithmic_tflops, "
-                           "i.e. algorithmic_vs_fp32_mfma_peak x the 157.3 TF an fp32-matrix-instruction kernel could reach",
-            **common}
-    else:
-        res["roofline"] = {
-            "kernel": "rvc::wino_conv_kernel<11,2,2,8,0,false,4>: ALL 18 launches per utterance of this symbol -- " + shapes,
-            "bound": "mfma", "achieved": round(exe_launch / t_launch / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(exe_launch / t_launch / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-            "achieved_is": "fp32 matrix flops the kernel EXECUTES (Winograd F(4,4): 0.477 of the conv's multiply-adds) / launch time",
-            **common}
+    traffic, traffic_src = pmc_traffic("winobf2_k11") if cfg2 else (None, None)
+    res["roofline"] = {
+        "kernel": "rvc::winobf2_conv_kernel<11,128,0>: ALL 12 launches per utterance of this symbol -- the 11-tap ResBlock convs of vocoder "
+                  f"stages 0-1 (C=256/128 at {T * rates[0]}/{T * rates[0] * rates[1]} columns) in the decoder's own mix (dilations 1/3/5, "
+                  "residual on every second one); per-launch figures are averages over the 12"
+                  + ("; taps rounded to bf16 first, as the bf16-storage decoder handle holds them" if cfg["weights"] == "bf16" else ""),
+        "bound": "mfma", "achieved": round(exe_launch / t_launch / 1e12, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(exe_launch / t_launch / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+        "achieved_is": "bf16 matrix flops the kernel EXECUTES / launch time, against the dense bf16 MFMA peak: the pipe's own "
+                       "occupancy.  One fp32 multiply-add of the Winograd F(4,4) form (7 * 3 / (4 * 11) = 0.477 of the conv's "
+                       "multiply-adds) costs six bf16 products (fp32 operands split exactly into three bf16, fp32 accumulate); "
+                       "the SURVEY 8d ALGORITHMIC rate (2 x MACs of the 11-tap conv / time) is algorithmic_tflops, "
+                       "i.e. algorithmic_vs_fp32_mfma_peak x the 157.3 TF an fp32-matrix-instruction kernel could reach",
+        "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(mix_alg_bytes / mix_launches),
+        "algorithmic_flops_per_launch": flops_launch, "executed_flops_per_launch": exe_launch,
+        "algorithmic_tflops": round(flops_launch / t_launch / 1e12, 2),
+        "algorithmic_vs_fp32_mfma_peak": round(flops_launch / t_launch / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+        "avg_launch_ms": round(t_launch * 1e3, 4), "launches_per_utterance": mix_launches,
+        "timing": "HIP events around the isolated launch mix on the launch stream (nothing else running); rocprofv3 --stats "
+                  "agrees for a sequential run (profiles/); with two utterances in flight a kernel's traced duration also "
+                  "contains the time it shares the chip"}
     del run_mix
 
     # ---- whole vocoder, timed with events around rvc_decoder_forward ----

@@ -88,9 +88,8 @@ int winobf_pack_weight(const float *w_host, int c_out, int c_in, int k, void **o
 int launch_winobf_conv(const float *x, const void *u, const float *bias, const float *res, const float *accin, float *y, int batch,
                        int c_in, int c_out, int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream);
 // ... with one transform point per wave (winobf2.hip): the form launch_winobf_conv takes unless the ablation build's
-// RVC_WBF_V2=0 asks for winobf.hip's own kernel; same fragments, packed at winobf2_block_rows(c_out) rows per block
+// RVC_WBF_V2=0 asks for winobf.hip's own kernel; takes c_out % 128 == 0 layers, fragments packed point-major
 bool winobf2_enabled();
-int winobf2_block_rows(int c_out);
 bool winobf2_supported(int c_in, int c_out, int k, int dil);
 int launch_winobf2_conv(const float *x, const void *u, const float *bias, const float *res, const float *accin, float *y, int batch,
                         int c_in, int c_out, int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream);

@@ -589,8 +589,11 @@ bool winobf2_enabled() {
     return on != 0;
 }
 
+// does this layer take winobf2.hip's form (its fragments are then packed point-major at 128 rows per block)?
+static bool winobf_takes_v2(int c_in, int c_out, int k) { return winobf2_enabled() && winobf2_supported(c_in, c_out, k, 1); }
+
 int winobf_block_rows(int c_out, int k) {
-    if (winobf2_enabled()) return winobf2_block_rows(c_out);   // the fragments are packed for the kernel that will read them
+    if (winobf2_enabled() && c_out % 128 == 0) return 128;   // the fragments are packed for the kernel that will read them
     static const int wide = knob("RVC_WBF_BM128", 1);
     if (!wide || c_out % 128) return 64;
     return (k == 7 || c_out >= 256 || wide == 2) ? 128 : 64;
@@ -612,7 +615,7 @@ int launch_winobf_conv(const float *x, const void *u, const float *bias, const f
     if (!(slope >= 0.f && slope <= 1.f)) return fail("winobf conv: leaky slope %g outside [0, 1]", (double)slope);
     if (!winobf_fits(c_in, c_out, L)) return fail("winobf conv: %d x %lld samples exceed the 2 GiB buffer addressing", c_in, (long long)L);
     if (L <= 0 || batch <= 0) return 0;
-    if (winobf2_enabled()) return launch_winobf2_conv(x, u, bias, res, accin, y, batch, c_in, c_out, L, k, dil, slope, out_scale, stream);
+    if (winobf_takes_v2(c_in, c_out, k)) return launch_winobf2_conv(x, u, bias, res, accin, y, batch, c_in, c_out, L, k, dil, slope, out_scale, stream);
     WinoBfParams p;
     p.x = x; p.u = u; p.bias = bias; p.res = res; p.accin = accin; p.y = y;
     p.c_in = c_in; p.c_out = c_out; p.L = L; p.dil = dil; p.slope = slope; p.out_scale = out_scale; p.batch = batch;
@@ -649,6 +652,7 @@ int launch_winobf_conv(const float *x, const void *u, const float *bias, const f
 void winobf_pack_host(const float *w_host, int c_out, int c_in, int k, std::vector<uint16_t> *out) {
     const int BM = winobf_block_rows(c_out, k), WM = BM / 32;
     const int G = (k + 3) / 4, n_chunks = c_in / WBF_CIC, n_m = c_out / BM;
+    const bool point_major = winobf_takes_v2(c_in, c_out, k);
     out->assign((size_t)c_out * c_in * WBF_NP * G * 3, 0);
     auto split3 = [](float v, uint16_t s[3]) {
         float r = v;
@@ -686,7 +690,8 @@ void winobf_pack_host(const float *w_host, int c_out, int c_in, int k, std::vect
                                 }
                                 uint16_t s[3];
                                 split3((float)u, s);
-                                const size_t step = ((size_t)mb * n_chunks + c) * WBF_NP + pt;
+                                // this kernel walks (chunk, point); winobf2.hip's waves each own a point and walk its chunks
+                                const size_t step = point_major ? ((size_t)mb * WBF_NP + pt) * n_chunks + c : ((size_t)mb * n_chunks + c) * WBF_NP + pt;
                                 for (int sp = 0; sp < 3; ++sp) {
                                     const size_t piece = ((step * G + g) * WM + mi) * 3 + sp;
                                     (*out)[piece * 512 + lane * 8 + e] = s[sp];

@@ -39,7 +39,7 @@ namespace rvc {
 
 struct Wbf2Params {
     const float *x = nullptr;        // [batch][c_in][L]
-    const void *u = nullptr;         // winobf_pack_host's slab at winobf2_block_rows(c_out) rows per block
+    const void *u = nullptr;         // winobf_pack_host's slab in its point-major form (128 rows per block)
     const float *bias = nullptr;     // [c_out]
     const float *res = nullptr;      // [batch][c_out][L] or null
     const float *accin = nullptr;    // [batch][c_out][L] or null
@@ -88,7 +88,7 @@ struct W2Geom {
     static constexpr int MLO = -((C0 + 3) / 4);
     static_assert(6 - C0 < 4 && 6 - C0 >= 0, "the window's last sample lies in its own super-block");
     static constexpr int WM = BM / 32, WN = W2_BNT / 32;
-    static constexpr int XT = W2_BNT + (-MLO) * W2_MAX_DIL;             // raw tiles per row: 64 windows + the -MLO d tiles in front
+    static constexpr int XT = W2_BNT + (G - 1 - MLO) * W2_MAX_DIL;      // raw tiles per row: 64 + (G - 1) d windows + the -MLO d tiles in front
     static constexpr int XTS = ((XT - 12 + 31) / 32) * 32 + 12;          // row stride in float2, == 12 mod 32 (ds_write_b64 of 4 rows: 4 bank groups)
     static_assert(XTS >= XT + 2, "");
     static constexpr int RAW_BYTES = W2_CP * 4 * XTS * 8;               // one raw chunk; two buffers
@@ -143,6 +143,17 @@ winobf2_conv_kernel(const Wbf2Params p) {
     const int c_in = p.c_in, c_out = p.c_out;
     const int n_chunks = c_in / CIC;
     const bool loader = wave == NP;
+    // DBG & 128 (ablation build): wave 0 and the loader write s_memtime stamps to the buffer passed as `accin` (which is then NOT
+    // added): [block][wave 0 | loader][32] -- tools/stamp_winobf2.py turns them into a per-phase breakdown
+    unsigned long long *const stamps = (DBG & 128) ? reinterpret_cast<unsigned long long *>(const_cast<float *>(p.accin)) + ((size_t)blockIdx.x * 2 + (loader ? 1 : 0)) * 32 : nullptr;
+    int n_stamp = 0;
+    auto stamp = [&]() __attribute__((always_inline)) {
+        if constexpr (DBG & 128) {
+            if ((wave == 0 || loader) && lane == 0 && n_stamp < 32) stamps[n_stamp] = __builtin_readcyclecounter();
+            ++n_stamp;
+        }
+    };
+    stamp();
 
     f32x16 acc[WM][2];
 #pragma unroll
@@ -153,64 +164,162 @@ winobf2_conv_kernel(const Wbf2Params p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (loader) {
-        // ================================ wave 7: raw input rows, two chunks ahead =========================================
+        // ================================ wave 7: raw input rows, and the halo windows ========================================
+        // (a) stages the raw rows: chunk c + 3 is FETCHED during phase c (into registers), chunk c + 2 -- fetched a phase earlier --
+        //     is written to LDS buffer c & 1 at the start of phase c.  Fetch and write in the same phase made this wave the slowest
+        //     of the block (two serial HBM round trips; and a wave holds at most 63 loads in flight, so 160 one-dword loads per
+        //     chunk were three round trips whatever the order): rows are fetched 16 bytes per lane where L % 4 == 0.
+        // (b) transforms the (G - 1) d windows BEHIND the block's 64: column `col` of tap group g reads window col + g d, so with
+        //     windows 64 .. 63 + (G - 1) d present all 64 accumulator columns are valid outputs -- 64 / d super-blocks per block
+        //     instead of (64 - (G - 1) d) / d.  At 383 760 columns and d = 1 that is 1500 blocks = 5.9 rounds of the 256 CUs instead
+        //     of 1548 = 6.05, i.e. six rounds instead of seven.  This wave has the time: one lane per (window, point, two channel
+        //     pairs), <= 280 items = five rounds of what a compute wave does four of.
+        // This wave shares its SIMD with compute wave 3 and, being the youngest, loses every issue arbitration to it: measured, its
+        // ~650 instructions per phase took longer than the compute waves' whole phase.  Its work is small and on the block's
+        // critical path (the barrier), so it gets the SIMD's issue slots first.
+        __builtin_amdgcn_s_setprio(2);
         const float *const px = p.x + (int64_t)b * c_in * L;
         const float slope = p.slope;
+        const int E = (G - 1) * d;                                     // halo windows
         const int xt_used = (p.sb_per_block + G - 1 - MLO) * d;      // valid tiles + the (G - 1) d windows behind them + the -MLO d in front
         const int64_t t_start = (sb0 + MLO) * 4 * d;
-        const int span = 4 * xt_used;
+        const int span = 4 * xt_used;                                  // staged samples per row (a multiple of 4, <= 4 XT)
         const bool edge = t_start < 0 || t_start + span > L;
         const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)px, 0, (int)((int64_t)c_in * L * 4), W2_RSRC_FLAGS);
         const int L4 = (int)(L * 4);
-        unsigned goff[NJ];
-        int loff[NJ];
-        unsigned keep[NJ];
+        // (the row width is decided ONCE, outside everything: a runtime `wide` test around each load makes hipcc wait for every load on its own)
+        auto run = [&](auto WIDE, auto EDGE) __attribute__((always_inline)) {
+        constexpr bool wide = decltype(WIDE)::value, edge_c = decltype(EDGE)::value;   // edge_c: some staged samples are conv padding (first / last blocks of a row)                   // rows 16-byte aligned: lane = 4 consecutive samples
+        // plan: slot k < NS of a row is one sample; wide: slots 0..3 = samples 4 lane .. 4 lane + 3 (one 16-byte load), then
+        // one-dword slots for samples 256 + lane, 320 + lane, ...; narrow: slot k = sample lane + 64 k
+        constexpr int NS_W = 4 + (4 * XT - 256 + 63) / 64, NS_N = NJ, NS = NS_W > NS_N ? NS_W : NS_N;
+        unsigned goff[NS];    // byte offset of the slot's (first) sample in a row, clamped into the row
+        int loff[NS];
+        unsigned keep[NS];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int tl = lane + j * 64;
-            const bool have = tl < span;
+        for (int k = 0; k < NS; ++k) {
+            const int tl = wide ? (k < 4 ? 4 * lane + k : 256 + 64 * (k - 4) + lane) : lane + 64 * k;
+            const bool have = tl < span && (wide ? k < NS_W : k < NS_N);
             const int tlc = have ? tl : 0;
             const int64_t t = t_start + tlc;
             const int64_t tc = t < 0 ? 0 : (t >= L ? L - 1 : t);
-            goff[j] = (unsigned)tc * 4u;
+            goff[k] = (unsigned)tc * 4u;
             const int sbl = tlc / (4 * d);
             const int r = tlc - sbl * 4 * d;
             const int ii = r / d;
             const int phi = r - ii * d;
-            loff[j] = have ? ii * XTS + sbl * d + phi : XT + (lane & 1);   // columns >= XT of a row are never read
-            keep[j] = (!edge || (t >= 0 && t < L)) ? 0xffffffffu : 0u;      // conv zero padding
+            loff[k] = have ? ii * XTS + sbl * d + phi : XT + (lane & 1);   // columns >= XT of a row are never read
+            keep[k] = (!edge || (t >= 0 && t < L)) ? 0xffffffffu : 0u;      // conv zero padding
         }
-        auto stage = [&](int c) __attribute__((always_inline)) {
-            w2_f32x2 *const dst0 = xs + (c & 1) * XRAW;
+        if constexpr (wide) {   // the 16-byte load of slots 0..3 starts at slot 0's sample; a group of four lies wholly inside or outside the row
+            const int64_t t0 = t_start + 4 * lane;
+            goff[0] = (unsigned)(t0 < 0 ? 0 : (t0 > L - 4 ? L - 4 : t0)) * 4u;
+        }
+        float xr[2 * CP][NS];                                         // [row of the chunk][slot]
+        auto load = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {                 // four channel pairs at a time: 40 loads in flight
-                w2_f32x2 xr[4 * NJ];
+            for (int row = 0; row < 2 * CP; ++row) {
+                const int s0 = (c * CIC + row) * L4;
+                if constexpr (wide) {
+                    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)goff[0], s0, 0));
+                    xr[row][0] = v.x; xr[row][1] = v.y; xr[row][2] = v.z; xr[row][3] = v.w;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int s0 = (c * CIC + 2 * (h * 4 + q)) * L4;
+                    for (int k = 4; k < NS_W; ++k) xr[row][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)goff[k], s0, 0));
+                } else {
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        xr[q * NJ + j] = w2_f32x2{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)goff[j], s0, 0)),
-                                                  __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)goff[j], s0 + L4, 0))};
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    w2_f32x2 *const dst = dst0 + (h * 4 + q) * 4 * XTS;
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        const w2_f32x2 v = w2_lrelu2(xr[q * NJ + j], slope);
-                        dst[loff[j]] = w2_f32x2{__uint_as_float(__float_as_uint(v.x) & keep[j]), __uint_as_float(__float_as_uint(v.y) & keep[j])};
-                    }
+                    for (int k = 0; k < NS_N; ++k) xr[row][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)goff[k], s0, 0));
                 }
             }
         };
-        stage(0);
+        auto write = [&](int c) __attribute__((always_inline)) {
+            w2_f32x2 *const dst0 = xs + (c & 1) * XRAW;
+#pragma unroll
+            for (int q = 0; q < CP; ++q) {
+                w2_f32x2 *const dst = dst0 + q * 4 * XTS;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    if (wide ? k >= NS_W : k >= NS_N) continue;
+                    const w2_f32x2 v = w2_lrelu2(w2_f32x2{xr[2 * q][k], xr[2 * q + 1][k]}, slope);
+                    if constexpr (edge_c) dst[loff[k]] = w2_f32x2{__uint_as_float(__float_as_uint(v.x) & keep[k]), __uint_as_float(__float_as_uint(v.y) & keep[k])};
+                    else dst[loff[k]] = v;
+                }
+            }
+        };
+        // halo windows: item = lane + 64 r -> (window 64 + e, point hp, unit hu = channel pairs 2 hu, 2 hu + 1)
+        constexpr int HR = ((G - 1) * W2_MAX_DIL * 28 + 63) / 64;
+        int h_src[HR], h_dst[HR];
+        float hbt[HR][7];
+        bool h_on[HR];
+#pragma unroll
+        for (int r = 0; r < HR; ++r) {
+            const int it = lane + 64 * r;
+            h_on[r] = it < E * 28;
+            const int itc = h_on[r] ? it : 0;
+            const int e = itc / 28, rem = itc - e * 28, hp = rem >> 2, hu = rem & 3;
+            h_src[r] = (2 * hu) * 4 * XTS - MLO * d + BNT + e;
+            h_dst[r] = hp * 2 * GM::B_WAVE + (hu >> 1) * GM::B_PLANE + (BNT + e) * 16 + (hu & 1) * 8;
+#pragma unroll
+            for (int n = 0; n < 7; ++n) hbt[r][n] = W2_BT[hp][n];
+        }
+        auto halo = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < HR; ++r) {
+                if (!h_on[r]) continue;
+                const w2_f32x2 *const raw = xs + (c & 1) * XRAW + h_src[r];
+                unsigned w[3][2];
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    w2_f32x2 q7[7];
+#pragma unroll
+                    for (int n = 0; n < 7; ++n) {
+                        const int sh = n - C0;
+                        q7[n] = raw[(e2 * 4 + (sh & 3)) * XTS + (sh >> 2) * d];
+                    }
+                    // the compute waves' expression, term for term (t_xform2)
+                    w2_f32x2 a = q7[0] * hbt[r][0], b2 = q7[1] * hbt[r][1];
+                    a = __builtin_elementwise_fma(w2_f32x2{hbt[r][2], hbt[r][2]}, q7[2], a);
+                    b2 = __builtin_elementwise_fma(w2_f32x2{hbt[r][3], hbt[r][3]}, q7[3], b2);
+                    a = __builtin_elementwise_fma(w2_f32x2{hbt[r][4], hbt[r][4]}, q7[4], a);
+                    b2 = __builtin_elementwise_fma(w2_f32x2{hbt[r][5], hbt[r][5]}, q7[5], b2);
+                    a = __builtin_elementwise_fma(w2_f32x2{hbt[r][6], hbt[r][6]}, q7[6], a);
+                    w2_f32x2 v = a + b2;
+#pragma unroll
+                    for (int level = 0; level < 3; ++level) {
+                        const unsigned ww = __builtin_bit_cast(unsigned, __builtin_convertvector(v, w2_bf16x2));
+                        w[level][e2] = ww;
+                        if (level < 2) v = v - w2_f32x2{__uint_as_float(ww << 16), __uint_as_float(ww & 0xffff0000u)};
+                    }
+                }
+                unsigned char *o = bs_all + (c & 1) * GM::B_WAVE + h_dst[r];
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) *reinterpret_cast<w2_u32x2 *>(o + sp * 2 * GM::B_PLANE) = w2_u32x2{w[sp][0], w[sp][1]};
+            }
+        };
+        const int last = n_chunks - 1;
+        load(0);
+        write(0);
+        load(1 < last ? 1 : last);
         lds_barrier();                                    // (P1) chunk 0's rows are in LDS
-        if (n_chunks > 1) stage(1);
-        lds_barrier();                                    // (P2) chunk 1's rows; the compute waves have transformed chunk 0
+        stamp();
+        halo(0);
+        write(1);
+        load(2 < last ? 2 : last);
+        lds_barrier();                                    // (P2) chunk 1's rows; chunk 0 is transformed
+        stamp();
         for (int c = 0; c < n_chunks; ++c) {
-            if (!(DBG & 8) && c + 2 < n_chunks) stage(c + 2);   // into buffer c & 1: chunk c was transformed before the last barrier
+            if (!(DBG & 8)) {
+                if (c + 2 < n_chunks) write(c + 2);       // into buffer c & 1: chunk c was transformed before the last barrier
+                load(c + 3 < last ? c + 3 : last);
+                halo(c + 1 < n_chunks ? c + 1 : c);       // chunk c + 1's halo windows, next to the compute waves' own 64
+            }
+            stamp();   // the loader: staged, now waiting
             lds_barrier();
+        }
+        };
+        if ((L & 3) == 0) {
+            if (edge) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{});
+        } else {
+            run(std::false_type{}, std::true_type{});
         }
     } else {
         // ================================ waves 0..6: point `wave` of every output tile =====================================
@@ -220,20 +329,24 @@ winobf2_conv_kernel(const Wbf2Params p) {
         float bt[7];
 #pragma unroll
         for (int n = 0; n < 7; ++n) bt[n] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, W2_BT[pt][n])));
-        // tap fragments: [c_out / BM][chunk][point][group][row block][split][lane][8 bf16], 1 KiB each
+        // tap fragments: [c_out / BM][point][chunk][group][row block][split][lane][8 bf16], 1 KiB each -- for one (block, point)
+        // the groups (chunk, tap group, row-block pair) follow each other in the order the wave consumes them, 6 KiB apiece: one
+        // running scalar offset, the six pieces at immediate offsets
         const __amdgpu_buffer_rsrc_t urs =
             __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, (int)((int64_t)c_in * c_out * NP * G * NSA * 2), W2_RSRC_FLAGS);
-        const int a_chunk_stride = NP * G * WM * NSA * 1024;
-        const int a_base = mblk * n_chunks * a_chunk_stride + pt * G * WM * NSA * 1024;
+        constexpr int A_GROUP = 2 * NSA * 1024;
+        const int n_groups = n_chunks * G * NPAIR;
+        const int a_base = (mblk * NP + pt) * n_groups * A_GROUP;
+        const int a_last = a_base + (n_groups - 1) * A_GROUP;
         w2_bf16x8 fa[2][2][NSA];                           // [buffer][row block of the pair][split]
-        auto load_a = [&](int buf, int c, int g, int pr) __attribute__((always_inline)) {
+        auto load_a = [&](int buf, int Q) __attribute__((always_inline)) {   // group Q of this wave's stream (clamped: the tail re-reads the last one)
+            int soff = a_base + Q * A_GROUP;
+            soff = soff < a_last ? soff : a_last;
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                for (int sp = 0; sp < NSA; ++sp) {
-                    const int soff = a_base + c * a_chunk_stride + ((g * WM + pr * 2 + rb) * NSA + sp) * 1024;
-                    fa[buf][rb][sp] = __builtin_bit_cast(w2_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(urs, 16 * lane, soff, 0));
-                }
+                for (int sp = 0; sp < NSA; ++sp)
+                    fa[buf][rb][sp] = __builtin_bit_cast(w2_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(urs, 16 * lane + (rb * NSA + sp) * 1024, soff, 0));
         };
         // window fragments of one tap group: [column tile][split]; single-buffered -- the products of a group are ordered so that
         // split 2 dies first, then split 1, and each is re-read for the next group while the current one finishes
@@ -259,11 +372,18 @@ winobf2_conv_kernel(const Wbf2Params p) {
                     tq[e][n] = raw[((2 * u + e) * 4 + (sh & 3)) * XTS + (sh >> 2) * d];
                 }
         };
-        auto t_xform = [&](int e) __attribute__((always_inline)) {
-            w2_f32x2 a = tq[e][0] * bt[0];
+        // both pairs of a unit at once, each as two independent half sums (four dependency chains instead of one of seven)
+        auto t_xform2 = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int n = 1; n < 7; ++n) a = __builtin_elementwise_fma(w2_f32x2{bt[n], bt[n]}, tq[e][n], a);
-            tv[e] = a;
+            for (int e = 0; e < 2; ++e) {
+                w2_f32x2 a = tq[e][0] * bt[0], b2 = tq[e][1] * bt[1];
+                a = __builtin_elementwise_fma(w2_f32x2{bt[2], bt[2]}, tq[e][2], a);
+                b2 = __builtin_elementwise_fma(w2_f32x2{bt[3], bt[3]}, tq[e][3], b2);
+                a = __builtin_elementwise_fma(w2_f32x2{bt[4], bt[4]}, tq[e][4], a);
+                b2 = __builtin_elementwise_fma(w2_f32x2{bt[5], bt[5]}, tq[e][5], b2);
+                a = __builtin_elementwise_fma(w2_f32x2{bt[6], bt[6]}, tq[e][6], a);
+                tv[e] = a + b2;
+            }
         };
         auto t_split = [&](int e, int level) __attribute__((always_inline)) {
             const unsigned w = __builtin_bit_cast(unsigned, __builtin_convertvector(tv[e], w2_bf16x2));
@@ -277,19 +397,22 @@ winobf2_conv_kernel(const Wbf2Params p) {
         };
         auto transform_unit = [&](int c, int u) __attribute__((always_inline)) {
             t_read(c, u);
+            t_xform2();
 #pragma unroll
-            for (int e = 0; e < 2; ++e) { t_xform(e); t_split(e, 0); t_split(e, 1); t_split(e, 2); }
+            for (int e = 0; e < 2; ++e) { t_split(e, 0); t_split(e, 1); t_split(e, 2); }
             t_write(c, u);
         };
 
         // ---- prologue ------------------------------------------------------------------------------------------------------
-        load_a(0, 0, 0, 0);
+        load_a(0, 0);
         lds_barrier();                                    // (P1)
+        stamp();
 #pragma unroll
         for (int u = 0; u < 4; ++u) transform_unit(0, u);
-        if (NPAIR > 1 || G > 1) load_a(1, 0, NPAIR > 1 ? 0 : 1, NPAIR > 1 ? 1 : 0);
+        load_a(1, 1);
         read_b(0, 0, 2); read_b(0, 0, 1); read_b(0, 0, 0);
         lds_barrier();                                    // (P2)
+        stamp();
 
         // ---- main loop: one phase per chunk ---------------------------------------------------------------------------------
         // group q = (tap group g, row-block pair pr), q = g * NPAIR + pr: 24 matrix instructions on four independent accumulators
@@ -310,10 +433,6 @@ winobf2_conv_kernel(const Wbf2Params p) {
             for (int q = 0; q < NQ; ++q) {
                 const int g = q / NPAIR, pr = q % NPAIR;
                 const int bufq = (q + par) & 1;
-                // group q + 2 (wrapping into the next chunk): where its tap fragments come from
-                const int q2 = (q + 2) % NQ, c2raw = c + (q + 2) / NQ;
-                const int c2 = c2raw < n_chunks ? c2raw : n_chunks - 1;
-                const int g2 = q2 / NPAIR, pr2 = q2 % NPAIR;
                 // the window fragments the NEXT group needs: a new tap group's (g + 1, or group 0 of the next chunk) when pr is the last pair
                 const bool b_turn = pr == NPAIR - 1;
                 const int gb = (g + 1) % G, cb_c = g + 1 < G ? c : c + 1;
@@ -334,10 +453,10 @@ winobf2_conv_kernel(const Wbf2Params p) {
                                 while (first > 0 && (first - 1) * (NQ - 1) / 4 == q) --first;
                                 const int k0 = (u - first) * 6;
                                 if (k == k0) t_read(cn, u);
-                                if (k == k0 + 1) { t_xform(0); t_split(0, 0); }
-                                if (k == k0 + 2) { t_split(0, 1); t_split(0, 2); }
-                                if (k == k0 + 3) { t_xform(1); t_split(1, 0); }
-                                if (k == k0 + 4) { t_split(1, 1); t_split(1, 2); }
+                                if (k == k0 + 1) t_xform2();
+                                if (k == k0 + 2) { t_split(0, 0); t_split(1, 0); }
+                                if (k == k0 + 3) { t_split(0, 1); t_split(1, 1); }
+                                if (k == k0 + 4) { t_split(0, 2); t_split(1, 2); }
                                 if (k == k0 + 5) t_write(cn, u);
                             }
                             if (b_turn && !(DBG & 32)) {
@@ -345,11 +464,12 @@ winobf2_conv_kernel(const Wbf2Params p) {
                                 if (k == 11) read_b(cb_c, gb, 1);           // split 1: products 1, 2
                                 if (k == 23) read_b(cb_c, gb, 0);           // split 0: products 3..5
                             }
-                            if (k == 4 * NPROD - 1 && !(DBG & 4)) load_a(bufq, c2, g2, pr2);
+                            if (k == 4 * NPROD - 1 && !(DBG & 4)) load_a(bufq, c * NQ + q + 2);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                 }
             }
+            stamp();   // a compute wave: products and transform done, now waiting
             lds_barrier();                                // the raw rows of chunk c + 2 are in LDS; B of chunk c + 1 is this wave's own
         };
         for (int c = 0; c < n_chunks; c += 2) {
@@ -377,7 +497,8 @@ winobf2_conv_kernel(const Wbf2Params p) {
     }
     const float *bias = p.bias;
     const float *res = p.res ? p.res + (int64_t)b * c_out * L : nullptr;
-    const float *accin = p.accin ? p.accin + (int64_t)b * c_out * L : nullptr;
+    const float *accin = (p.accin && !(DBG & 128)) ? p.accin + (int64_t)b * c_out * L : nullptr;
+    if constexpr (DBG & 128) { n_stamp = 20; stamp(); }   // epilogue stamps from slot 20 on
     float *y = p.y + (int64_t)b * c_out * L;
     const float out_scale = p.out_scale;
     f32x4 *const red = reinterpret_cast<f32x4 *>(smem);
@@ -388,9 +509,43 @@ winobf2_conv_kernel(const Wbf2Params p) {
     const int64_t t_blk0 = sb0 * 4 * d;
     const int64_t left = L - t_blk0;
     const int n_t = (int)(left < 4 * n_tiles_blk ? left : 4 * n_tiles_blk);   // valid outputs per row in this block
+    // The residual values this thread will add are fetched FIRST, for every pass: one block per CU, so nothing else hides their
+    // HBM latency -- it runs under the accumulators' trip through LDS, and the second pass's loads do not queue behind the first
+    // pass's stores (the running sum of the last conv of a ResBlock, one launch in six, is fetched where it is added).
+    // (a thread with nothing to add fetches the start of its row instead: a load behind a per-thread condition makes hipcc
+    // branch around it and wait for each load on its own -- sixteen serial round trips, measured 9 500 cycles)
+    f32x4 pre_r[NPAIR][8];                                // direct: [group 2][channel 4]; tile path: [row pass 8]
+    if (res) {
+#pragma unroll
+        for (int pr = 0; pr < NPAIR; ++pr) {
+            if (direct) {
+#pragma unroll
+                for (int gi = 0; gi < 2; ++gi) {
+                    const int grp = tid + gi * W2_NTH;
+                    const int ln = grp & 63, rq = (grp >> 6) & 3, tile = grp >> 8;
+                    const int col = (tile & 1) * 32 + (ln & 31);
+                    const int64_t t0 = (sb0 + col) * 4;
+                    const bool ok = col < n_tiles_blk && t0 < L;
+                    const int64_t base = (int64_t)(m0 + pr * 64 + (tile >> 1) * 32 + 8 * rq + 4 * (ln >> 5)) * L + (ok ? t0 : 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pre_r[pr][gi * 4 + e] = *reinterpret_cast<const f32x4 *>(res + base + (int64_t)e * L);
+                }
+            } else if (l4) {
+                constexpr int RPP = W2_NTH / BNT;
+                const int tq4 = (tid % BNT) * 4, rq = tid / BNT;
+                const int64_t base = (int64_t)(m0 + pr * 64 + rq) * L + (tq4 < n_t ? t_blk0 + tq4 : 0);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pre_r[pr][k] = *reinterpret_cast<const f32x4 *>(res + base + (int64_t)k * RPP * L);
+            }
+        }
+    }
+    // Each pass leaves its results in registers; residual, running sum and the stores come after the LAST pass, so the residual's
+    // HBM latency runs under both passes' LDS traffic (with add + store inside the pass the first pass waited ~8 000 cycles for it).
+    f32x4 outv[NPAIR][8];
+    stamp();   // residual loads issued
 #pragma unroll
     for (int pr = 0; pr < NPAIR; ++pr) {
-        if (pr > 0) lds_barrier();                        // the previous pass's tile has been copied out
+        if (pr > 0) lds_barrier();                        // the previous pass's tile has been read back
         if (!loader) {
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
@@ -401,7 +556,9 @@ winobf2_conv_kernel(const Wbf2Params p) {
                         red[((wave * 4 + rb * 2 + cb) * 4 + rq) * 64 + lane] =
                             f32x4{acc[pr * 2 + rb][cb][4 * rq], acc[pr * 2 + rb][cb][4 * rq + 1], acc[pr * 2 + rb][cb][4 * rq + 2], acc[pr * 2 + rb][cb][4 * rq + 3]};
         }
+        stamp();   // accumulators written
         lds_barrier();
+        stamp();   // accumulators parked
         f32x4 o[2][4];                                    // [group][channel of the quad] -> 4 outputs
         int g_row[2], g_col[2];
 #pragma unroll
@@ -415,9 +572,11 @@ winobf2_conv_kernel(const Wbf2Params p) {
             const int row0 = rb * 32 + 8 * rq + 4 * (ln >> 5);           // + comp: channel inside the pair's 64
             g_row[gi] = row0;
             g_col[gi] = cb * 32 + (ln & 31);
+            f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+            if (bias) bq = *reinterpret_cast<const f32x4 *>(bias + m0 + pr * 64 + row0);   // row0 is a multiple of 4
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float bv = bias ? bias[m0 + pr * 64 + row0 + e] : 0.f;
+                const float bv = bq[e];
                 const float t0 = v[0][e] * -2.f, t1 = v[1][e] * (-2.f / 3.f), t2 = v[2][e] * (-2.f / 9.f), t3 = v[3][e] * (16.f / 9.f),
                             t4 = v[4][e] * (16.f / 15.f), t5 = v[5][e] * (2.f / 45.f), t6 = v[6][e];
                 const float s12 = t1 + t2, m12 = t1 - t2, s34 = t3 + t4, m34 = t3 - t4;
@@ -429,29 +588,10 @@ winobf2_conv_kernel(const Wbf2Params p) {
         }
         if (direct) {
 #pragma unroll
-            for (int gi = 0; gi < 2; ++gi) {
-                const int col = g_col[gi];
-                const int64_t t0 = (sb0 + col) * 4;
-                if (col < n_tiles_blk && t0 < L) {
-                    const int64_t base = (int64_t)(m0 + pr * 64 + g_row[gi]) * L + t0;
-                    if (res) {
-                        f32x4 rv[4];
+            for (int gi = 0; gi < 2; ++gi)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) rv[e] = *reinterpret_cast<const f32x4 *>(res + base + (int64_t)e * L);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[gi][e] += rv[e];
-                    }
-                    if (accin) {
-                        f32x4 av[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) av[e] = *reinterpret_cast<const f32x4 *>(accin + base + (int64_t)e * L);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[gi][e] += av[e];
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x4 *>(y + base + (int64_t)e * L) = o[gi][e] * out_scale;
-                }
-            }
+                for (int e = 0; e < 4; ++e) outv[pr][gi * 4 + e] = o[gi][e];
+            stamp();   // outputs in registers
             continue;
         }
         lds_barrier();                                    // every thread has read its points: the tile may overlay them
@@ -471,29 +611,10 @@ winobf2_conv_kernel(const Wbf2Params p) {
         lds_barrier();
         if (l4) {   // 16-byte pieces: 64 threads per row, 8 rows per pass
             constexpr int RPP = W2_NTH / BNT, PASSES = 64 / RPP;
+            static_assert(PASSES == 8, "a thread holds eight rows of a pass");
             const int tq4 = (tid % BNT) * 4, rq = tid / BNT;
-            if (tq4 < n_t) {
-                const int64_t base = (int64_t)(m0 + pr * 64 + rq) * L + t_blk0 + tq4;
-                f32x4 v[PASSES];
 #pragma unroll
-                for (int k = 0; k < PASSES; ++k) v[k] = *reinterpret_cast<const f32x4 *>(yt + (rq + k * RPP) * YS + tq4);
-                if (res) {
-                    f32x4 rv[PASSES];
-#pragma unroll
-                    for (int k = 0; k < PASSES; ++k) rv[k] = *reinterpret_cast<const f32x4 *>(res + base + (int64_t)k * RPP * L);
-#pragma unroll
-                    for (int k = 0; k < PASSES; ++k) v[k] += rv[k];
-                }
-                if (accin) {
-                    f32x4 av[PASSES];
-#pragma unroll
-                    for (int k = 0; k < PASSES; ++k) av[k] = *reinterpret_cast<const f32x4 *>(accin + base + (int64_t)k * RPP * L);
-#pragma unroll
-                    for (int k = 0; k < PASSES; ++k) v[k] += av[k];
-                }
-#pragma unroll
-                for (int k = 0; k < PASSES; ++k) *reinterpret_cast<f32x4 *>(y + base + (int64_t)k * RPP * L) = v[k] * out_scale;
-            }
+            for (int k = 0; k < PASSES; ++k) outv[pr][k] = *reinterpret_cast<const f32x4 *>(yt + (rq + k * RPP) * YS + tq4);
         } else {
             for (int e = tid; e < 64 * 4 * BNT; e += W2_NTH) {
                 const int rq = e / (4 * BNT), tq1 = e - rq * (4 * BNT);
@@ -506,12 +627,70 @@ winobf2_conv_kernel(const Wbf2Params p) {
             }
         }
     }
+    stamp();   // every pass reduced
+    // ---- residual, running sum, scale, stores -------------------------------------------------------------------------------
+    if (direct) {
+#pragma unroll
+        for (int pr = 0; pr < NPAIR; ++pr)
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) {
+                const int grp = tid + gi * W2_NTH;
+                const int ln = grp & 63, rq = (grp >> 6) & 3, tile = grp >> 8;
+                const int col = (tile & 1) * 32 + (ln & 31);
+                const int64_t t0 = (sb0 + col) * 4;
+                if (col < n_tiles_blk && t0 < L) {
+                    const int64_t base = (int64_t)(m0 + pr * 64 + (tile >> 1) * 32 + 8 * rq + 4 * (ln >> 5)) * L + t0;
+                    f32x4 ov[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[e] = outv[pr][gi * 4 + e];
+                    if (res) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ov[e] += pre_r[pr][gi * 4 + e];
+                    }
+                    if (accin) {
+                        f32x4 av[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) av[e] = *reinterpret_cast<const f32x4 *>(accin + base + (int64_t)e * L);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ov[e] += av[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x4 *>(y + base + (int64_t)e * L) = ov[e] * out_scale;
+                }
+            }
+    } else if (l4) {
+        constexpr int RPP = W2_NTH / BNT;
+        const int tq4 = (tid % BNT) * 4, rq = tid / BNT;
+        if (tq4 < n_t) {
+#pragma unroll
+            for (int pr = 0; pr < NPAIR; ++pr) {
+                const int64_t base = (int64_t)(m0 + pr * 64 + rq) * L + t_blk0 + tq4;
+                f32x4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = outv[pr][k];
+                if (res) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += pre_r[pr][k];
+                }
+                if (accin) {
+                    f32x4 av[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) av[k] = *reinterpret_cast<const f32x4 *>(accin + base + (int64_t)k * RPP * L);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += av[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) *reinterpret_cast<f32x4 *>(y + base + (int64_t)k * RPP * L) = v[k] * out_scale;
+            }
+        }
+    }
+    stamp();   // stores issued
 }
 
 template <int KW, int BM, int DBG = 0>
 static int winobf2_launch(Wbf2Params p, hipStream_t stream) {
     using GM = W2Geom<KW, BM>;
-    p.sb_per_block = (W2_BNT - (GM::G - 1) * p.dil) / p.dil;   // valid tiles + the (G - 1) d windows behind them <= 64 transformed windows
+    p.sb_per_block = W2_BNT / p.dil;   // every accumulator column a valid tile: the (G - 1) d windows behind the 64 are the loader wave's
     const int64_t n_sb = ceil_div(p.L, (int64_t)4 * p.dil);
     static std::once_flag once;
     static hipError_t err = hipSuccess;
@@ -527,11 +706,11 @@ static int winobf2_launch(Wbf2Params p, hipStream_t stream) {
     return 0;
 }
 
-// the block rows a layer runs with (its tap fragments are packed for it): 128 where c_out allows, else 64
-int winobf2_block_rows(int c_out) { return c_out % 128 == 0 ? 128 : 64; }
-
+// This form runs 128-row blocks; layers whose c_out is not a multiple of 128 (the 64-channel stage: four 16-channel chunks are
+// too short a K loop to pay for this kernel's prologue and its output transform through LDS -- measured 1.17-1.28x slower than
+// winobf.hip's 64 x 128 blocks, profiles/r04_convbf_shapes_v2_first.txt) stay on winobf.hip.
 bool winobf2_supported(int c_in, int c_out, int k, int dil) {
-    return (k == 7 || k == 11) && dil >= 1 && dil <= W2_MAX_DIL && c_in % W2_CIC == 0 && c_out % 64 == 0;
+    return (k == 7 || k == 11) && dil >= 1 && dil <= W2_MAX_DIL && c_in % W2_CIC == 0 && c_out % 128 == 0;
 }
 
 bool winobf2_fits(int c_in, int c_out, int64_t L) {
@@ -547,9 +726,8 @@ int launch_winobf2_conv(const float *x, const void *u, const float *bias, const 
     Wbf2Params p;
     p.x = x; p.u = u; p.bias = bias; p.res = res; p.accin = accin; p.y = y;
     p.c_in = c_in; p.c_out = c_out; p.L = L; p.dil = dil; p.slope = slope; p.out_scale = out_scale; p.batch = batch;
-    const bool wide = winobf2_block_rows(c_out) == 128;
 #ifdef RVC_ABLATE
-    if (k == 11 && wide) {   // where does the time go (tools/ablate_winobf2.sh; wrong results)
+    if (k == 11) {   // where does the time go (tools/ablate_winobf2.sh; wrong results)
         static const int dbg = knob("RVC_W2_DBG", 0);
         switch (dbg) {
             case 1: return winobf2_launch<11, 128, 1>(p, stream);
@@ -563,12 +741,13 @@ int launch_winobf2_conv(const float *x, const void *u, const float *bias, const 
             case 45: return winobf2_launch<11, 128, 45>(p, stream);
             case 61: return winobf2_launch<11, 128, 61>(p, stream);
             case 63: return winobf2_launch<11, 128, 63>(p, stream);
+            case 64: return winobf2_launch<11, 128, 64>(p, stream);
+            case 128: return winobf2_launch<11, 128, 128>(p, stream);
             default: break;
         }
     }
 #endif
-    if (k == 7) return wide ? winobf2_launch<7, 128>(p, stream) : winobf2_launch<7, 64>(p, stream);
-    return wide ? winobf2_launch<11, 128>(p, stream) : winobf2_launch<11, 64>(p, stream);
+    return k == 7 ? winobf2_launch<7, 128>(p, stream) : winobf2_launch<11, 128>(p, stream);
 }
 
 }  // namespace rvc
