@@ -45,6 +45,13 @@ static inline int knob(const char *name, int dflt) {
 static inline constexpr int knob(const char *, int dflt) { return dflt; }
 #endif
 
+// Every kernel that issues bf16 / fp16 matrix instructions REQUESTS this much dynamic LDS whatever it uses: it then never
+// shares a CU with any other workgroup.  A workgroup of round 3's first gemmbf_kernel sharing a CU with a workgroup of the fp32
+// Winograd kernel (wino.hip) made the latter return wrong accumulators (profiles/r04_mfma_cohabitation.txt: reproduced
+// stand-alone, bare bf16 matrix loops do NOT do it, cause still not isolated), so co-residence of the two kernel families is
+// excluded by construction instead of by the sizes their LDS layouts happen to have.
+constexpr int LDS_WHOLE_CU = 163840;
+
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -54,7 +54,7 @@ constexpr int GBF_A_SLOT = 4 * 3 * 1024;            // [32-row block 4][split 3]
 constexpr int GBF_B_PLANE = GBF_BN * 16;            // [256 columns][8 bf16]
 constexpr int GBF_B_SLOT = 3 * 2 * GBF_B_PLANE;     // [split][k half]
 constexpr int GBF_LDS_USED = 3 * GBF_A_SLOT + 2 * GBF_B_SLOT;
-constexpr int GBF_LDS = 163840;                     // requested: the whole CU (see above)
+constexpr int GBF_LDS = LDS_WHOLE_CU;               // requested: the whole CU (common.h)
 static_assert(GBF_LDS_USED <= GBF_LDS, "");
 
 typedef float gbf_f32x2 __attribute__((ext_vector_type(2)));

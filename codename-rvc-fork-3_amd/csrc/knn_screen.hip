@@ -774,10 +774,11 @@ int knn_screened_search(const float *index, const void *aux_dev, int64_t n_rows,
         auto reserve = [](const void *fn, size_t bytes) {
             if (lds_err == hipSuccess) lds_err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         };
-        reserve((const void *)knn_screen_glds_kernel<true>, ScreenTile<2, 64>::LDS_BYTES);
-        reserve((const void *)knn_screen_glds_kernel<false>, ScreenTile<2, 64>::LDS_BYTES);
-        reserve((const void *)knn_screen_kernel<true, 2, 64>, ScreenTile<2, 64>::LDS_BYTES);
-        reserve((const void *)knn_screen_kernel<false, 2, 64>, ScreenTile<2, 64>::LDS_BYTES);
+        static_assert(ScreenTile<2, 64>::LDS_BYTES <= LDS_WHOLE_CU, "");
+        reserve((const void *)knn_screen_glds_kernel<true>, LDS_WHOLE_CU);      // fp16 matrix instructions: these own their CU (common.h)
+        reserve((const void *)knn_screen_glds_kernel<false>, LDS_WHOLE_CU);
+        reserve((const void *)knn_screen_kernel<true, 2, 64>, LDS_WHOLE_CU);
+        reserve((const void *)knn_screen_kernel<false, 2, 64>, LDS_WHOLE_CU);
         reserve((const void *)knn_screen_kernel<true, 1, 32>, ScreenTile<1, 32>::LDS_BYTES);
         reserve((const void *)knn_screen_kernel<false, 1, 32>, ScreenTile<1, 32>::LDS_BYTES);
     });
@@ -800,11 +801,11 @@ int knn_screened_search(const float *index, const void *aux_dev, int64_t n_rows,
     auto launch = [&](bool append, unsigned nblocks) {
 #define RVC_SCREEN(AP, W, K)                                                                                               \
     hipLaunchKernelGGL((knn_screen_kernel<AP, W, K>), dim3(nblocks), dim3((ScreenTile<W, K>::THREADS)),                   \
-                       (ScreenTile<W, K>::LDS_BYTES), stream, p)
+                       ((W) == 2 ? (size_t)LDS_WHOLE_CU : (size_t)ScreenTile<W, K>::LDS_BYTES), stream, p)
         static const int glds_env = knob("RVC_KNN_GLDS", 0);   // 1: the LDS-DMA staged variant (measured equal: 0.555 vs 0.545 ms)
         if (s.wm == 2 && s.bk == 64 && glds_env) {
-            if (append) hipLaunchKernelGGL(knn_screen_glds_kernel<true>, dim3(nblocks), dim3(512), (ScreenTile<2, 64>::LDS_BYTES), stream, p);
-            else hipLaunchKernelGGL(knn_screen_glds_kernel<false>, dim3(nblocks), dim3(512), (ScreenTile<2, 64>::LDS_BYTES), stream, p);
+            if (append) hipLaunchKernelGGL(knn_screen_glds_kernel<true>, dim3(nblocks), dim3(512), LDS_WHOLE_CU, stream, p);
+            else hipLaunchKernelGGL(knn_screen_glds_kernel<false>, dim3(nblocks), dim3(512), LDS_WHOLE_CU, stream, p);
         } else if (s.wm == 2 && s.bk == 64) {
 #ifdef RVC_ABLATE
             static const int dbg = knob("RVC_KNN_DBG", 0);

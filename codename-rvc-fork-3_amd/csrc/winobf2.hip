@@ -695,13 +695,13 @@ static int winobf2_launch(Wbf2Params p, hipStream_t stream) {
     static std::once_flag once;
     static hipError_t err = hipSuccess;
     std::call_once(once, [] {
-        err = hipFuncSetAttribute((const void *)winobf2_conv_kernel<KW, BM, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, GM::LDS_BYTES);
+        err = hipFuncSetAttribute((const void *)winobf2_conv_kernel<KW, BM, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
     });
     if (err != hipSuccess) return fail("winobf2 conv: cannot reserve %d bytes of LDS: %s", GM::LDS_BYTES, hipGetErrorString(err));
     p.n_tile_blocks = (int)ceil_div(n_sb, p.sb_per_block);
     const int n_m = p.c_out / BM;
     dim3 grid((unsigned)(ceil_div(p.n_tile_blocks, 8) * 8 * n_m), 1, (unsigned)p.batch);
-    hipLaunchKernelGGL((winobf2_conv_kernel<KW, BM, DBG>), grid, dim3(W2_NTH), GM::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((winobf2_conv_kernel<KW, BM, DBG>), grid, dim3(W2_NTH), LDS_WHOLE_CU, stream, p);   // owns its CU (common.h)
     RVC_LAUNCH_CHECK();
     return 0;
 }

@@ -502,16 +502,26 @@ def test_decoder_full_synth_golden(native, dev, ref_inputs):
     assert rms(out - g["o"]) <= 5e-5, rms(out - g["o"])
 
 
+@pytest.mark.parametrize("co", ["gemmbf", "winobf2", "knn_screen"])
 @pytest.mark.parametrize("k,c", [(11, 128), (3, 64), (7, 32)])
-def test_fp32_winograd_next_to_the_bf16_gemm_is_bit_exact(native, dev, k, c):
-    """Regression test of profiles/r03_mfma_cohabitation.txt: while one thread launches gemmbf.hip (bf16 matrix instructions) in
-    a loop on its own stream, the fp32 Winograd kernel on another stream must return bit-identical results every time.  It does
-    because gemmbf asks for a CU's whole LDS and so never shares one; in its first form (two 60 KiB blocks per CU) 300 of 300
-    runs of this loop came back wrong by up to 2.2."""
+def test_fp32_winograd_next_to_the_bf16_gemm_is_bit_exact(native, dev, k, c, co):
+    """Regression test of profiles/r03_mfma_cohabitation.txt / r04_mfma_cohabitation.txt: while one thread launches a kernel that
+    issues bf16 / fp16 matrix instructions in a loop on its own stream -- gemmbf.hip, winobf2.hip, the kNN screening pass -- the
+    fp32 Winograd kernel on another stream must return bit-identical results every time.  It does because every such kernel asks
+    for a CU's whole LDS (common.h: LDS_WHOLE_CU) and so never shares one; next to gemmbf's first form (two 60 KiB blocks per CU)
+    300 of 300 runs of this loop came back wrong by up to 2.2."""
     import threading
     g = torch.Generator().manual_seed(k * 1000 + c)
     a = native.gemm_bf16x3_pack_weight(torch.randn(512, 512, 3, generator=g) * 0.03, dev)
     xg = torch.randn(1, 512, 51000, generator=g).to(dev)
+    if co == "winobf2":
+        ub = native.conv1d_winobf_pack_weight(torch.randn(128, 128, 11, generator=g) * 0.03, dev)
+        xb = torch.randn(1, 128, 100000, generator=g).to(dev)
+        bb = torch.zeros(128, device=dev)
+    if co == "knn_screen":
+        index = torch.randn(50000, 768, generator=g).to(dev)
+        norms = native.knn_index_norms(index)
+        q = torch.randn(600, 768, generator=g).to(dev)
     L = 60000 if c >= 64 else 400000
     x = torch.randn(1, c, L, generator=g).to(dev)
     res = torch.randn(1, c, L, generator=g).to(dev)
@@ -525,7 +535,12 @@ def test_fp32_winograd_next_to_the_bf16_gemm_is_bit_exact(native, dev, k, c):
         st = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(st):
             while not state["stop"]:
-                native.conv1d_bf16x3(xg, a, None, 512, 3, stride=2, act="gelu")
+                if co == "gemmbf":
+                    native.conv1d_bf16x3(xg, a, None, 512, 3, stride=2, act="gelu")
+                elif co == "winobf2":
+                    native.conv1d_winobf_forward(xb, ub, bb, 128, 11, 1, 0.1)
+                else:
+                    native.knn_search(index, norms, q)
                 st.synchronize()
 
     def victim():
