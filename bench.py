@@ -279,6 +279,7 @@ def main():
     elapsed = time.perf_counter() - t0
     samples = sum(int(o.shape[0]) for o in outs)
     total_samples, t_max = D.reduce_report(samples, elapsed, dev)
+    rank_seconds = D.gather_seconds(elapsed, dev)
     # outside the timed region: EVERY timed waveform must be finite and inside [-1, 1] (a silent NaN utterance must not
     # count as throughput)
     for o in outs:
@@ -319,6 +320,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(t_max / args.steps * 1e3, 2),
+        "ms_per_step_ranks": {"min": round(min(rank_seconds) / args.steps * 1e3, 2), "max": round(max(rank_seconds) / args.steps * 1e3, 2),
+                              "all": [round(t / args.steps * 1e3, 2) for t in rank_seconds]},
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

@@ -230,6 +230,16 @@ def reduce_report(samples: int, seconds: float, device):
     return int(s.item()), float(t.item())
 
 
+def gather_seconds(seconds: float, device):
+    """Every rank's own wall time of the timed region, in rank order (the bench line's per-rank min / max)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(seconds)]
+    mine = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(o.item()) for o in out]
+
+
 # ---- starting the ranks (extract.py:141-152 starts its per-device workers itself; so does this) ------------------
 def free_port() -> int:
     s = socket.socket()
