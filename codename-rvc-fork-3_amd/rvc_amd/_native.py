@@ -234,7 +234,7 @@ def knn_blend(index: torch.Tensor, feats: torch.Tensor, d2: torch.Tensor, ids: t
 
 
 def knn_roofline_report(n_rows: int, n_queries: int, dim: int, seconds: float, peak_hbm_gbs: float,
-                        peak_f32_tflops: float, peak_f16_tflops: float) -> dict:
+                        peak_f32_tflops: float, peak_f16_tflops: float, traffic=None, traffic_source=None) -> dict:
     """SURVEY §8d's kNN roofline for one rvc_knn_search of (n_queries x n_rows) that took `seconds` (all launches of the
     search: query conversion, sample pass, bound, main pass, exact re-scoring).  §8d prices a pass over the index at
     n_rows * dim * 4 B (the fp32 rows the reference's algorithm reads) times ceil(Q / Qt) passes; the screened regime
@@ -255,10 +255,7 @@ def knn_roofline_report(n_rows: int, n_queries: int, dim: int, seconds: float, p
             "unit": "GB/s", "frac": round(bytes_8d / seconds / 1e9 / peak_hbm_gbs, 4),
             "bytes_moved_per_search": bytes_moved, "moved_gbs": round(bytes_moved / seconds / 1e9, 1),
             "moved_frac": round(bytes_moved / seconds / 1e9 / peak_hbm_gbs, 4),
-            "traffic": ({100_000: 0.90e9, 2_000_000: 9.93e9}.get(n_rows) if screened and n_queries == 1599 else None),
-            "traffic_source": ("profiles/r02_knn_pmc.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
-                               "tools/bench_knn.py at this shape, summed over the search's five launches, calibrated on a "
-                               "launch with known bytes") if screened and n_queries == 1599 and n_rows in (100_000, 2_000_000) else None,
+            "traffic": traffic, "traffic_source": traffic_source,   # measured HBM bytes per search (the caller's: profiles/pmc_knn_*.json)
             "mfma_tflops": round(flops / seconds / 1e12, 2),
             "mfma_frac": round(flops / seconds / 1e12 / (peak_f16_tflops if screened else peak_f32_tflops), 4),
             "mfma_peak_used": "fp16 dense 2500 TF" if screened else "fp32 157.3 TF",
