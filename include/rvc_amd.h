@@ -342,7 +342,10 @@ int rvc_conv1d_wino_forward(const float *x_dev, const float *u_dev, const float 
  * of a product.  One layer agrees with float64 as closely as the fp32 Winograd form does.
  * K in {7, 11}, dilation 1..5, C_in a multiple of 16, C_out a multiple of 64, leaky slope in [0, 1], C_in * L < 2^29.
  * u_dev: rvc_conv1d_winobf_weight_bytes() bytes -- the tap transform, evaluated in float64 on the host, rounded to fp32, split
- * into three bf16 and laid out as matrix-instruction fragments by rvc_conv1d_winobf_pack_weight. */
+ * into three bf16 and laid out as matrix-instruction fragments by rvc_conv1d_winobf_pack_weight, in the order the kernel that will
+ * read them consumes them: C_out % 128 == 0 runs csrc/winobf2.hip (one transform point per wave, 128-channel x 64-column blocks),
+ * other C_out csrc/winobf.hip (64 x 128 blocks) -- a slab is only valid for the (C_out, C_in, K) it was packed for.
+ * Both kernels request the CU's whole LDS (like the bf16x3 GEMM below): no other workgroup ever shares their CU. */
 int rvc_conv1d_winobf_weight_bytes(int c_out, int c_in, int k, size_t *bytes);
 int rvc_conv1d_winobf_pack_weight(const float *w_host, int c_out, int c_in, int k, void *u_dev, void *stream);
 int rvc_conv1d_winobf_forward(const float *x_dev, const void *u_dev, const float *bias_dev, const float *res_dev,
