@@ -163,6 +163,237 @@ winobf2_conv_kernel(const Wbf2Params p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // ---- what the epilogue needs (an earlier request by the loader wave, which idles through the last phases, was tried: 64 more live
+    //      registers in that wave's path spill) --------------------------------------------------------------------------------
+    const float *bias = p.bias;
+    const float *res = p.res ? p.res + (int64_t)b * c_out * L : nullptr;
+    const float *accin = (p.accin && !(DBG & 128)) ? p.accin + (int64_t)b * c_out * L : nullptr;
+    float *y = p.y + (int64_t)b * c_out * L;
+    const float out_scale = p.out_scale;
+    f32x4 *const red = reinterpret_cast<f32x4 *>(smem);
+    float *const yt = w2_smem;
+    constexpr int YS = GM::YS;
+    const bool l4 = (L & 3) == 0;
+    const bool direct = d == 1 && l4;
+    const int64_t t_blk0 = sb0 * 4 * d;
+    const int64_t left = L - t_blk0;
+    const int n_t = (int)(left < 4 * n_tiles_blk ? left : 4 * n_tiles_blk);   // valid outputs per row in this block
+    // The residual values this thread will add are fetched FIRST, for every pass: one block per CU, so nothing else hides their
+    // HBM latency -- it runs under the accumulators' trip through LDS, and the second pass's loads do not queue behind the first
+    // pass's stores (the running sum of the last conv of a ResBlock, one launch in six, is fetched where it is added).
+    // (a thread with nothing to add fetches the start of its row instead: a load behind a per-thread condition makes hipcc
+    // branch around it and wait for each load on its own -- sixteen serial round trips, measured 9 500 cycles)
+    f32x4 pre_r[NPAIR][8];                                // direct: [group 2][channel 4]; tile path: [row pass 8]
+    auto prefetch_residual = [&]() __attribute__((always_inline)) {
+    if (res) {
+#pragma unroll
+        for (int pr = 0; pr < NPAIR; ++pr) {
+            if (direct) {
+#pragma unroll
+                for (int gi = 0; gi < 2; ++gi) {
+                    const int grp = tid + gi * W2_NTH;
+                    const int ln = grp & 63, rq = (grp >> 6) & 3, tile = grp >> 8;
+                    const int col = (tile & 1) * 32 + (ln & 31);
+                    const int64_t t0 = (sb0 + col) * 4;
+                    const bool ok = col < n_tiles_blk && t0 < L;
+                    const int64_t base = (int64_t)(m0 + pr * 64 + (tile >> 1) * 32 + 8 * rq + 4 * (ln >> 5)) * L + (ok ? t0 : 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pre_r[pr][gi * 4 + e] = *reinterpret_cast<const f32x4 *>(res + base + (int64_t)e * L);
+                }
+            } else if (l4) {
+                constexpr int RPP = W2_NTH / BNT;
+                const int tq4 = (tid % BNT) * 4, rq = tid / BNT;
+                const int64_t base = (int64_t)(m0 + pr * 64 + rq) * L + (tq4 < n_t ? t_blk0 + tq4 : 0);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pre_r[pr][k] = *reinterpret_cast<const f32x4 *>(res + base + (int64_t)k * RPP * L);
+            }
+        }
+    }
+    };
+    // ---- raw-row staging (the loader wave's job; every wave lends a hand with chunk 0, see stage_pair0) ---------------------
+        const float *const px = p.x + (int64_t)b * c_in * L;
+    const float slope = p.slope;
+    const int E = (G - 1) * d;                                     // halo windows
+    const int xt_used = (p.sb_per_block + G - 1 - MLO) * d;      // valid tiles + the (G - 1) d windows behind them + the -MLO d in front
+    const int64_t t_start = (sb0 + MLO) * 4 * d;
+    const int span = 4 * xt_used;                                  // staged samples per row (a multiple of 4, <= 4 XT)
+    const bool edge = t_start < 0 || t_start + span > L;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)px, 0, (int)((int64_t)c_in * L * 4), W2_RSRC_FLAGS);
+    const int L4 = (int)(L * 4);
+    // (the row width is decided ONCE, outside everything: a runtime `wide` test around each load makes hipcc wait for every load on its own)
+    auto run = [&](auto WIDE, auto EDGE) __attribute__((always_inline)) {
+    constexpr bool wide = decltype(WIDE)::value, edge_c = decltype(EDGE)::value;   // edge_c: some staged samples are conv padding (first / last blocks of a row)                   // rows 16-byte aligned: lane = 4 consecutive samples
+    // plan: slot k < NS of a row is one sample; wide: slots 0..3 = samples 4 lane .. 4 lane + 3 (one 16-byte load), then
+    // one-dword slots for samples 256 + lane, 320 + lane, ...; narrow: slot k = sample lane + 64 k
+    constexpr int NS_W = 4 + (4 * XT - 256 + 63) / 64, NS_N = NJ, NS = NS_W > NS_N ? NS_W : NS_N;
+    unsigned goff[NS];    // byte offset of the slot's (first) sample in a row, clamped into the row
+    int loff[NS];
+    unsigned keep[NS];
+    // x / m for x < 2048, m <= 20 as (x * (65536 / m + 1)) >> 16 (exact there): the plan is on the block's critical path in front
+    // of its first loads, and twelve 32-bit divisions by a runtime d are ~300 instructions
+    const unsigned inv4d = 65536u / (unsigned)(4 * d) + 1u, invd = 65536u / (unsigned)d + 1u;
+    static_assert(4 * XT < 2048, "");
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int tl = wide ? (k < 4 ? 4 * lane + k : 256 + 64 * (k - 4) + lane) : lane + 64 * k;
+        const bool have = tl < span && (wide ? k < NS_W : k < NS_N);
+        const int tlc = have ? tl : 0;
+        const int64_t t = t_start + tlc;
+        const int64_t tc = t < 0 ? 0 : (t >= L ? L - 1 : t);
+        goff[k] = (unsigned)tc * 4u;
+        const int sbl = (int)(((unsigned)tlc * inv4d) >> 16);
+        const int r = tlc - sbl * 4 * d;
+        const int ii = (int)(((unsigned)r * invd) >> 16);
+        const int phi = r - ii * d;
+        loff[k] = have ? ii * XTS + sbl * d + phi : XT + (lane & 1);   // columns >= XT of a row are never read
+        keep[k] = (!edge || (t >= 0 && t < L)) ? 0xffffffffu : 0u;      // conv zero padding
+    }
+    if constexpr (wide) {   // the 16-byte load of slots 0..3 starts at slot 0's sample; a group of four lies wholly inside or outside the row
+        const int64_t t0 = t_start + 4 * lane;
+        goff[0] = (unsigned)(t0 < 0 ? 0 : (t0 > L - 4 ? L - 4 : t0)) * 4u;
+    }
+    float xr[2 * CP][NS];                                         // [row of the chunk][slot]
+    auto load = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int row = 0; row < 2 * CP; ++row) {
+            const int s0 = (c * CIC + row) * L4;
+            if constexpr (wide) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)goff[0], s0, 0));
+                xr[row][0] = v.x; xr[row][1] = v.y; xr[row][2] = v.z; xr[row][3] = v.w;
+#pragma unroll
+                for (int k = 4; k < NS_W; ++k) xr[row][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)goff[k], s0, 0));
+            } else {
+#pragma unroll
+                for (int k = 0; k < NS_N; ++k) xr[row][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)goff[k], s0, 0));
+            }
+        }
+    };
+    auto write = [&](int c) __attribute__((always_inline)) {
+        w2_f32x2 *const dst0 = xs + (c & 1) * XRAW;
+#pragma unroll
+        for (int q = 0; q < CP; ++q) {
+            w2_f32x2 *const dst = dst0 + q * 4 * XTS;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                if (wide ? k >= NS_W : k >= NS_N) continue;
+                const w2_f32x2 v = w2_lrelu2(w2_f32x2{xr[2 * q][k], xr[2 * q + 1][k]}, slope);
+                if constexpr (edge_c) dst[loff[k]] = w2_f32x2{__uint_as_float(__float_as_uint(v.x) & keep[k]), __uint_as_float(__float_as_uint(v.y) & keep[k])};
+                else dst[loff[k]] = v;
+            }
+        }
+    };
+    // Chunk 0 is staged by ALL eight waves, one channel pair each: with the loader alone the block's first barrier came 10 600
+    // cycles after its start (48 loads, their HBM round trip at the moment every CU starts a block, 48 LDS writes, all in one wave).
+    auto stage_pair0 = [&](int q) __attribute__((always_inline)) {
+        float r0[NS], r1[NS];
+        const int s0 = 2 * q * L4;
+        if constexpr (wide) {
+            const f32x4 v0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)goff[0], s0, 0));
+            const f32x4 v1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)goff[0], s0 + L4, 0));
+            r0[0] = v0.x; r0[1] = v0.y; r0[2] = v0.z; r0[3] = v0.w;
+            r1[0] = v1.x; r1[1] = v1.y; r1[2] = v1.z; r1[3] = v1.w;
+#pragma unroll
+            for (int k = 4; k < NS_W; ++k) {
+                r0[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)goff[k], s0, 0));
+                r1[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)goff[k], s0 + L4, 0));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NS_N; ++k) {
+                r0[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)goff[k], s0, 0));
+                r1[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)goff[k], s0 + L4, 0));
+            }
+        }
+        w2_f32x2 *const dst = xs + q * 4 * XTS;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            if (wide ? k >= NS_W : k >= NS_N) continue;
+            const w2_f32x2 v = w2_lrelu2(w2_f32x2{r0[k], r1[k]}, slope);
+            if constexpr (edge_c) dst[loff[k]] = w2_f32x2{__uint_as_float(__float_as_uint(v.x) & keep[k]), __uint_as_float(__float_as_uint(v.y) & keep[k])};
+            else dst[loff[k]] = v;
+        }
+    };
+    if (!loader) {            // compute wave w: channel pair w of chunk 0, then on to its own prologue
+        stage_pair0(wave);
+        return;
+    }
+    // halo windows: item = lane + 64 r -> (window 64 + e, point hp, unit hu = channel pairs 2 hu, 2 hu + 1)
+    constexpr int HR = ((G - 1) * W2_MAX_DIL * 28 + 63) / 64;
+    int h_src[HR], h_dst[HR];
+    float hbt[HR][7];
+    bool h_on[HR];
+#pragma unroll
+    for (int r = 0; r < HR; ++r) {
+        const int it = lane + 64 * r;
+        h_on[r] = it < E * 28;
+        const int itc = h_on[r] ? it : 0;
+        const int e = itc / 28, rem = itc - e * 28, hp = rem >> 2, hu = rem & 3;
+        h_src[r] = (2 * hu) * 4 * XTS - MLO * d + BNT + e;
+        h_dst[r] = hp * 2 * GM::B_WAVE + (hu >> 1) * GM::B_PLANE + (BNT + e) * 16 + (hu & 1) * 8;
+#pragma unroll
+        for (int n = 0; n < 7; ++n) hbt[r][n] = W2_BT[hp][n];
+    }
+    auto halo = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < HR; ++r) {
+            if (!h_on[r]) continue;
+            const w2_f32x2 *const raw = xs + (c & 1) * XRAW + h_src[r];
+            unsigned w[3][2];
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                w2_f32x2 q7[7];
+#pragma unroll
+                for (int n = 0; n < 7; ++n) {
+                    const int sh = n - C0;
+                    q7[n] = raw[(e2 * 4 + (sh & 3)) * XTS + (sh >> 2) * d];
+                }
+                // the compute waves' expression, term for term (t_xform2)
+                w2_f32x2 a = q7[0] * hbt[r][0], b2 = q7[1] * hbt[r][1];
+                a = __builtin_elementwise_fma(w2_f32x2{hbt[r][2], hbt[r][2]}, q7[2], a);
+                b2 = __builtin_elementwise_fma(w2_f32x2{hbt[r][3], hbt[r][3]}, q7[3], b2);
+                a = __builtin_elementwise_fma(w2_f32x2{hbt[r][4], hbt[r][4]}, q7[4], a);
+                b2 = __builtin_elementwise_fma(w2_f32x2{hbt[r][5], hbt[r][5]}, q7[5], b2);
+                a = __builtin_elementwise_fma(w2_f32x2{hbt[r][6], hbt[r][6]}, q7[6], a);
+                w2_f32x2 v = a + b2;
+#pragma unroll
+                for (int level = 0; level < 3; ++level) {
+                    const unsigned ww = __builtin_bit_cast(unsigned, __builtin_convertvector(v, w2_bf16x2));
+                    w[level][e2] = ww;
+                    if (level < 2) v = v - w2_f32x2{__uint_as_float(ww << 16), __uint_as_float(ww & 0xffff0000u)};
+                }
+            }
+            unsigned char *o = bs_all + (c & 1) * GM::B_WAVE + h_dst[r];
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) *reinterpret_cast<w2_u32x2 *>(o + sp * 2 * GM::B_PLANE) = w2_u32x2{w[sp][0], w[sp][1]};
+        }
+    };
+    const int last = n_chunks - 1;
+    load(1 < last ? 1 : last);                        // (in flight while this wave stages its pair of chunk 0)
+    stage_pair0(CP - 1);
+    lds_barrier();                                    // (P1) chunk 0's rows are in LDS
+    stamp();
+    halo(0);
+    write(1);
+    load(2 < last ? 2 : last);
+    lds_barrier();                                    // (P2) chunk 1's rows; chunk 0 is transformed
+    stamp();
+    for (int c = 0; c < n_chunks; ++c) {
+        if (!(DBG & 8)) {
+            if (c + 2 < n_chunks) write(c + 2);       // into buffer c & 1: chunk c was transformed before the last barrier
+            if (c + 3 <= last) load(c + 3);
+            if (c + 1 < n_chunks) halo(c + 1);        // chunk c + 1's halo windows, next to the compute waves' own 64
+        }
+        stamp();   // the loader: staged, now waiting
+        lds_barrier();
+    }
+    };
+    auto run_staging = [&]() __attribute__((always_inline)) {
+        if ((L & 3) == 0) {
+            if (edge) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{});
+        } else {
+            run(std::false_type{}, std::true_type{});
+        }
+    };
     if (loader) {
         // ================================ wave 7: raw input rows, and the halo windows ========================================
         // (a) stages the raw rows: chunk c + 3 is FETCHED during phase c (into registers), chunk c + 2 -- fetched a phase earlier --
@@ -178,149 +409,7 @@ winobf2_conv_kernel(const Wbf2Params p) {
         // ~650 instructions per phase took longer than the compute waves' whole phase.  Its work is small and on the block's
         // critical path (the barrier), so it gets the SIMD's issue slots first.
         __builtin_amdgcn_s_setprio(2);
-        const float *const px = p.x + (int64_t)b * c_in * L;
-        const float slope = p.slope;
-        const int E = (G - 1) * d;                                     // halo windows
-        const int xt_used = (p.sb_per_block + G - 1 - MLO) * d;      // valid tiles + the (G - 1) d windows behind them + the -MLO d in front
-        const int64_t t_start = (sb0 + MLO) * 4 * d;
-        const int span = 4 * xt_used;                                  // staged samples per row (a multiple of 4, <= 4 XT)
-        const bool edge = t_start < 0 || t_start + span > L;
-        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)px, 0, (int)((int64_t)c_in * L * 4), W2_RSRC_FLAGS);
-        const int L4 = (int)(L * 4);
-        // (the row width is decided ONCE, outside everything: a runtime `wide` test around each load makes hipcc wait for every load on its own)
-        auto run = [&](auto WIDE, auto EDGE) __attribute__((always_inline)) {
-        constexpr bool wide = decltype(WIDE)::value, edge_c = decltype(EDGE)::value;   // edge_c: some staged samples are conv padding (first / last blocks of a row)                   // rows 16-byte aligned: lane = 4 consecutive samples
-        // plan: slot k < NS of a row is one sample; wide: slots 0..3 = samples 4 lane .. 4 lane + 3 (one 16-byte load), then
-        // one-dword slots for samples 256 + lane, 320 + lane, ...; narrow: slot k = sample lane + 64 k
-        constexpr int NS_W = 4 + (4 * XT - 256 + 63) / 64, NS_N = NJ, NS = NS_W > NS_N ? NS_W : NS_N;
-        unsigned goff[NS];    // byte offset of the slot's (first) sample in a row, clamped into the row
-        int loff[NS];
-        unsigned keep[NS];
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            const int tl = wide ? (k < 4 ? 4 * lane + k : 256 + 64 * (k - 4) + lane) : lane + 64 * k;
-            const bool have = tl < span && (wide ? k < NS_W : k < NS_N);
-            const int tlc = have ? tl : 0;
-            const int64_t t = t_start + tlc;
-            const int64_t tc = t < 0 ? 0 : (t >= L ? L - 1 : t);
-            goff[k] = (unsigned)tc * 4u;
-            const int sbl = tlc / (4 * d);
-            const int r = tlc - sbl * 4 * d;
-            const int ii = r / d;
-            const int phi = r - ii * d;
-            loff[k] = have ? ii * XTS + sbl * d + phi : XT + (lane & 1);   // columns >= XT of a row are never read
-            keep[k] = (!edge || (t >= 0 && t < L)) ? 0xffffffffu : 0u;      // conv zero padding
-        }
-        if constexpr (wide) {   // the 16-byte load of slots 0..3 starts at slot 0's sample; a group of four lies wholly inside or outside the row
-            const int64_t t0 = t_start + 4 * lane;
-            goff[0] = (unsigned)(t0 < 0 ? 0 : (t0 > L - 4 ? L - 4 : t0)) * 4u;
-        }
-        float xr[2 * CP][NS];                                         // [row of the chunk][slot]
-        auto load = [&](int c) __attribute__((always_inline)) {
-#pragma unroll
-            for (int row = 0; row < 2 * CP; ++row) {
-                const int s0 = (c * CIC + row) * L4;
-                if constexpr (wide) {
-                    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)goff[0], s0, 0));
-                    xr[row][0] = v.x; xr[row][1] = v.y; xr[row][2] = v.z; xr[row][3] = v.w;
-#pragma unroll
-                    for (int k = 4; k < NS_W; ++k) xr[row][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)goff[k], s0, 0));
-                } else {
-#pragma unroll
-                    for (int k = 0; k < NS_N; ++k) xr[row][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)goff[k], s0, 0));
-                }
-            }
-        };
-        auto write = [&](int c) __attribute__((always_inline)) {
-            w2_f32x2 *const dst0 = xs + (c & 1) * XRAW;
-#pragma unroll
-            for (int q = 0; q < CP; ++q) {
-                w2_f32x2 *const dst = dst0 + q * 4 * XTS;
-#pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    if (wide ? k >= NS_W : k >= NS_N) continue;
-                    const w2_f32x2 v = w2_lrelu2(w2_f32x2{xr[2 * q][k], xr[2 * q + 1][k]}, slope);
-                    if constexpr (edge_c) dst[loff[k]] = w2_f32x2{__uint_as_float(__float_as_uint(v.x) & keep[k]), __uint_as_float(__float_as_uint(v.y) & keep[k])};
-                    else dst[loff[k]] = v;
-                }
-            }
-        };
-        // halo windows: item = lane + 64 r -> (window 64 + e, point hp, unit hu = channel pairs 2 hu, 2 hu + 1)
-        constexpr int HR = ((G - 1) * W2_MAX_DIL * 28 + 63) / 64;
-        int h_src[HR], h_dst[HR];
-        float hbt[HR][7];
-        bool h_on[HR];
-#pragma unroll
-        for (int r = 0; r < HR; ++r) {
-            const int it = lane + 64 * r;
-            h_on[r] = it < E * 28;
-            const int itc = h_on[r] ? it : 0;
-            const int e = itc / 28, rem = itc - e * 28, hp = rem >> 2, hu = rem & 3;
-            h_src[r] = (2 * hu) * 4 * XTS - MLO * d + BNT + e;
-            h_dst[r] = hp * 2 * GM::B_WAVE + (hu >> 1) * GM::B_PLANE + (BNT + e) * 16 + (hu & 1) * 8;
-#pragma unroll
-            for (int n = 0; n < 7; ++n) hbt[r][n] = W2_BT[hp][n];
-        }
-        auto halo = [&](int c) __attribute__((always_inline)) {
-#pragma unroll
-            for (int r = 0; r < HR; ++r) {
-                if (!h_on[r]) continue;
-                const w2_f32x2 *const raw = xs + (c & 1) * XRAW + h_src[r];
-                unsigned w[3][2];
-#pragma unroll
-                for (int e2 = 0; e2 < 2; ++e2) {
-                    w2_f32x2 q7[7];
-#pragma unroll
-                    for (int n = 0; n < 7; ++n) {
-                        const int sh = n - C0;
-                        q7[n] = raw[(e2 * 4 + (sh & 3)) * XTS + (sh >> 2) * d];
-                    }
-                    // the compute waves' expression, term for term (t_xform2)
-                    w2_f32x2 a = q7[0] * hbt[r][0], b2 = q7[1] * hbt[r][1];
-                    a = __builtin_elementwise_fma(w2_f32x2{hbt[r][2], hbt[r][2]}, q7[2], a);
-                    b2 = __builtin_elementwise_fma(w2_f32x2{hbt[r][3], hbt[r][3]}, q7[3], b2);
-                    a = __builtin_elementwise_fma(w2_f32x2{hbt[r][4], hbt[r][4]}, q7[4], a);
-                    b2 = __builtin_elementwise_fma(w2_f32x2{hbt[r][5], hbt[r][5]}, q7[5], b2);
-                    a = __builtin_elementwise_fma(w2_f32x2{hbt[r][6], hbt[r][6]}, q7[6], a);
-                    w2_f32x2 v = a + b2;
-#pragma unroll
-                    for (int level = 0; level < 3; ++level) {
-                        const unsigned ww = __builtin_bit_cast(unsigned, __builtin_convertvector(v, w2_bf16x2));
-                        w[level][e2] = ww;
-                        if (level < 2) v = v - w2_f32x2{__uint_as_float(ww << 16), __uint_as_float(ww & 0xffff0000u)};
-                    }
-                }
-                unsigned char *o = bs_all + (c & 1) * GM::B_WAVE + h_dst[r];
-#pragma unroll
-                for (int sp = 0; sp < 3; ++sp) *reinterpret_cast<w2_u32x2 *>(o + sp * 2 * GM::B_PLANE) = w2_u32x2{w[sp][0], w[sp][1]};
-            }
-        };
-        const int last = n_chunks - 1;
-        load(0);
-        write(0);
-        load(1 < last ? 1 : last);
-        lds_barrier();                                    // (P1) chunk 0's rows are in LDS
-        stamp();
-        halo(0);
-        write(1);
-        load(2 < last ? 2 : last);
-        lds_barrier();                                    // (P2) chunk 1's rows; chunk 0 is transformed
-        stamp();
-        for (int c = 0; c < n_chunks; ++c) {
-            if (!(DBG & 8)) {
-                if (c + 2 < n_chunks) write(c + 2);       // into buffer c & 1: chunk c was transformed before the last barrier
-                load(c + 3 < last ? c + 3 : last);
-                halo(c + 1 < n_chunks ? c + 1 : c);       // chunk c + 1's halo windows, next to the compute waves' own 64
-            }
-            stamp();   // the loader: staged, now waiting
-            lds_barrier();
-        }
-        };
-        if ((L & 3) == 0) {
-            if (edge) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{});
-        } else {
-            run(std::false_type{}, std::true_type{});
-        }
+        run_staging();
     } else {
         // ================================ waves 0..6: point `wave` of every output tile =====================================
         const int pt = wave;
@@ -405,6 +494,7 @@ winobf2_conv_kernel(const Wbf2Params p) {
 
         // ---- prologue ------------------------------------------------------------------------------------------------------
         load_a(0, 0);
+        run_staging();                                    // this wave's channel pair of chunk 0 (the loader takes the eighth)
         lds_barrier();                                    // (P1)
         stamp();
 #pragma unroll
@@ -428,7 +518,9 @@ winobf2_conv_kernel(const Wbf2Params p) {
         constexpr int ia6[6] = {0, 1, 0, 2, 1, 0}, ib6[6] = {2, 1, 1, 0, 0, 0};
         auto phase = [&](int c, auto PAR) __attribute__((always_inline)) {
             constexpr int par = decltype(PAR)::value;
-            const int cn = c + 1 < n_chunks ? c + 1 : c;  // the last phase re-transforms its own chunk (same bits, never needed): no branch in the body
+            // the last phase re-transforms its own chunk (same bits, never needed): no branch in the body.  (A third instantiation of
+            // the body without that work was tried: with three copies of the loop the register allocator spills 878 registers.)
+            const int cn = c + 1 < n_chunks ? c + 1 : c;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int g = q / NPAIR, pr = q % NPAIR;
@@ -495,50 +587,8 @@ winobf2_conv_kernel(const Wbf2Params p) {
         if (s == 12345.678f) p.y[tid] = s;
         return;
     }
-    const float *bias = p.bias;
-    const float *res = p.res ? p.res + (int64_t)b * c_out * L : nullptr;
-    const float *accin = (p.accin && !(DBG & 128)) ? p.accin + (int64_t)b * c_out * L : nullptr;
     if constexpr (DBG & 128) { n_stamp = 20; stamp(); }   // epilogue stamps from slot 20 on
-    float *y = p.y + (int64_t)b * c_out * L;
-    const float out_scale = p.out_scale;
-    f32x4 *const red = reinterpret_cast<f32x4 *>(smem);
-    float *const yt = w2_smem;
-    constexpr int YS = GM::YS;
-    const bool l4 = (L & 3) == 0;
-    const bool direct = d == 1 && l4;
-    const int64_t t_blk0 = sb0 * 4 * d;
-    const int64_t left = L - t_blk0;
-    const int n_t = (int)(left < 4 * n_tiles_blk ? left : 4 * n_tiles_blk);   // valid outputs per row in this block
-    // The residual values this thread will add are fetched FIRST, for every pass: one block per CU, so nothing else hides their
-    // HBM latency -- it runs under the accumulators' trip through LDS, and the second pass's loads do not queue behind the first
-    // pass's stores (the running sum of the last conv of a ResBlock, one launch in six, is fetched where it is added).
-    // (a thread with nothing to add fetches the start of its row instead: a load behind a per-thread condition makes hipcc
-    // branch around it and wait for each load on its own -- sixteen serial round trips, measured 9 500 cycles)
-    f32x4 pre_r[NPAIR][8];                                // direct: [group 2][channel 4]; tile path: [row pass 8]
-    if (res) {
-#pragma unroll
-        for (int pr = 0; pr < NPAIR; ++pr) {
-            if (direct) {
-#pragma unroll
-                for (int gi = 0; gi < 2; ++gi) {
-                    const int grp = tid + gi * W2_NTH;
-                    const int ln = grp & 63, rq = (grp >> 6) & 3, tile = grp >> 8;
-                    const int col = (tile & 1) * 32 + (ln & 31);
-                    const int64_t t0 = (sb0 + col) * 4;
-                    const bool ok = col < n_tiles_blk && t0 < L;
-                    const int64_t base = (int64_t)(m0 + pr * 64 + (tile >> 1) * 32 + 8 * rq + 4 * (ln >> 5)) * L + (ok ? t0 : 0);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) pre_r[pr][gi * 4 + e] = *reinterpret_cast<const f32x4 *>(res + base + (int64_t)e * L);
-                }
-            } else if (l4) {
-                constexpr int RPP = W2_NTH / BNT;
-                const int tq4 = (tid % BNT) * 4, rq = tid / BNT;
-                const int64_t base = (int64_t)(m0 + pr * 64 + rq) * L + (tq4 < n_t ? t_blk0 + tq4 : 0);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) pre_r[pr][k] = *reinterpret_cast<const f32x4 *>(res + base + (int64_t)k * RPP * L);
-            }
-        }
-    }
+    prefetch_residual();
     // Each pass leaves its results in registers; residual, running sum and the stores come after the LAST pass, so the residual's
     // HBM latency runs under both passes' LDS traffic (with add + store inside the pass the first pass waited ~8 000 cycles for it).
     f32x4 outv[NPAIR][8];
