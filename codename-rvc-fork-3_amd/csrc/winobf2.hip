@@ -284,6 +284,8 @@ winobf2_conv_kernel(const Wbf2Params p) {
     };
     // Chunk 0 is staged by ALL eight waves, one channel pair each: with the loader alone the block's first barrier came 10 600
     // cycles after its start (48 loads, their HBM round trip at the moment every CU starts a block, 48 LDS writes, all in one wave).
+    // (Staging chunk 1 the same way, also before the first barrier, measured SLOWER: the burst at a block's start runs at the ~11 B/clk
+    // a CU gets while every CU starts a block, so twice the bytes in front of the first barrier moved it from 5 900 to 9 400 cycles.)
     auto stage_pair0 = [&](int q) __attribute__((always_inline)) {
         float r0[NS], r1[NS];
         const int s0 = 2 * q * L4;
