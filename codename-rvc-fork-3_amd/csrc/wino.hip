@@ -71,6 +71,11 @@ __device__ __forceinline__ f32x2 lrelu2(f32x2 v, float slope) {
     asm("v_max_f32 %0, %1, %2" : "=v"(b) : "v"(v.y), "v"(sv.y));
     return f32x2{a, b};
 }
+// the same without inline assembly (ablation build: bisection of the cohabitation finding)
+__device__ __forceinline__ f32x2 lrelu2_plain(f32x2 v, float slope) {
+    const f32x2 sv = v * slope;
+    return f32x2{__builtin_fmaxf(v.x, sv.x), __builtin_fmaxf(v.y, sv.y)};
+}
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
 }
@@ -207,14 +212,14 @@ wino_conv_kernel(const WinoParams p) {
             for (int cp = 0; cp < CP; ++cp)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const f32x2 v = lrelu2(xr[cp * NJ + j], slope);
+                    const f32x2 v = (DBG & 2048) ? lrelu2_plain(xr[cp * NJ + j], slope) : lrelu2(xr[cp * NJ + j], slope);
                     dst[cp * 4 * XTS + loff[j]] = ((inb >> j) & 1) ? v : f32x2{0.f, 0.f};
                 }
         } else {
 #pragma unroll
             for (int cp = 0; cp < CP; ++cp)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) dst[cp * 4 * XTS + loff[j]] = lrelu2(xr[cp * NJ + j], slope);
+                for (int j = 0; j < NJ; ++j) dst[cp * 4 * XTS + loff[j]] = (DBG & 2048) ? lrelu2_plain(xr[cp * NJ + j], slope) : lrelu2(xr[cp * NJ + j], slope);
         }
     };
     // DBG & 64 (ablation build; correct results): the taps by plain loads into registers and ds_write instead of LDS-DMA
@@ -567,6 +572,7 @@ static int wino_launch_kw(const WinoParams &p, hipStream_t stream) {
             case 512: return wino_launch_cfg<3, 2, 2, CIC, 512>(p, stream);
             case 1024: return wino_launch_cfg<3, 2, 2, CIC, 1024>(p, stream);
             case 768: return wino_launch_cfg<3, 2, 2, CIC, 768>(p, stream);
+            case 2048: return wino_launch_cfg<3, 2, 2, CIC, 2048>(p, stream);
             default: break;
         }
     }

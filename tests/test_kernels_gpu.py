@@ -84,6 +84,7 @@ def test_conv1d_winograd_matches_float64(native, dev, c_in, c_out, k, dil, lengt
     (256, 256, 11, 3, 2051, 1), (64, 128, 7, 1, 777, 1), (128, 64, 11, 1, 1234, 2), (64, 64, 11, 5, 9999, 1),
     (256, 256, 7, 5, 300, 2), (128, 128, 11, 3, 31, 1), (64, 64, 7, 1, 16384, 1),
     (128, 256, 11, 5, 1237, 2), (256, 256, 7, 1, 50, 1), (192, 128, 7, 3, 8191, 1),     # 128-row blocks: ragged, short, odd c_in
+    (16, 128, 7, 1, 3000, 1), (48, 128, 11, 3, 5000, 1), (128, 128, 11, 1, 383760, 1),   # one chunk; an odd chunk count; the benchmarked stage-1 shape
 ])
 def test_conv1d_winograd_bf16x3_matches_float64(native, dev, c_in, c_out, k, dil, length, batch):
     """winobf.hip: the F(4,4) form of the 7- / 11-tap ResBlock convs (residuals.py:75-86) on the bf16 matrix cores, every

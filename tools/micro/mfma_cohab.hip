@@ -248,7 +248,7 @@ int main(int argc, char **argv) {
     add_micro("V3 V2 + LDS-DMA taps, vmcnt(0) + LDS-only barrier (wino.hip's skeleton)", micro_victim<3>);
     add_micro("V4 V3 allocated 232 registers per lane (wino_conv_kernel's count)", micro_victim<3, 2>);
     // the library's wino kernel
-    auto add_wino = [&](const char *name, int C, int K, int64_t L) {
+    auto add_wino = [&](const char *name, int C, int K, int64_t L, bool with_res = true) {
         std::vector<float> w((size_t)C * C * K), x((size_t)C * L), bias(C);
         for (auto &v : w) v = (rand() / (float)RAND_MAX - 0.5f) * 0.1f;
         for (auto &v : x) v = (rand() / (float)RAND_MAX - 0.5f) * 2.f;
@@ -260,11 +260,12 @@ int main(int argc, char **argv) {
         CK(hipMemcpy(db, bias.data(), C * 4, hipMemcpyHostToDevice));
         if (rvc_conv1d_wino_pack_weight(w.data(), C, C, K, u, nullptr)) { fprintf(stderr, "pack: %s\n", rvc_last_error()); exit(1); }
         victims.push_back({name, [=](hipStream_t st) {
-            if (rvc_conv1d_wino_forward(dx, u, db, dres, nullptr, y, 1, C, C, L, K, 1, 0.1f, 1.f, st)) { fprintf(stderr, "wino: %s\n", rvc_last_error()); exit(1); }
+            if (rvc_conv1d_wino_forward(dx, u, db, with_res ? dres : nullptr, nullptr, y, 1, C, C, L, K, 1, 0.1f, 1.f, st)) { fprintf(stderr, "wino: %s\n", rvc_last_error()); exit(1); }
         }, y, (size_t)C * L, C});
     };
     add_wino("W3 library wino_conv_kernel, 3 taps, C = 64", 64, 3, 200000);
     add_wino("W11 library wino_conv_kernel, 11 taps, C = 128", 128, 11, 60000);
+    add_wino("X3 library wino_conv_kernel, 3 taps, C = 64, no residual", 64, 3, 200000, false);
 
     // round 3's gemmbf_kernel<1, DBG> (HuBERT conv layer 1: 512 -> 512 channels, 3 taps, stride 2, 51 000 samples in)
     rvc_r03::GemmBfParams gp;
@@ -302,6 +303,11 @@ int main(int argc, char **argv) {
         {"the same kernel without tap LDS-DMA (DBG 4)", gemm_co(rvc_r03::gemmbf_kernel<1, 4>, G), 8},
         {"the same kernel without activation staging (DBG 1)", gemm_co(rvc_r03::gemmbf_kernel<1, 1>, G), 8},
         {"the same kernel without barriers (DBG 8)", gemm_co(rvc_r03::gemmbf_kernel<1, 8>, G), 8},
+        {"the same kernel without tap LDS-DMA AND without activation staging (DBG 5): fragments from LDS + matrix instructions + barriers + epilogue", gemm_co(rvc_r03::gemmbf_kernel<1, 5>, G), 8},
+        {"... and without barriers (DBG 13)", gemm_co(rvc_r03::gemmbf_kernel<1, 13>, G), 8},
+        {"the whole loop but no epilogue (DBG 16: no GELU, no stores)", gemm_co(rvc_r03::gemmbf_kernel<1, 16>, G), 8},
+        {"no DMA, no staging, no epilogue (DBG 21): LDS fragment reads + matrix instructions + barriers only", gemm_co(rvc_r03::gemmbf_kernel<1, 21>, G), 8},
+        {"no DMA, no staging, no barriers, no epilogue (DBG 29)", gemm_co(rvc_r03::gemmbf_kernel<1, 29>, G), 8},
         {"bare bf16 32x32x16 matrix loop, registers only, 4 waves, 60 KB LDS", bare_co(launch_co<0, 4>, 40000, 60 * 1024), 6},
         {"the same bare bf16 matrix loop allocated 144 registers per lane (gemmbf's count)", bare_co(launch_co<0, 4, 1>, 40000, 60 * 1024), 6},
         {"the same bare bf16 matrix loop allocated 232 registers per lane", bare_co(launch_co<0, 4, 2>, 40000, 60 * 1024), 6},
