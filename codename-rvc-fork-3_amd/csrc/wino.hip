@@ -269,6 +269,7 @@ wino_conv_kernel(const WinoParams p) {
         const int buf = c & 1;
         // buffer buf ^ 1 was last read in iteration c - 1 and every wave has passed that iteration's barrier
         if (!(DBG & 4) && c + 1 < n_chunks) dma_u(buf ^ 1, c + 1);
+        if constexpr (DBG & 4096) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ablation: no memory return lands while the matrix instructions run
         const f32x2 *ua = us + buf * UTOT + wm * 32 + l31;
         const unsigned *ua16 = reinterpret_cast<const unsigned *>(us + buf * UTOT) + wm * 32 + l31;
         const f32x2 *xb = xs + buf * XTOT + col - MLO * d;
@@ -573,6 +574,8 @@ static int wino_launch_kw(const WinoParams &p, hipStream_t stream) {
             case 1024: return wino_launch_cfg<3, 2, 2, CIC, 1024>(p, stream);
             case 768: return wino_launch_cfg<3, 2, 2, CIC, 768>(p, stream);
             case 2048: return wino_launch_cfg<3, 2, 2, CIC, 2048>(p, stream);
+            case 4096: return wino_launch_cfg<3, 2, 2, CIC, 4096>(p, stream);
+            case 4160: return wino_launch_cfg<3, 2, 2, CIC, 4160>(p, stream);
             default: break;
         }
     }
