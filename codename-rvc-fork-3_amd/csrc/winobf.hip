@@ -599,7 +599,9 @@ int winobf_block_rows(int c_out, int k) {
     return (k == 7 || c_out >= 256 || wide == 2) ? 128 : 64;
 }
 
+// (3 taps: winobf2.hip's F(4,3) form only, i.e. c_out % 128 == 0)
 bool winobf_supported(int c_in, int c_out, int k, int dil) {
+    if (k == 3) return dil >= 1 && dil <= WBF_MAX_DIL && winobf_takes_v2(c_in, c_out, k);
     return (k == 7 || k == 11) && dil >= 1 && dil <= WBF_MAX_DIL && c_in % WBF_CIC == 0 && c_out % 64 == 0;
 }
 
@@ -607,7 +609,7 @@ bool winobf_fits(int c_in, int c_out, int64_t L) {
     return (int64_t)c_in * L < ((int64_t)1 << 29) && (int64_t)c_in * c_out * WBF_NP * 3 * 6 < ((int64_t)1 << 31);
 }
 
-size_t winobf_weight_bytes(int c_out, int c_in, int k) { return (size_t)c_out * c_in * WBF_NP * ((k + 3) / 4) * 3 * 2; }
+size_t winobf_weight_bytes(int c_out, int c_in, int k) { return (size_t)c_out * c_in * (k == 3 ? 6 : WBF_NP * ((k + 3) / 4)) * 3 * 2; }
 
 int launch_winobf_conv(const float *x, const void *u, const float *bias, const float *res, const float *accin, float *y, int batch,
                        int c_in, int c_out, int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream) {
@@ -651,9 +653,10 @@ int launch_winobf_conv(const float *x, const void *u, const float *bias, const f
 // (lane l: channel l & 31, input channels 8 (l >> 5) .. + 7).
 void winobf_pack_host(const float *w_host, int c_out, int c_in, int k, std::vector<uint16_t> *out) {
     const int BM = winobf_block_rows(c_out, k), WM = BM / 32;
-    const int G = (k + 3) / 4, n_chunks = c_in / WBF_CIC, n_m = c_out / BM;
+    const int R = k == 3 ? 3 : 4, NPT = R + 3;          // 3 taps: F(4,3), one group on the points 0, 1, -1, 2, -2, inf (winobf2.hip only)
+    const int G = (k + R - 1) / R, n_chunks = c_in / WBF_CIC, n_m = c_out / BM;
     const bool point_major = winobf_takes_v2(c_in, c_out, k);
-    out->assign((size_t)c_out * c_in * WBF_NP * G * 3, 0);
+    out->assign((size_t)c_out * c_in * NPT * G * 3, 0);
     auto split3 = [](float v, uint16_t s[3]) {
         float r = v;
         for (int i = 0; i < 3; ++i) {
@@ -666,7 +669,7 @@ void winobf_pack_host(const float *w_host, int c_out, int c_in, int k, std::vect
     };
     for (int mb = 0; mb < n_m; ++mb)
         for (int c = 0; c < n_chunks; ++c)
-            for (int pt = 0; pt < WBF_NP; ++pt)
+            for (int pt = 0; pt < NPT; ++pt)
                 for (int g = 0; g < G; ++g)
                     for (int mi = 0; mi < WM; ++mi)
                         for (int lane = 0; lane < 64; ++lane)
@@ -675,11 +678,19 @@ void winobf_pack_host(const float *w_host, int c_out, int c_in, int k, std::vect
                                 const int ci = c * WBF_CIC + 8 * (lane >> 5) + e;
                                 double w[4];
                                 for (int kk = 0; kk < 4; ++kk) {
-                                    const int tap = 4 * g + kk;
+                                    const int tap = R * g + kk;
                                     w[kk] = tap < k ? (double)w_host[((size_t)co * c_in + ci) * k + tap] : 0.0;
                                 }
                                 double u;
-                                switch (pt) {
+                                if (R == 3) switch (pt) {   // rows of G3 without their scale factors (the epilogue's)
+                                    case 0: u = w[0]; break;
+                                    case 1: u = w[0] + w[1] + w[2]; break;
+                                    case 2: u = w[0] - w[1] + w[2]; break;
+                                    case 3: u = w[0] + 2.0 * w[1] + 4.0 * w[2]; break;
+                                    case 4: u = w[0] - 2.0 * w[1] + 4.0 * w[2]; break;
+                                    default: u = w[2]; break;
+                                }
+                                else switch (pt) {
                                     case 0: u = w[0]; break;
                                     case 1: u = w[0] + w[1] + w[2] + w[3]; break;
                                     case 2: u = w[0] - w[1] + w[2] - w[3]; break;
@@ -691,7 +702,7 @@ void winobf_pack_host(const float *w_host, int c_out, int c_in, int k, std::vect
                                 uint16_t s[3];
                                 split3((float)u, s);
                                 // this kernel walks (chunk, point); winobf2.hip's waves each own a point and walk its chunks
-                                const size_t step = point_major ? ((size_t)mb * WBF_NP + pt) * n_chunks + c : ((size_t)mb * n_chunks + c) * WBF_NP + pt;
+                                const size_t step = point_major ? ((size_t)mb * NPT + pt) * n_chunks + c : ((size_t)mb * n_chunks + c) * NPT + pt;
                                 for (int sp = 0; sp < 3; ++sp) {
                                     const size_t piece = ((step * G + g) * WM + mi) * 3 + sp;
                                     (*out)[piece * 512 + lane * 8 + e] = s[sp];
@@ -700,7 +711,7 @@ void winobf_pack_host(const float *w_host, int c_out, int c_in, int k, std::vect
 }
 
 int winobf_pack_weight(const float *w_host, int c_out, int c_in, int k, void **out_dev) {
-    if (c_in % WBF_CIC || c_out % 64 || !(k == 7 || k == 11)) return fail("winobf_pack_weight: unsupported shape");
+    if (!winobf_supported(c_in, c_out, k, 1)) return fail("winobf_pack_weight: unsupported shape");
     std::vector<uint16_t> u;
     winobf_pack_host(w_host, c_out, c_in, k, &u);
     hipError_t e = hipMalloc(out_dev, u.size() * sizeof(uint16_t));
@@ -714,8 +725,8 @@ int winobf_pack_weight(const float *w_host, int c_out, int c_in, int k, void **o
 using namespace rvc;
 
 extern "C" int rvc_conv1d_winobf_weight_bytes(int c_out, int c_in, int k, size_t *bytes) {
-    if (!bytes || c_in <= 0 || c_out <= 0 || c_in % WBF_CIC || c_out % 64 || !(k == 7 || k == 11))
-        return fail("rvc_conv1d_winobf_weight_bytes: c_in must be a multiple of 16, c_out of 64, k 7 or 11");
+    if (!bytes || c_in <= 0 || c_out <= 0 || !winobf_supported(c_in, c_out, k, 1))
+        return fail("rvc_conv1d_winobf_weight_bytes: c_in must be a multiple of 16, c_out of 64, k 7 or 11 (k 3: c_out a multiple of 128)");
     *bytes = winobf_weight_bytes(c_out, c_in, k);
     return 0;
 }

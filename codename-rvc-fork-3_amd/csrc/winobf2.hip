@@ -54,7 +54,7 @@ struct Wbf2Params {
 };
 
 constexpr int W2_MAX_DIL = 5;
-constexpr int W2_NTH = 512, W2_BNT = 64, W2_CIC = 16, W2_CP = 8, W2_NP = 7, W2_R = 4;
+constexpr int W2_NTH = 512, W2_BNT = 64, W2_CIC = 16, W2_CP = 8, W2_R = 4, W2_LOADER = 7;
 
 typedef float w2_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 w2_bf16x2 __attribute__((ext_vector_type(2)));
@@ -79,27 +79,39 @@ __constant__ float W2_BT[7][8] = {
     {0.f, 0.25f, 0.f, -1.25f, 0.f, 1.f, 0.f, 0.f},
     {0.f, -0.5f, 0.25f, 2.5f, -1.25f, -2.f, 1.f, 0.f},
 };
+// ... and of F(4,3)'s (three taps: one group, six points 0, 1, -1, 2, -2, inf on a six-sample window; wino.hip's expressions)
+__constant__ float W2_BT3[6][8] = {
+    {4.f, 0.f, -5.f, 0.f, 1.f, 0.f, 0.f, 0.f},
+    {0.f, -4.f, -4.f, 1.f, 1.f, 0.f, 0.f, 0.f},
+    {0.f, 4.f, -4.f, -1.f, 1.f, 0.f, 0.f, 0.f},
+    {0.f, -2.f, -1.f, 2.f, 1.f, 0.f, 0.f, 0.f},
+    {0.f, 2.f, -1.f, -2.f, 1.f, 0.f, 0.f, 0.f},
+    {0.f, 4.f, 0.f, -5.f, 0.f, 1.f, 0.f, 0.f},
+};
 
 template <int KW, int BM>
 struct W2Geom {
-    static constexpr int G = (KW + W2_R - 1) / W2_R;
+    static constexpr int R = KW == 3 ? 3 : W2_R;                         // taps per group: F(4,3) for the 3-tap layers, F(4,4) groups otherwise
+    static constexpr int NP = R + 3;                                     // transform points = samples of a window = compute waves
+    static constexpr int G = (KW + R - 1) / R;
     static constexpr int C0 = (KW - 1) / 2;
-    // one window's samples sit at offsets (n - C0) d, n = 0..6: super-block steps MLO .. 0
+    // one window's samples sit at offsets (n - C0) d, n = 0..NP-1: super-block steps MLO .. MHI
     static constexpr int MLO = -((C0 + 3) / 4);
-    static_assert(6 - C0 < 4 && 6 - C0 >= 0, "the window's last sample lies in its own super-block");
+    static constexpr int MHI = (NP - 1 - C0) / 4;                        // 1 for three taps (sample 4 d is the next super-block's first), else 0
+    static_assert(NP - 1 - C0 >= 0 && MHI <= 1, "");
     static constexpr int WM = BM / 32, WN = W2_BNT / 32;
-    static constexpr int XT = W2_BNT + (G - 1 - MLO) * W2_MAX_DIL;      // raw tiles per row: 64 + (G - 1) d windows + the -MLO d tiles in front
+    static constexpr int XT = W2_BNT + (G - 1 - MLO + MHI) * W2_MAX_DIL;   // raw tiles per row: 64 + (G - 1) d windows + the -MLO d tiles in front (+ MHI d behind)
     static constexpr int XTS = ((XT - 12 + 31) / 32) * 32 + 12;          // row stride in float2, == 12 mod 32 (ds_write_b64 of 4 rows: 4 bank groups)
     static_assert(XTS >= XT + 2, "");
     static constexpr int RAW_BYTES = W2_CP * 4 * XTS * 8;               // one raw chunk; two buffers
     static constexpr int XB = W2_BNT + (G - 1) * W2_MAX_DIL;             // window fragments per (split, k half): the products read up to here
     static constexpr int B_PLANE = XB * 16;
     static constexpr int B_WAVE = 3 * 2 * B_PLANE;                      // [split][k half][window][8 bf16], one chunk of one point
-    static constexpr int B_BYTES = W2_NP * 2 * B_WAVE;                  // every compute wave: two chunks
+    static constexpr int B_BYTES = NP * 2 * B_WAVE;                  // every compute wave: two chunks
     static constexpr int LOOP_BYTES = 2 * RAW_BYTES + B_BYTES;
     static constexpr int NJ = (4 * XT + 63) / 64;                       // staged samples per loader lane per channel row
     // epilogue, per pass of one row-block pair (64 channels x 64 columns): the 7 points' accumulators, then the output tile
-    static constexpr int RED_BYTES = W2_NP * 4 * 4096;
+    static constexpr int RED_BYTES = NP * 4 * 4096;
     static constexpr int YS = 4 * W2_BNT + 4;
     static constexpr int OUT_BYTES = 64 * YS * 4;
     static constexpr int EPI_BYTES = RED_BYTES > OUT_BYTES ? RED_BYTES : OUT_BYTES;
@@ -113,7 +125,7 @@ template <int KW, int BM, int DBG = 0>
 __global__ void __launch_bounds__(W2_NTH) __attribute__((amdgpu_waves_per_eu(2, 2)))
 winobf2_conv_kernel(const Wbf2Params p) {
     using GM = W2Geom<KW, BM>;
-    constexpr int NP = W2_NP, G = GM::G, C0 = GM::C0, MLO = GM::MLO, WM = GM::WM, CP = W2_CP, CIC = W2_CIC;
+    constexpr int NP = GM::NP, G = GM::G, C0 = GM::C0, MLO = GM::MLO, MHI = GM::MHI, WM = GM::WM, CP = W2_CP, CIC = W2_CIC;
     constexpr int XT = GM::XT, XTS = GM::XTS, NJ = GM::NJ, BNT = W2_BNT;
     constexpr int NPAIR = WM / 2;                         // row-block pairs (two 32-channel blocks each)
     constexpr int NSA = 3;                                // bf16 numbers per transformed tap (exact split of an fp32 value)
@@ -142,7 +154,7 @@ winobf2_conv_kernel(const Wbf2Params p) {
     const int64_t L = p.L;
     const int c_in = p.c_in, c_out = p.c_out;
     const int n_chunks = c_in / CIC;
-    const bool loader = wave == NP;
+    const bool loader = wave == W2_LOADER;                 // (three taps: six points, wave 6 only lends a hand with chunk 0 and the epilogue)
     // DBG & 128 (ablation build): wave 0 and the loader write s_memtime stamps to the buffer passed as `accin` (which is then NOT
     // added): [block][wave 0 | loader][32] -- tools/stamp_winobf2.py turns them into a per-phase breakdown
     unsigned long long *const stamps = (DBG & 128) ? reinterpret_cast<unsigned long long *>(const_cast<float *>(p.accin)) + ((size_t)blockIdx.x * 2 + (loader ? 1 : 0)) * 32 : nullptr;
@@ -214,7 +226,7 @@ winobf2_conv_kernel(const Wbf2Params p) {
         const float *const px = p.x + (int64_t)b * c_in * L;
     const float slope = p.slope;
     const int E = (G - 1) * d;                                     // halo windows
-    const int xt_used = (p.sb_per_block + G - 1 - MLO) * d;      // valid tiles + the (G - 1) d windows behind them + the -MLO d in front
+    const int xt_used = (p.sb_per_block + G - 1 - MLO + MHI) * d;   // valid tiles + the (G - 1) d windows behind them + the -MLO d in front (+ MHI d behind)
     const int64_t t_start = (sb0 + MLO) * 4 * d;
     const int span = 4 * xt_used;                                  // staged samples per row (a multiple of 4, <= 4 XT)
     const bool edge = t_start < 0 || t_start + span > L;
@@ -320,12 +332,12 @@ winobf2_conv_kernel(const Wbf2Params p) {
         return;
     }
     // halo windows: item = lane + 64 r -> (window 64 + e, point hp, unit hu = channel pairs 2 hu, 2 hu + 1)
-    constexpr int HR = ((G - 1) * W2_MAX_DIL * 28 + 63) / 64;
+    constexpr int HR = G > 1 ? ((G - 1) * W2_MAX_DIL * 28 + 63) / 64 : 1;   // (one tap group: no halo, the arrays below stay unused)
     int h_src[HR], h_dst[HR];
     float hbt[HR][7];
     bool h_on[HR];
 #pragma unroll
-    for (int r = 0; r < HR; ++r) {
+    for (int r = 0; r < (G > 1 ? HR : 0); ++r) {
         const int it = lane + 64 * r;
         h_on[r] = it < E * 28;
         const int itc = h_on[r] ? it : 0;
@@ -337,7 +349,7 @@ winobf2_conv_kernel(const Wbf2Params p) {
     }
     auto halo = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
-        for (int r = 0; r < HR; ++r) {
+        for (int r = 0; r < (G > 1 ? HR : 0); ++r) {
             if (!h_on[r]) continue;
             const w2_f32x2 *const raw = xs + (c & 1) * XRAW + h_src[r];
             unsigned w[3][2];
@@ -396,7 +408,7 @@ winobf2_conv_kernel(const Wbf2Params p) {
             run(std::false_type{}, std::true_type{});
         }
     };
-    if (loader) {
+    if (wave >= NP) {
         // ================================ wave 7: raw input rows, and the halo windows ========================================
         // (a) stages the raw rows: chunk c + 3 is FETCHED during phase c (into registers), chunk c + 2 -- fetched a phase earlier --
         //     is written to LDS buffer c & 1 at the start of phase c.  Fetch and write in the same phase made this wave the slowest
@@ -410,16 +422,21 @@ winobf2_conv_kernel(const Wbf2Params p) {
         // This wave shares its SIMD with compute wave 3 and, being the youngest, loses every issue arbitration to it: measured, its
         // ~650 instructions per phase took longer than the compute waves' whole phase.  Its work is small and on the block's
         // critical path (the barrier), so it gets the SIMD's issue slots first.
-        __builtin_amdgcn_s_setprio(2);
+        if (loader) __builtin_amdgcn_s_setprio(2);
         run_staging();
+        if (!loader) {   // three taps, wave 6: no point of its own -- its channel pair of chunk 0 is staged, now it keeps the barriers company
+            lds_barrier();                                // (P1)
+            lds_barrier();                                // (P2)
+            for (int c = 0; c < n_chunks; ++c) lds_barrier();
+        }
     } else {
         // ================================ waves 0..6: point `wave` of every output tile =====================================
         const int pt = wave;
         unsigned char *const bs = bs_all + pt * 2 * GM::B_WAVE;
         // input transform coefficients of this point (wave-uniform: scalar registers)
-        float bt[7];
+        float bt[NP];
 #pragma unroll
-        for (int n = 0; n < 7; ++n) bt[n] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, W2_BT[pt][n])));
+        for (int n = 0; n < NP; ++n) bt[n] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, KW == 3 ? W2_BT3[pt][n] : W2_BT[pt][n])));
         // tap fragments: [c_out / BM][point][chunk][group][row block][split][lane][8 bf16], 1 KiB each -- for one (block, point)
         // the groups (chunk, tap group, row-block pair) follow each other in the order the wave consumes them, 6 KiB apiece: one
         // running scalar offset, the six pieces at immediate offsets
@@ -450,7 +467,7 @@ winobf2_conv_kernel(const Wbf2Params p) {
         };
         // ---- input transform of chunk c for this point: lane = window, unit u = channel pairs 2u, 2u + 1 -------------------
         const int t_src = -MLO * d + lane;                 // raw tile of the window's own super-block
-        w2_f32x2 tq[2][7];
+        w2_f32x2 tq[2][NP];
         w2_f32x2 tv[2];
         unsigned tw[3][2];
         auto t_read = [&](int c, int u) __attribute__((always_inline)) {
@@ -458,7 +475,7 @@ winobf2_conv_kernel(const Wbf2Params p) {
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int n = 0; n < 7; ++n) {
+                for (int n = 0; n < NP; ++n) {
                     const int sh = n - C0;
                     tq[e][n] = raw[((2 * u + e) * 4 + (sh & 3)) * XTS + (sh >> 2) * d];
                 }
@@ -472,7 +489,7 @@ winobf2_conv_kernel(const Wbf2Params p) {
                 b2 = __builtin_elementwise_fma(w2_f32x2{bt[3], bt[3]}, tq[e][3], b2);
                 a = __builtin_elementwise_fma(w2_f32x2{bt[4], bt[4]}, tq[e][4], a);
                 b2 = __builtin_elementwise_fma(w2_f32x2{bt[5], bt[5]}, tq[e][5], b2);
-                a = __builtin_elementwise_fma(w2_f32x2{bt[6], bt[6]}, tq[e][6], a);
+                if constexpr (NP == 7) a = __builtin_elementwise_fma(w2_f32x2{bt[6], bt[6]}, tq[e][6], a);
                 tv[e] = a + b2;
             }
         };
@@ -598,7 +615,7 @@ winobf2_conv_kernel(const Wbf2Params p) {
 #pragma unroll
     for (int pr = 0; pr < NPAIR; ++pr) {
         if (pr > 0) lds_barrier();                        // the previous pass's tile has been read back
-        if (!loader) {
+        if (wave < NP) {
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -629,13 +646,22 @@ winobf2_conv_kernel(const Wbf2Params p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float bv = bq[e];
-                const float t0 = v[0][e] * -2.f, t1 = v[1][e] * (-2.f / 3.f), t2 = v[2][e] * (-2.f / 9.f), t3 = v[3][e] * (16.f / 9.f),
-                            t4 = v[4][e] * (16.f / 15.f), t5 = v[5][e] * (2.f / 45.f), t6 = v[6][e];
-                const float s12 = t1 + t2, m12 = t1 - t2, s34 = t3 + t4, m34 = t3 - t4;
-                o[gi][e].x = (t0 + s12) + (s34 + t5) + bv;
-                o[gi][e].y = fmaf(0.5f, m34, m12) + fmaf(2.f, t5, bv);
-                o[gi][e].z = fmaf(0.25f, s34, s12) + fmaf(4.f, t5, bv);
-                o[gi][e].w = fmaf(0.125f, m34, m12) + fmaf(8.f, t5, t6) + bv;
+                if constexpr (KW == 3) {   // F(4,3): A^T diag(1/4, -1/6, -1/6, 1/24, 1/24, 1), wino.hip's expression
+                    const float d0 = v[0][e], d1 = v[1][e], d2 = v[2][e], d3 = v[3][e], d4 = v[4][e], d5 = v[5][e];
+                    const float s12 = (d1 + d2) * (-1.f / 6.f), m12 = (d1 - d2) * (-1.f / 6.f), s34 = (d3 + d4) * (1.f / 24.f), m34 = (d3 - d4) * (1.f / 24.f);
+                    o[gi][e].x = fmaf(0.25f, d0, s12 + s34) + bv;
+                    o[gi][e].y = fmaf(2.f, m34, m12) + bv;
+                    o[gi][e].z = fmaf(4.f, s34, s12) + bv;
+                    o[gi][e].w = fmaf(8.f, m34, m12) + d5 + bv;
+                } else {
+                    const float t0 = v[0][e] * -2.f, t1 = v[1][e] * (-2.f / 3.f), t2 = v[2][e] * (-2.f / 9.f), t3 = v[3][e] * (16.f / 9.f),
+                                t4 = v[4][e] * (16.f / 15.f), t5 = v[5][e] * (2.f / 45.f), t6 = v[6][e];
+                    const float s12 = t1 + t2, m12 = t1 - t2, s34 = t3 + t4, m34 = t3 - t4;
+                    o[gi][e].x = (t0 + s12) + (s34 + t5) + bv;
+                    o[gi][e].y = fmaf(0.5f, m34, m12) + fmaf(2.f, t5, bv);
+                    o[gi][e].z = fmaf(0.25f, s34, s12) + fmaf(4.f, t5, bv);
+                    o[gi][e].w = fmaf(0.125f, m34, m12) + fmaf(8.f, t5, t6) + bv;
+                }
             }
         }
         if (direct) {
@@ -762,11 +788,11 @@ static int winobf2_launch(Wbf2Params p, hipStream_t stream) {
 // too short a K loop to pay for this kernel's prologue and its output transform through LDS -- measured 1.17-1.28x slower than
 // winobf.hip's 64 x 128 blocks, profiles/r04_convbf_shapes_v2_first.txt) stay on winobf.hip.
 bool winobf2_supported(int c_in, int c_out, int k, int dil) {
-    return (k == 7 || k == 11) && dil >= 1 && dil <= W2_MAX_DIL && c_in % W2_CIC == 0 && c_out % 128 == 0;
+    return (k == 3 || k == 7 || k == 11) && dil >= 1 && dil <= W2_MAX_DIL && c_in % W2_CIC == 0 && c_out % 128 == 0;
 }
 
 bool winobf2_fits(int c_in, int c_out, int64_t L) {
-    return (int64_t)c_in * L < ((int64_t)1 << 29) && (int64_t)c_in * c_out * W2_NP * 3 * 6 < ((int64_t)1 << 31);
+    return (int64_t)c_in * L < ((int64_t)1 << 29) && (int64_t)c_in * c_out * 7 * 3 * 6 < ((int64_t)1 << 31);
 }
 
 int launch_winobf2_conv(const float *x, const void *u, const float *bias, const float *res, const float *accin, float *y, int batch,
@@ -799,7 +825,7 @@ int launch_winobf2_conv(const float *x, const void *u, const float *bias, const 
         }
     }
 #endif
-    return k == 7 ? winobf2_launch<7, 128>(p, stream) : winobf2_launch<11, 128>(p, stream);
+    return k == 3 ? winobf2_launch<3, 128>(p, stream) : k == 7 ? winobf2_launch<7, 128>(p, stream) : winobf2_launch<11, 128>(p, stream);
 }
 
 }  // namespace rvc

@@ -85,9 +85,13 @@ def test_conv1d_winograd_matches_float64(native, dev, c_in, c_out, k, dil, lengt
     (256, 256, 7, 5, 300, 2), (128, 128, 11, 3, 31, 1), (64, 64, 7, 1, 16384, 1),
     (128, 256, 11, 5, 1237, 2), (256, 256, 7, 1, 50, 1), (192, 128, 7, 3, 8191, 1),     # 128-row blocks: ragged, short, odd c_in
     (16, 128, 7, 1, 3000, 1), (48, 128, 11, 3, 5000, 1), (128, 128, 11, 1, 383760, 1),   # one chunk; an odd chunk count; the benchmarked stage-1 shape
+    # three taps (F(4,3), six points, winobf2.hip only): every dilation, ragged lengths, batch, one chunk, odd chunk count, full length
+    (128, 128, 3, 1, 4096, 1), (128, 128, 3, 3, 4097, 1), (256, 256, 3, 5, 2051, 2), (128, 128, 3, 5, 31, 1), (256, 128, 3, 1, 777, 1),
+    (16, 128, 3, 1, 3000, 1), (48, 128, 3, 3, 5000, 1), (256, 256, 3, 1, 50, 2), (128, 128, 3, 2, 9999, 1), (128, 128, 3, 1, 383760, 1),
 ])
 def test_conv1d_winograd_bf16x3_matches_float64(native, dev, c_in, c_out, k, dil, length, batch):
-    """winobf.hip: the F(4,4) form of the 7- / 11-tap ResBlock convs (residuals.py:75-86) on the bf16 matrix cores, every
+    """winobf.hip / winobf2.hip: the F(4,4) form of the 7- / 11-tap ResBlock convs and the F(4,3) form of the 3-tap ones at
+    >= 128 channels (residuals.py:75-86) on the bf16 matrix cores, every
     fp32 operand split exactly into three bf16 and the six products of order <= 2^-16 accumulated in fp32.  Against
     F.conv1d in float64 with the fused activation, bias, residual, running sum and scale; every dilation, lengths that are
     not multiples of a tile, blocks with ragged tile counts, batch > 1.  The gate is the fp32 Winograd form's (6e-5 at

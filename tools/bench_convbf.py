@@ -32,7 +32,7 @@ for C, L in ((256, 38376), (128, 383760), (64, 767520)):
             msw = timed(lambda: _native.conv1d_wino_forward(x, u, bias, C, K, dil, 0.1, res=res, out=y))
             msb = timed(lambda: _native.conv1d_winobf_forward(x, ub, bias, C, K, dil, 0.1, res=res, out=y))
             gf = 2.0 * C * C * K * L / 1e9
-            G = (K + 3) // 4
-            exe = 2.0 * C * C * 7 * G * (L / 4) * 6 / 1e9      # bf16 matrix flops executed
+            G = (K + 3) // 4 if K != 3 else 1
+            exe = 2.0 * C * C * (6 if K == 3 else 7) * G * (L / 4) * 6 / 1e9      # bf16 matrix flops executed
             print(f"C={C:3d} K={K:2d} d={dil} L={L:7d}: direct {msd*1e3:7.1f} us | fp32 winograd {msw*1e3:7.1f} us | bf16x3 winograd {msb*1e3:7.1f} us "
                   f"x{msw/msb:.2f} ({gf/msb:6.1f} TF/s algorithmic, {exe/msb:6.1f} TF/s on the bf16 pipe = {exe/msb/2500*100:.0f} % of 2.5 PF)", flush=True)
