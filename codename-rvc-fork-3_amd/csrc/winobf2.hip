@@ -534,6 +534,7 @@ winobf2_conv_kernel(const Wbf2Params p) {
         //   * the window fragments of the next tap group, split by split, as soon as the last product on a split has been issued;
         //   * the tap loads of group q + 2.
         constexpr int NQ = G * NPAIR;
+        static_assert(NQ >= 2, "the next chunk's transform needs a group in front of the one that re-reads its fragments");
         constexpr int ia6[6] = {0, 1, 0, 2, 1, 0}, ib6[6] = {2, 1, 1, 0, 0, 0};
         auto phase = [&](int c, auto PAR) __attribute__((always_inline)) {
             constexpr int par = decltype(PAR)::value;
@@ -787,8 +788,12 @@ static int winobf2_launch(Wbf2Params p, hipStream_t stream) {
 // This form runs 128-row blocks; layers whose c_out is not a multiple of 128 (the 64-channel stage: four 16-channel chunks are
 // too short a K loop to pay for this kernel's prologue and its output transform through LDS -- measured 1.17-1.28x slower than
 // winobf.hip's 64 x 128 blocks, profiles/r04_convbf_shapes_v2_first.txt) stay on winobf.hip.
+static bool w2_rows64() {   // ablation build: 64-row blocks for c_out % 128 != 0 (A/B against winobf.hip)
+    static const int on = knob("RVC_WBF_V2_64", 0);
+    return on != 0;
+}
 bool winobf2_supported(int c_in, int c_out, int k, int dil) {
-    return (k == 3 || k == 7 || k == 11) && dil >= 1 && dil <= W2_MAX_DIL && c_in % W2_CIC == 0 && c_out % 128 == 0;
+    return (k == 3 || k == 7 || k == 11) && dil >= 1 && dil <= W2_MAX_DIL && c_in % W2_CIC == 0 && (c_out % 128 == 0 || (w2_rows64() && c_out % 64 == 0 && k != 3));
 }
 
 bool winobf2_fits(int c_in, int c_out, int64_t L) {
@@ -824,6 +829,8 @@ int launch_winobf2_conv(const float *x, const void *u, const float *bias, const 
             default: break;
         }
     }
+    if (k == 3 && c_out % 128 == 0 && knob("RVC_W2_DBG", 0) == 128) return winobf2_launch<3, 128, 128>(p, stream);
+    if (c_out % 128) return k == 7 ? winobf2_launch<7, 64>(p, stream) : winobf2_launch<11, 64>(p, stream);
 #endif
     return k == 3 ? winobf2_launch<3, 128>(p, stream) : k == 7 ? winobf2_launch<7, 128>(p, stream) : winobf2_launch<11, 128>(p, stream);
 }

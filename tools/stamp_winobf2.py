@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-phase cycle breakdown of winobf2_conv_kernel<11,128> (ablation build, RVC_W2_DBG=128: wave 0 and the loader wave stamp
+"""Per-phase cycle breakdown of winobf2_conv_kernel<11,128> (K=3 in the environment: <3,128>) (ablation build, RVC_W2_DBG=128: wave 0 and the loader wave stamp
 s_memtime at every barrier).  C = 128, K = 11, 383 760 columns, d from the environment (D, default 1)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +9,7 @@ os.environ["RVC_W2_DBG"] = "128"
 import numpy as np, torch
 from rvc_amd import _native
 dev = "cuda:0"
-C, K, L, D = int(os.environ.get("C", 128)), 11, int(os.environ.get("L", 383760)), int(os.environ.get("D", 1))
+C, K, L, D = int(os.environ.get("C", 128)), int(os.environ.get("K", 11)), int(os.environ.get("L", 383760)), int(os.environ.get("D", 1))
 x = torch.randn(1, C, L, device=dev); res = torch.randn(1, C, L, device=dev); bias = torch.zeros(C, device=dev)
 u = _native.conv1d_winobf_pack_weight(torch.randn(C, C, K) * 0.03, dev)
 stamps = torch.zeros(1, C, L, device=dev)          # the kernel writes [block][2][32] uint64 into it
