@@ -222,7 +222,7 @@ winobf2_conv_kernel(const Wbf2Params p) {
         }
     }
     };
-    // ---- raw-row staging (the loader wave's job; every wave lends a hand with chunk 0, see stage_pair0) ---------------------
+    // ---- raw-row staging (the loader wave's job; every wave lends a hand with chunk 0, see pair0_load) ---------------------
         const float *const px = p.x + (int64_t)b * c_in * L;
     const float slope = p.slope;
     const int E = (G - 1) * d;                                     // halo windows
@@ -264,23 +264,29 @@ winobf2_conv_kernel(const Wbf2Params p) {
         const int64_t t0 = t_start + 4 * lane;
         goff[0] = (unsigned)(t0 < 0 ? 0 : (t0 > L - 4 ? L - 4 : t0)) * 4u;
     }
-    float xr[2 * CP][NS];                                         // [row of the chunk][slot]
-    auto load = [&](int c) __attribute__((always_inline)) {
+    // one tap group (3 taps): a phase is ~4 400 cycles of matrix work, about an HBM round trip under this kernel's own traffic --
+    // with one register set (chunk c + 3 requested in phase c AFTER chunk c + 2 has been written out of it) this wave reached
+    // every barrier ~2 400 cycles after the compute waves.  Two sets there: chunk c + 3 is requested FIRST THING in phase c.
+    constexpr int NSET = G == 1 ? 2 : 1;
+    float xr[NSET][2 * CP][NS];                                   // [set][row of the chunk][slot]
+    auto load = [&](int c, auto SET) __attribute__((always_inline)) {
+        constexpr int st = decltype(SET)::value;
 #pragma unroll
         for (int row = 0; row < 2 * CP; ++row) {
             const int s0 = (c * CIC + row) * L4;
             if constexpr (wide) {
                 const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)goff[0], s0, 0));
-                xr[row][0] = v.x; xr[row][1] = v.y; xr[row][2] = v.z; xr[row][3] = v.w;
+                xr[st][row][0] = v.x; xr[st][row][1] = v.y; xr[st][row][2] = v.z; xr[st][row][3] = v.w;
 #pragma unroll
-                for (int k = 4; k < NS_W; ++k) xr[row][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)goff[k], s0, 0));
+                for (int k = 4; k < NS_W; ++k) xr[st][row][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)goff[k], s0, 0));
             } else {
 #pragma unroll
-                for (int k = 0; k < NS_N; ++k) xr[row][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)goff[k], s0, 0));
+                for (int k = 0; k < NS_N; ++k) xr[st][row][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)goff[k], s0, 0));
             }
         }
     };
-    auto write = [&](int c) __attribute__((always_inline)) {
+    auto write = [&](int c, auto SET) __attribute__((always_inline)) {
+        constexpr int st = decltype(SET)::value;
         w2_f32x2 *const dst0 = xs + (c & 1) * XRAW;
 #pragma unroll
         for (int q = 0; q < CP; ++q) {
@@ -288,7 +294,7 @@ winobf2_conv_kernel(const Wbf2Params p) {
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
                 if (wide ? k >= NS_W : k >= NS_N) continue;
-                const w2_f32x2 v = w2_lrelu2(w2_f32x2{xr[2 * q][k], xr[2 * q + 1][k]}, slope);
+                const w2_f32x2 v = w2_lrelu2(w2_f32x2{xr[st][2 * q][k], xr[st][2 * q + 1][k]}, slope);
                 if constexpr (edge_c) dst[loff[k]] = w2_f32x2{__uint_as_float(__float_as_uint(v.x) & keep[k]), __uint_as_float(__float_as_uint(v.y) & keep[k])};
                 else dst[loff[k]] = v;
             }
@@ -298,8 +304,10 @@ winobf2_conv_kernel(const Wbf2Params p) {
     // cycles after its start (48 loads, their HBM round trip at the moment every CU starts a block, 48 LDS writes, all in one wave).
     // (Staging chunk 1 the same way, also before the first barrier, measured SLOWER: the burst at a block's start runs at the ~11 B/clk
     // a CU gets while every CU starts a block, so twice the bytes in front of the first barrier moved it from 5 900 to 9 400 cycles.)
-    auto stage_pair0 = [&](int q) __attribute__((always_inline)) {
-        float r0[NS], r1[NS];
+    // (the loader puts its requests for chunks 1 and 2 BETWEEN this pair's loads and their use: loads return in order, and the first
+    // barrier waits for chunk 0 only)
+    float r0[NS], r1[NS];
+    auto pair0_load = [&](int q) __attribute__((always_inline)) {
         const int s0 = 2 * q * L4;
         if constexpr (wide) {
             const f32x4 v0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)goff[0], s0, 0));
@@ -318,6 +326,8 @@ winobf2_conv_kernel(const Wbf2Params p) {
                 r1[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)goff[k], s0 + L4, 0));
             }
         }
+    };
+    auto pair0_write = [&](int q) __attribute__((always_inline)) {
         w2_f32x2 *const dst = xs + q * 4 * XTS;
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
@@ -328,7 +338,8 @@ winobf2_conv_kernel(const Wbf2Params p) {
         }
     };
     if (!loader) {            // compute wave w: channel pair w of chunk 0, then on to its own prologue
-        stage_pair0(wave);
+        pair0_load(wave);
+        pair0_write(wave);
         return;
     }
     // halo windows: item = lane + 64 r -> (window 64 + e, point hp, unit hu = channel pairs 2 hu, 2 hu + 1)
@@ -381,24 +392,38 @@ winobf2_conv_kernel(const Wbf2Params p) {
             for (int sp = 0; sp < 3; ++sp) *reinterpret_cast<w2_u32x2 *>(o + sp * 2 * GM::B_PLANE) = w2_u32x2{w[sp][0], w[sp][1]};
         }
     };
+    // (Pulling the block's residual tile into L2 from here during the last two phases -- LDS-DMA into a sink, no registers -- cut the
+    // epilogue's request time from 5 100 to 3 200 cycles and cost as much in those phases, the requests queueing in front of the
+    // compute waves' tap loads: 414 -> 420 us on one box, A/B.)
     const int last = n_chunks - 1;
-    load(1 < last ? 1 : last);                        // (in flight while this wave stages its pair of chunk 0)
-    stage_pair0(CP - 1);
+    constexpr std::integral_constant<int, 0> S0{};
+    constexpr std::integral_constant<int, NSET - 1> S1{};   // chunk k waits in set k & 1 (one set: always 0)
+    pair0_load(CP - 1);
+    load(1 < last ? 1 : last, S1);                    // (in flight while this wave stages its pair of chunk 0)
+    if constexpr (NSET == 2) load(2 < last ? 2 : last, S0);
+    pair0_write(CP - 1);
     lds_barrier();                                    // (P1) chunk 0's rows are in LDS
     stamp();
     halo(0);
-    write(1);
-    load(2 < last ? 2 : last);
+    write(1, S1);
+    if constexpr (NSET == 1) load(2 < last ? 2 : last, S0);
     lds_barrier();                                    // (P2) chunk 1's rows; chunk 0 is transformed
     stamp();
-    for (int c = 0; c < n_chunks; ++c) {
+    // phase c: chunk c + 2 (requested a phase ago) goes to LDS buffer c & 1 -- chunk c was transformed before the last barrier --
+    // and chunk c + 3 is requested: into the registers chunk c + 2 left, or (two sets) up front into the other set
+    auto phase_l = [&](int c, auto SET_W, auto SET_L) __attribute__((always_inline)) {
         if (!(DBG & 8)) {
-            if (c + 2 < n_chunks) write(c + 2);       // into buffer c & 1: chunk c was transformed before the last barrier
-            if (c + 3 <= last) load(c + 3);
+            if (NSET == 2 && c + 3 <= last) load(c + 3, SET_L);
+            if (c + 2 < n_chunks) write(c + 2, SET_W);
+            if (NSET == 1 && c + 3 <= last) load(c + 3, SET_L);
             if (c + 1 < n_chunks) halo(c + 1);        // chunk c + 1's halo windows, next to the compute waves' own 64
         }
         stamp();   // the loader: staged, now waiting
         lds_barrier();
+    };
+    for (int c = 0; c < n_chunks; c += 2) {
+        phase_l(c, S0, S1);
+        if (c + 1 < n_chunks) phase_l(c + 1, S1, S0);
     }
     };
     auto run_staging = [&]() __attribute__((always_inline)) {
@@ -548,6 +573,9 @@ winobf2_conv_kernel(const Wbf2Params p) {
                 // the window fragments the NEXT group needs: a new tap group's (g + 1, or group 0 of the next chunk) when pr is the last pair
                 const bool b_turn = pr == NPAIR - 1;
                 const int gb = (g + 1) % G, cb_c = g + 1 < G ? c : c + 1;
+                // (A priority that FALLS as a wave advances through its phase -- so that of a SIMD's two compute waves the one behind
+                // goes first, instead of the older one finishing early and leaving the younger alone with the pipe -- measured 3-5 %
+                // SLOWER, 388 -> 403 us at C = 128 K = 11.)
 #pragma unroll
                 for (int i = 0; i < NPROD; ++i) {
                     const int ia = ia6[i], ib = ib6[i];
@@ -608,6 +636,18 @@ winobf2_conv_kernel(const Wbf2Params p) {
         return;
     }
     if constexpr (DBG & 128) { n_stamp = 20; stamp(); }   // epilogue stamps from slot 20 on
+    // the bias of this thread's channel quads, both passes: requested BEFORE the residual (a wave's loads return in order; fetched
+    // inside the pass it sat behind the sixteen residual loads and the first pass waited for all of them)
+    f32x4 bq_all[NPAIR][2];
+#pragma unroll
+    for (int pr = 0; pr < NPAIR; ++pr)
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int grp = tid + gi * W2_NTH;
+            const int ln = grp & 63, rq = (grp >> 6) & 3, tile = grp >> 8;
+            const int row0 = (tile >> 1) * 32 + 8 * rq + 4 * (ln >> 5);
+            bq_all[pr][gi] = bias ? *reinterpret_cast<const f32x4 *>(bias + m0 + pr * 64 + row0) : f32x4{0.f, 0.f, 0.f, 0.f};   // row0 is a multiple of 4
+        }
     prefetch_residual();
     // Each pass leaves its results in registers; residual, running sum and the stores come after the LAST pass, so the residual's
     // HBM latency runs under both passes' LDS traffic (with add + store inside the pass the first pass waited ~8 000 cycles for it).
@@ -642,8 +682,7 @@ winobf2_conv_kernel(const Wbf2Params p) {
             const int row0 = rb * 32 + 8 * rq + 4 * (ln >> 5);           // + comp: channel inside the pair's 64
             g_row[gi] = row0;
             g_col[gi] = cb * 32 + (ln & 31);
-            f32x4 bq = {0.f, 0.f, 0.f, 0.f};
-            if (bias) bq = *reinterpret_cast<const f32x4 *>(bias + m0 + pr * 64 + row0);   // row0 is a multiple of 4
+            const f32x4 bq = bq_all[pr][gi];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float bv = bq[e];

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""A/B on ONE box (boxes differ by several per cent): child processes alternate between two settings, each timing the winobf2 conv
+at C = 128, 383 760 columns, K / D from the environment (default 11 / 1), with residual.
+  AB=<n>        the ablation library with RVC_W2_DBG=0 against RVC_W2_DBG=<n> (default 64)
+  AB_LIB=<.so>  the product library against another build of it (e.g. the previous commit's)"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "codename-rvc-fork-3_amd")]
+    import torch
+    from rvc_amd import _native
+    dev = "cuda:0"
+    C, L, K, D = 128, 383760, int(os.environ.get("K", 11)), int(os.environ.get("D", 1))
+    x = torch.randn(1, C, L, device=dev); r = torch.randn(1, C, L, device=dev); b = torch.zeros(C, device=dev); y = torch.empty_like(x)
+    u = _native.conv1d_winobf_pack_weight(torch.randn(C, C, K) * 0.03, dev)
+    f = lambda: _native.conv1d_winobf_forward(x, u, b, C, K, D, 0.1, res=r, out=y)
+    for _ in range(5): f()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    out = []
+    for _ in range(7):
+        e0.record()
+        for _ in range(12): f()
+        e1.record(); torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) / 12 * 1e3)
+    print(f"{sorted(out)[3]:.1f}")
+    sys.exit(0)
+libdir = os.path.join(ROOT, "codename-rvc-fork-3_amd", "rvc_amd", "_lib")
+if os.environ.get("AB_LIB"):
+    names = ("product", os.environ["AB_LIB"])
+    envs = (dict(os.environ), dict(os.environ, RVC_AMD_LIB=os.path.join(libdir, os.environ["AB_LIB"])))
+else:
+    ab = os.environ.get("AB", "64")
+    env = dict(os.environ, RVC_AMD_LIB=os.path.join(libdir, "librvc_amd_ablate.so"))
+    names = ("RVC_W2_DBG=0", "RVC_W2_DBG=" + ab)
+    envs = (dict(env, RVC_W2_DBG="0"), dict(env, RVC_W2_DBG=ab))
+for k in os.environ.get("KS", os.environ.get("K", "11")).split(","):
+    res = ([], [])
+    for rep in range(4):
+        for i in (0, 1):
+            o = subprocess.run([sys.executable, __file__, "child"], env=dict(envs[i], K=k), capture_output=True, text=True)
+            res[i].append(float(o.stdout.strip().splitlines()[-1]))
+    print(f"K={k} d={os.environ.get('D', 1)}: {names[0]} {res[0]} us | {names[1]} {res[1]} us", flush=True)
