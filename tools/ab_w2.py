@@ -2,7 +2,8 @@
 """A/B on ONE box (boxes differ by several per cent): child processes alternate between two settings, each timing the winobf2 conv
 at C = 128, 383 760 columns, K / D from the environment (default 11 / 1), with residual.
   AB=<n>        the ablation library with RVC_W2_DBG=0 against RVC_W2_DBG=<n> (default 64)
-  AB_LIB=<.so>  the product library against another build of it (e.g. the previous commit's)"""
+  AB_LIB=<.so>  the product library against another build of it (e.g. the previous commit's)
+  AB_ENV=A=B    the ablation library without and with that environment setting (e.g. RVC_WBF_V3=1)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
@@ -28,6 +29,11 @@ libdir = os.path.join(ROOT, "codename-rvc-fork-3_amd", "rvc_amd", "_lib")
 if os.environ.get("AB_LIB"):
     names = ("product", os.environ["AB_LIB"])
     envs = (dict(os.environ), dict(os.environ, RVC_AMD_LIB=os.path.join(libdir, os.environ["AB_LIB"])))
+elif os.environ.get("AB_ENV"):
+    k_, v_ = os.environ["AB_ENV"].split("=", 1)
+    env = dict(os.environ, RVC_AMD_LIB=os.path.join(libdir, "librvc_amd_ablate.so"))
+    names = ("default", os.environ["AB_ENV"])
+    envs = (env, dict(env, **dict(kv.split("=", 1) for kv in os.environ["AB_ENV"].split(","))))
 else:
     ab = os.environ.get("AB", "64")
     env = dict(os.environ, RVC_AMD_LIB=os.path.join(libdir, "librvc_amd_ablate.so"))
