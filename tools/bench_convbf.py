@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the 7- / 11-tap ResBlock conv shapes of the 48 kHz vocoder at the cfg-2 lengths in three forms: direct fp32 MFMA
+"""Time the 3- (C >= 128) / 7- / 11-tap ResBlock conv shapes of the 48 kHz vocoder at the cfg-2 lengths in three forms: direct fp32 MFMA
 (conv.hip), fp32 Winograd (wino.hip), bf16x3 Winograd (winobf.hip).  HIP events, median of 5 batches of 12 launches."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +12,8 @@ for C, L in ((256, 38376), (128, 383760), (64, 767520)):
     if only and C != only: continue
     x = torch.randn(1, C, L, device=dev); res = torch.randn(1, C, L, device=dev); bias = torch.zeros(C, device=dev)
     y = torch.empty_like(x)
-    for K in tuple(int(k) for k in os.environ.get("BENCH_K", "7,11").split(",")):
+    for K in tuple(int(k) for k in os.environ.get("BENCH_K", "3,7,11").split(",")):
+        if K == 3 and C % 128: continue          # the 3-tap bf16x3 form exists for 128-row blocks only
         wt = torch.randn(C, C, K) * 0.03
         w = _native.conv1d_pack_weight(wt, dev); u = _native.conv1d_wino_pack_weight(wt, dev); ub = _native.conv1d_winobf_pack_weight(wt, dev)
         for dil in (1, 3, 5):
