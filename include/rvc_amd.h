@@ -336,11 +336,12 @@ int rvc_conv1d_wino_forward(const float *x_dev, const float *u_dev, const float 
                             int dilation, float slope_in, float out_scale, void *stream);
 
 /* ---- ... and on the bf16 matrix cores with fp32-exact operands (what the decoder uses for its 7- / 11-tap layers at
- * >= 64 channels) ------------------------------------------------------------------------------------------------------- *
+ * >= 64 channels and its 3-tap layers at c_out % 128 == 0) ------------------------------------------------------------------------------------------------------- *
  * The same F(4,4) form with every fp32 operand split exactly into three bf16 numbers (8 + 8 + 8 significand bits) and the six
  * products of order <= 2^-16 formed by v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the dropped terms are below 2^-23
  * of a product.  One layer agrees with float64 as closely as the fp32 Winograd form does.
- * K in {7, 11}, dilation 1..5, C_in a multiple of 16, C_out a multiple of 64, leaky slope in [0, 1], C_in * L < 2^29.
+ * K in {7, 11}, dilation 1..5, C_in a multiple of 16, C_out a multiple of 64, leaky slope in [0, 1], C_in * L < 2^29;
+ * K = 3 (F(4,3): six points, one tap group) with C_out a multiple of 128.
  * u_dev: rvc_conv1d_winobf_weight_bytes() bytes -- the tap transform, evaluated in float64 on the host, rounded to fp32, split
  * into three bf16 and laid out as matrix-instruction fragments by rvc_conv1d_winobf_pack_weight, in the order the kernel that will
  * read them consumes them: C_out % 128 == 0 runs csrc/winobf2.hip (one transform point per wave, 128-channel x 64-column blocks),
