@@ -325,10 +325,10 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": ("f32 activations x bf16-stored vocoder taps (7/11-tap convs: bf16x3 Winograd fragments of the bf16-valued taps on the bf16 "
+        "dtype": ("f32 activations x bf16-stored vocoder taps (7/11-tap convs, 3-tap ones at >= 128 channels: bf16x3 Winograd fragments of the bf16-valued taps on the bf16 "
                   "matrix cores, fp32 accumulate; 3-tap and 32-channel layers: fp32 matrix instruction on taps widened from bf16)")
                  if cfg["weights"] == "bf16" else
-                 "f32 (vocoder 7/11-tap convs: fp32 operands as exact bf16x3 splits on the bf16 matrix cores, fp32 accumulate)",
+                 "f32 (vocoder 7/11-tap convs and 3-tap ones at >= 128 channels: fp32 operands as exact bf16x3 splits on the bf16 matrix cores, fp32 accumulate)",
         "data": "synthetic (seeded random-init weights, FM-tone utterances, clustered index)",
         "rtf": round(value / sr, 2),
         "headline_is": "inputs resident in HBM, waveform left in HBM (the bench contract's definition of `value`); `host_io` is the "
