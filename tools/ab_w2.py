@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B on ONE box (boxes differ by several per cent): child processes alternate between two settings, each timing the winobf2 conv
-at C = 128, 383 760 columns, K / D from the environment (default 11 / 1), with residual.
+at C / L / K / D from the environment (default 128 / 383 760 / 11 / 1), with residual.
   AB=<n>        the ablation library with RVC_W2_DBG=0 against RVC_W2_DBG=<n> (default 64)
   AB_LIB=<.so>  the product library against another build of it (e.g. the previous commit's)
   AB_ENV=A=B    the ablation library without and with that environment setting (e.g. RVC_WBF_V3=1)"""
@@ -11,7 +11,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch
     from rvc_amd import _native
     dev = "cuda:0"
-    C, L, K, D = 128, 383760, int(os.environ.get("K", 11)), int(os.environ.get("D", 1))
+    C, L, K, D = int(os.environ.get("C", 128)), int(os.environ.get("L", 383760)), int(os.environ.get("K", 11)), int(os.environ.get("D", 1))
     x = torch.randn(1, C, L, device=dev); r = torch.randn(1, C, L, device=dev); b = torch.zeros(C, device=dev); y = torch.empty_like(x)
     u = _native.conv1d_winobf_pack_weight(torch.randn(C, C, K) * 0.03, dev)
     f = lambda: _native.conv1d_winobf_forward(x, u, b, C, K, D, 0.1, res=r, out=y)
@@ -45,4 +45,4 @@ for k in os.environ.get("KS", os.environ.get("K", "11")).split(","):
         for i in (0, 1):
             o = subprocess.run([sys.executable, __file__, "child"], env=dict(envs[i], K=k), capture_output=True, text=True)
             res[i].append(float(o.stdout.strip().splitlines()[-1]))
-    print(f"K={k} d={os.environ.get('D', 1)}: {names[0]} {res[0]} us | {names[1]} {res[1]} us", flush=True)
+    print(f"C={os.environ.get('C', 128)} K={k} d={os.environ.get('D', 1)}: {names[0]} {res[0]} us | {names[1]} {res[1]} us", flush=True)
