@@ -507,11 +507,12 @@ def test_decoder_full_synth_golden(native, dev, ref_inputs):
     assert rms(out - g["o"]) <= 5e-5, rms(out - g["o"])
 
 
-@pytest.mark.parametrize("co", ["gemmbf", "winobf2", "knn_screen"])
+@pytest.mark.parametrize("co", ["gemmbf", "winobf2", "knn_screen", "attention_bf"])
 @pytest.mark.parametrize("k,c", [(11, 128), (3, 64), (7, 32)])
 def test_fp32_winograd_next_to_the_bf16_gemm_is_bit_exact(native, dev, k, c, co):
     """Regression test of profiles/r03_mfma_cohabitation.txt / r04_mfma_cohabitation.txt: while one thread launches a kernel that
-    issues bf16 / fp16 matrix instructions in a loop on its own stream -- gemmbf.hip, winobf2.hip, the kNN screening pass -- the
+    issues bf16 / fp16 matrix instructions in a loop on its own stream -- gemmbf.hip, winobf2.hip, the kNN screening pass, HuBERT's
+    bf16x3 attention -- the
     fp32 Winograd kernel on another stream must return bit-identical results every time.  It does because every such kernel asks
     for a CU's whole LDS (common.h: LDS_WHOLE_CU) and so never shares one; next to gemmbf's first form (two 60 KiB blocks per CU)
     300 of 300 runs of this loop came back wrong by up to 2.2."""
@@ -523,6 +524,8 @@ def test_fp32_winograd_next_to_the_bf16_gemm_is_bit_exact(native, dev, k, c, co)
         ub = native.conv1d_winobf_pack_weight(torch.randn(128, 128, 11, generator=g) * 0.03, dev)
         xb = torch.randn(1, 128, 100000, generator=g).to(dev)
         bb = torch.zeros(128, device=dev)
+    if co == "attention_bf":
+        qkv = (torch.randn(1, 1599, 3 * 12 * 64, generator=g) * 1.5).to(dev)
     if co == "knn_screen":
         index = torch.randn(50000, 768, generator=g).to(dev)
         norms = native.knn_index_norms(index)
@@ -544,6 +547,8 @@ def test_fp32_winograd_next_to_the_bf16_gemm_is_bit_exact(native, dev, k, c, co)
                     native.conv1d_bf16x3(xg, a, None, 512, 3, stride=2, act="gelu")
                 elif co == "winobf2":
                     native.conv1d_winobf_forward(xb, ub, bb, 128, 11, 1, 0.1)
+                elif co == "attention_bf":
+                    native.attention_qkv(qkv, 12, 0.125)
                 else:
                     native.knn_search(index, norms, q)
                 st.synchronize()
@@ -692,10 +697,13 @@ def test_bigru_timeout_is_recomputed_not_poisoned(native, dev):
 
 # ---- K7 attention ------------------------------------------------------------------------------------
 @pytest.mark.parametrize("batch,frames,heads,hd", [(1, 1, 12, 64), (1, 31, 2, 64), (2, 97, 12, 64), (1, 1599, 12, 64),
-                                                   (1, 64, 3, 64), (1, 200, 2, 96), (2, 333, 2, 96)])
+                                                   (1, 64, 3, 64), (1, 200, 2, 96), (2, 333, 2, 96),
+                                                   (1, 256, 1, 64), (1, 257, 5, 64), (3, 500, 4, 64), (1, 4799, 12, 64)])
 def test_attention_matches_float64_softmax(native, dev, batch, frames, heads, hd):
     """softmax(q k^T / sqrt(d)) v against a float64 evaluation of the same formula (what transformers' HubertAttention
-    computes, modeling_hubert.py eager path), on the fused-projection layout [B, T, 3, H, d]; key splits included."""
+    computes, modeling_hubert.py eager path), on the fused-projection layout [B, T, 3, H, d]; key splits included.  Head dim 64
+    runs K7b (attention_bf_kernel: bf16x3 products, 8-wave workgroups of 256 queries -- whole / partial / single workgroups per
+    head, 1-8 key splits, a 45 s utterance's 4799 frames), head dim 96 K7."""
     torch.manual_seed(frames)
     qkv = torch.randn(batch, frames, 3 * heads * hd) * 1.5
     got = native.attention_qkv(qkv.to(dev), heads, hd ** -0.5).cpu()
