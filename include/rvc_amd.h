@@ -170,7 +170,10 @@ int rvc_bigru_forward(const float *gi_dev, const float *whhT_dev, const float *b
  * emb_rel_k_dev / emb_rel_v_dev: [21][head_dim] relative-position embeddings shared by the heads (both or neither):
  *   score[i][j] += scale * q_i . emb_rel_k[j - i + 10],  out_i += sum_r p[i][i + r - 10] emb_rel_v[r],  |j - i| <= 10.
  * fp32 throughout (matrix cores in exact-fp32 mode); exp is evaluated as 2^(x log2 e) on the hardware exp unit.
- * workspace_dev: rvc_attention_workspace_bytes() bytes (partial results when the keys are split across waves). */
+ * head_dim 64 without relative terms (HuBERT) runs both GEMMs on the bf16 matrix cores instead, every fp32 operand split exactly into
+ * three bf16 (six products, fp32 accumulate: fp32-level results, max abs error vs float64 ~4e-6 at 1599 frames); its 8-wave workgroups
+ * request the CU's whole LDS like every kernel of this library that issues bf16 matrix instructions.
+ * workspace_dev: rvc_attention_workspace_bytes() bytes (partial results when the keys are split; the K / V fragment slab of the bf16 form). */
 int rvc_attention_workspace_bytes(int batch, int64_t n_frames, int n_heads, int head_dim, size_t *bytes);
 int rvc_attention_qkv_f32(const float *qkv_dev, const float *emb_rel_k_dev, const float *emb_rel_v_dev, float *out_dev,
                           int batch, int64_t n_frames, int n_heads, int head_dim, float scale, void *workspace_dev,
