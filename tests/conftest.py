@@ -36,3 +36,70 @@ def ref_inputs():
     """The reference's own realistic Synthesizer inputs (logs/reference/ref_*.npy, train.py:839-842)."""
     return (np.load(os.path.join(GOLDEN, "ref_feats.npy")), np.load(os.path.join(GOLDEN, "ref_f0c.npy")),
             np.load(os.path.join(GOLDEN, "ref_f0f.npy")))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The full-length oracle legs run in a host process pool (tests/_oracle_farm.py) that starts with the session and works
+# underneath the kernel / pipeline tests; tests/test_fullsize_gpu.py runs last and reads the results.
+# ------------------------------------------------------------------------------------------------------------------
+
+_FARM = None
+
+
+def _farm_keys(items):
+    """The farm jobs the selected test_fullsize_gpu.py items will ask for."""
+    keys = set()
+    for it in items:
+        if "test_fullsize_gpu" not in it.nodeid:
+            continue
+        name = it.name
+        case = name[name.index("[") + 1:-1] if "[" in name else ""
+        if name.startswith("test_full_length_plain_peaked_rmvpe"):
+            keys.add("peaked:" + case)
+        elif name.startswith("test_baseline_config_full_length_vs_oracle"):
+            keys.add("flat:cfg" + case)
+        elif name.startswith("test_45s_two_segments_vs_oracle"):
+            keys.add("flat:45s")
+        elif name.startswith("test_decoder_T3198_stage_by_stage_vs_oracle"):
+            keys.add("decoder:" + case.replace("-hint1", "").replace("-hint2", ""))
+    return keys
+
+
+def pytest_collection_modifyitems(config, items):
+    late = [it for it in items if "test_fullsize_gpu" in it.nodeid]
+    if late:
+        items[:] = [it for it in items if "test_fullsize_gpu" not in it.nodeid] + late
+
+
+def pytest_collection_finish(session):
+    global _FARM
+    keys = _farm_keys(session.items)
+    if not keys or session.config.option.collectonly:
+        return
+    import torch
+    if not torch.cuda.is_available():
+        return
+    from _oracle_farm import Farm, draw_index_on_device
+    _FARM = Farm()
+    index_file = None
+    if "peaked:cfg5" in keys:        # cfg 5's 2 M rows are drawn on the device as bench.py draws them; the worker maps the host copy
+        index_file = os.path.join(_FARM.dir, "cfg5_index.npy")
+        np.save(index_file, draw_index_on_device(2_000_000, "cuda:0").cpu().numpy())
+        torch.cuda.empty_cache()
+    _FARM.cfg5_index_file = index_file
+    _FARM.submit_all(index_file, which=keys)
+    print(f"\n[oracle farm] {len(_FARM.futures)} oracle jobs on {_FARM.workers} workers x {_FARM.threads} threads, results in {_FARM.dir}")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    global _FARM
+    if _FARM is not None:
+        _FARM.close()
+        _FARM = None
+
+
+@pytest.fixture(scope="session")
+def oracle_farm():
+    if _FARM is None:
+        pytest.skip("oracle farm not started (no GPU)")
+    return _FARM

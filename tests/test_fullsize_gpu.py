@@ -1,7 +1,9 @@
 """Full-length parity on the MI355X: the shapes bench.py times (BASELINE cfg 1 / cfg 2), the multi-segment path, the
 vocoder at T = 3198 stage by stage, and the a18 caller -- each against the oracle run on the box's host cores under the
 same seed (or against a reference-generated fixture).  Gate: 1e-3 waveform RMS (north_star); integers bit-exact.
-The oracle runs take tens of seconds each; they are the price of not extrapolating parity from 3 s clips."""
+The oracle runs take tens of seconds each; they are the price of not extrapolating parity from 3 s clips.  Since round 5
+they run ONCE per (kind, case) in a host process pool that starts with the session (tests/_oracle_farm.py, conftest.py) and
+works underneath the kernel tests; this file runs last and reads the results."""
 import os
 import time
 
@@ -71,36 +73,36 @@ def _f0_tie_report(f0_p, sal_p, f0_o, sal_o):
     return differ
 
 
-def _run_pair(S, sds, vc, hubert, cpt, audio, big, rate, seed, **okw):
-    """Product and oracle on one input under one seed.  If their f0 contours differ (only on certified near-tie frames),
-    the oracle is re-run on the product's contour so that the waveform comparison tests everything downstream of that
-    decision at full length; the number of such frames is reported and bounded by the caller."""
+def _run_pair(farm, key, vc, hubert, audio, rate, seed):
+    """Product and oracle on one input under one seed; the oracle side is farm job `key` (tests/_oracle_farm.py: FLAT).  If
+    their f0 contours differ (only on certified near-tie frames), the oracle is re-run on the product's contour so that the
+    waveform comparison tests everything downstream of that decision at full length; the number of such frames is reported
+    and bounded by the caller."""
     from oracle import rvc_oracle as O
-    taps = {}
-    t0 = time.time()
-    torch.manual_seed(seed)
-    want = O.pipeline(sds[0], sds[1], cpt, audio.copy(), sid=0, pitch=0, big_npy=big, index_rate=rate, protect=0.5, taps=taps, **okw)
-    t_oracle = time.time() - t0
+    from _oracle_farm import FLAT
+    res = farm.get(key)
+    want, f0_o, sal_o = res["want"], res["f0_raw"], res["salience"]
+    t_oracle = float(res["t_oracle"])
     vc.vc.debug_taps = {}
     got = vc.vc.pipeline(hubert, vc.net_g, 0, audio.copy(), 0, "rmvpe", "", rate, True, 3, 1, "v2", 0.5, 128, False, 1, None,
                          noise_seed=seed)
     f0_p = vc.vc.debug_taps["f0_raw"].cpu().numpy()
     sal_p = vc.vc.debug_taps["salience"].cpu().numpy()
     vc.vc.debug_taps = None
-    differ = _f0_tie_report(f0_p, sal_p, taps["f0_raw"], taps["salience"])
+    differ = _f0_tie_report(f0_p, sal_p, f0_o, sal_o)
     plain_err = rms(got - want) if got.shape == want.shape else float("nan")
     # The coarse pitch (integer 1..255, the pitch-embedding index; pipeline.py:401-408) rounds a mel-scaled f0: contours equal
     # to fp noise can still land on either side of a .5 boundary.  One such frame changes the embedding of 10 ms of a 45 s
     # clip -- 1.3e-3 whole-clip RMS when it happens (seen on about one run in three of the 45 s case; the GPU contour itself
     # moves by ~1e-7 relative from run to run).  Each flip must be a certified rounding near-tie; the oracle then follows
     # the product's contour like for the arg-max ties.
-    n_f = min(len(f0_p), len(taps["f0_raw"]))
+    n_f = min(len(f0_p), len(f0_o))
     keep = np.ones(n_f, bool)
     keep[differ[differ < n_f]] = False
-    c_p, c_o = O.f0_to_coarse(f0_p[:n_f].astype(np.float64))[0], O.f0_to_coarse(taps["f0_raw"][:n_f].astype(np.float64))[0]
+    c_p, c_o = O.f0_to_coarse(f0_p[:n_f].astype(np.float64))[0], O.f0_to_coarse(f0_o[:n_f].astype(np.float64))[0]
     flips = np.nonzero((c_p != c_o) & keep)[0]
     for t in flips:
-        f = float(taps["f0_raw"][t])
+        f = float(f0_o[t])
         mel = (1127 * np.log(1 + f / 700) - O.F0_MEL_MIN) * 254 / (O.F0_MEL_MAX - O.F0_MEL_MIN) + 1
         assert abs(abs(mel - np.floor(mel)) - 0.5) <= 2e-3 and abs(int(c_p[t]) - int(c_o[t])) == 1, (t, f, mel, c_p[t], c_o[t])
     # Even with NO differing frame the two contours are only equal to fp32 noise (<= F0_NOISE relative, asserted above), and
@@ -110,17 +112,16 @@ def _run_pair(S, sds, vc, hubert, cpt, audio, big, rate, seed, **okw):
     # has been checked on its own just above, this checks everything downstream of it at full length.  The plain error is
     # reported; the UNCONDITIONAL plain gate is test_full_length_plain_peaked_rmvpe below (trained-like salience).
     if len(differ) or len(flips) or plain_err > 3e-4:
-        torch.manual_seed(seed)
-        want = O.pipeline(sds[0], sds[1], cpt, audio.copy(), sid=0, pitch=0, big_npy=big, index_rate=rate, protect=0.5,
-                          f0_override=f0_p, **okw)
-    rel = np.abs(f0_p[:len(taps["f0_raw"])] - taps["f0_raw"]) / np.maximum(taps["f0_raw"], 1.0)
+        farm.submit_pipeline(key + ":follow", False, FLAT[key.split(":")[1]], f0_override=f0_p)
+        want = farm.get(key + ":follow")["want"]
+    rel = np.abs(f0_p[:len(f0_o)] - f0_o) / np.maximum(f0_o, 1.0)
     rel[differ] = 0
     return got, want, dict(tie_frames=len(differ), coarse_flips=len(flips), n_frames=len(f0_p), plain_err=plain_err, t_oracle=t_oracle,
-                           f0_rel_max=float(rel.max()), opt_ts=taps.get("opt_ts"))
+                           f0_rel_max=float(rel.max()), opt_ts=list(res["opt_ts"]))
 
 
 @pytest.mark.parametrize("cfg", [2, 1])
-def test_baseline_config_full_length_vs_oracle(S, hubert, sds, cfg):
+def test_baseline_config_full_length_vs_oracle(S, hubert, oracle_farm, cfg):
     """cfg 2 exactly as bench.py runs it (30 s, 48 k NSF, 100 000-row index, index_rate 0.75) and cfg 1 (10 s, 40 k,
     index_rate 0): whole Pipeline.pipeline vs oracle.pipeline under one seed.  Reference: pipeline.py:509-694.
 
@@ -131,13 +132,12 @@ def test_baseline_config_full_length_vs_oracle(S, hubert, sds, cfg):
     certified as salience near-ties (_f0_tie_report), and the waveform gate is applied with the oracle following the
     product on those frames."""
     secs, sr, rows, rate = (30, 48000, 100_000, 0.75) if cfg == 2 else (10, 40000, 0, 0.0)
-    cpt = S.make_synth_checkpoint(sr, "HiFi-GAN", seed=0)
     vc = _converter(S, sr, "HiFi-GAN", hubert)
     big = S.synth_index(rows, seed=0) if rows else None
     if rows:
         vc.vc.set_index(big)
     audio = S.synth_audio(16000 * secs, seed=0)
-    got, want, info = _run_pair(S, sds, vc, hubert, cpt, audio, big, rate, 1234, knn_dtype=np.float32)
+    got, want, info = _run_pair(oracle_farm, f"flat:cfg{cfg}", vc, hubert, audio, rate, 1234)
     assert got.dtype == np.float32 and got.shape == want.shape == ((1_439_040,) if cfg == 2 else (399_200,))
     err = rms(got - want)
     print(f"cfg {cfg} full length: rms err {err:.3e} (oracle rms {rms(want):.3f}, oracle {info['t_oracle']:.0f} s); "
@@ -149,21 +149,8 @@ def test_baseline_config_full_length_vs_oracle(S, hubert, sds, cfg):
     assert info["coarse_flips"] <= 0.002 * info["n_frames"], info
 
 
-def _synth_index_device(n_rows, seed=0, n_centres=512, jitter=0.05, dim=768):
-    """synthetic.synth_index's recipe (cluster centres + jitter) drawn on the device, as bench.py does for cfg 5: 2 M rows
-    are 6.1 GB, too slow to draw with NumPy inside a test."""
-    g = torch.Generator(device=DEV).manual_seed(seed)
-    centres = torch.randn(n_centres, dim, device=DEV, generator=g) * 0.35
-    out = torch.empty(n_rows, dim, device=DEV)
-    for s in range(0, n_rows, 1 << 18):
-        e = min(n_rows, s + (1 << 18))
-        which = torch.randint(0, n_centres, (e - s,), device=DEV, generator=g)
-        out[s:e] = centres[which] + jitter * torch.randn(e - s, dim, device=DEV, generator=g)
-    return out
-
-
 @pytest.mark.parametrize("case", ["cfg2", "cfg1", "45s", "cfg4", "cfg5"])
-def test_full_length_plain_peaked_rmvpe(S, hubert, case):
+def test_full_length_plain_peaked_rmvpe(S, hubert, oracle_farm, case):
     """The north_star gate with NOTHING conditional: product vs oracle at the benchmarked lengths, each side on its OWN
     f0 contour (no f0_override, no tie certificates on f0), waveform <= 1e-3 RMS, f0 <= 2e-5 relative on EVERY frame.
 
@@ -181,12 +168,9 @@ def test_full_length_plain_peaked_rmvpe(S, hubert, case):
     (oracle: fp32 math on the same bf16-valued weights) over the 100 k index, and RefineGAN over the 2 M-row index (drawn on
     the device as bench.py draws it; the oracle searches a host copy of the same rows)."""
     from oracle import rvc_oracle as O
-    secs, sr, rows, rate, aseed, seed, voc, bf16 = {
-        "cfg2": (30, 48000, 100_000, 0.75, 0, 1234, "HiFi-GAN", False), "cfg1": (10, 40000, 0, 0.0, 0, 1234, "HiFi-GAN", False),
-        "45s": (45, 48000, 0, 0.0, 45, 99, "HiFi-GAN", False), "cfg4": (30, 48000, 100_000, 0.75, 0, 1234, "MRF HiFi-GAN", True),
-        "cfg5": (30, 48000, 2_000_000, 0.75, 0, 1234, "RefineGAN", False)}[case]
+    from _oracle_farm import PEAKED
+    secs, sr, rows, rate, aseed, seed, voc, bf16 = PEAKED[case]
     rm_sd = S.make_rmvpe_state_dict(0, peaked=True)
-    hub_sd = S.make_hubert_state_dict(1)
     cpt = S.make_synth_checkpoint(sr, voc, seed=0, smooth_pitch=True)
     from rvc_amd.infer.infer import VoiceConverter
     vc = VoiceConverter(device=DEV)
@@ -195,21 +179,14 @@ def test_full_length_plain_peaked_rmvpe(S, hubert, case):
     vc.load_checkpoint_dict(cpt)
     vc.hubert_model = hubert
     vc.vc.load_rmvpe_state_dict(rm_sd)
-    big = None
-    if rows > 200_000:
-        index_dev = _synth_index_device(rows)
-        big = index_dev.cpu().numpy()
-        vc.vc.set_index(index_dev)
+    if rows > 200_000:           # the rows conftest drew on the device at session start; the farm worker searches the same file
+        vc.vc.set_index(torch.from_numpy(np.load(oracle_farm.cfg5_index_file)).to(DEV))
     elif rows:
-        big = S.synth_index(rows, seed=0)
-        vc.vc.set_index(big)
+        vc.vc.set_index(S.synth_index(rows, seed=0))
     audio = S.synth_audio(16000 * secs, seed=aseed)
-    taps = {}
-    t0 = time.time()
-    torch.manual_seed(seed)
-    want = O.pipeline(hub_sd, rm_sd, cpt, audio.copy(), sid=0, pitch=0, big_npy=big, index_rate=rate, protect=0.5, taps=taps,
-                      knn_dtype=np.float32, **({"dec_bf16": True} if bf16 else {}))
-    t_oracle = time.time() - t0
+    res = oracle_farm.get("peaked:" + case)
+    want, t_oracle = res["want"], float(res["t_oracle"])
+    taps = {"f0_raw": res["f0_raw"], "salience": res["salience"], "opt_ts": list(res["opt_ts"])}
     vc.vc.debug_taps = {}
     got = vc.vc.pipeline(hubert, vc.net_g, 0, audio.copy(), 0, "rmvpe", "", rate, True, 3, 1, "v2", 0.5, 128, False, 1, None,
                          noise_seed=seed)
@@ -264,13 +241,12 @@ def test_multi_segment_matches_reference_golden(S, hubert):
     assert err <= 1e-3, err
 
 
-def test_45s_two_segments_vs_oracle(S, hubert, sds):
+def test_45s_two_segments_vs_oracle(S, hubert, oracle_farm):
     """> 41 s at the default tier: the host-filtfilt branch, two segments, waveform (not only lengths) vs the oracle
     (tie-aware in f0 like the full-length test above)."""
-    cpt = S.make_synth_checkpoint(48000, "HiFi-GAN", seed=0)
     vc = _converter(S, 48000, "HiFi-GAN", hubert)
     audio = S.synth_audio(16000 * 45, seed=45)
-    got, want, info = _run_pair(S, sds, vc, hubert, cpt, audio, None, 0.0, 99)
+    got, want, info = _run_pair(oracle_farm, "flat:45s", vc, hubert, audio, 0.0, 99)
     assert len(info["opt_ts"]) == 1 and got.shape == want.shape == (int(load_golden("segmentation")["outlen_45"]),)
     err = rms(got - want)
     print(f"45 s, 2 segments: rms err {err:.3e} (oracle rms {rms(want):.3f}); f0 near-tie frames {info['tie_frames']} of "
@@ -281,22 +257,8 @@ def test_45s_two_segments_vs_oracle(S, hubert, sds):
     assert info["coarse_flips"] <= 0.002 * info["n_frames"], info
 
 
-class _SeededNoise:
-    """The oracle's noise interface (rand / randn in draw order) on a seeded CPU generator: the product side replays the
-    same generator tensor by tensor, so RefineGAN's 24 AdaIN draws (3.8 GB at T = 3198) never sit in one Python list."""
-
-    def __init__(self, seed):
-        self.g = torch.Generator().manual_seed(seed)
-
-    def randn(self, *shape):
-        return torch.randn(*shape, generator=self.g)
-
-    def rand(self, *shape):
-        return torch.rand(*shape, generator=self.g)
-
-
 @pytest.mark.parametrize("case", ["nsf-hint1", "nsf-hint2", "mrf", "mrf-bf16", "refine"])
-def test_decoder_T3198_stage_by_stage_vs_oracle(S, case):
+def test_decoder_T3198_stage_by_stage_vs_oracle(S, oracle_farm, case):
     """Every vocoder at the benchmarked shape (T = 3198 -> 1 535 040 samples) with a tap on the source signal and after every
     stage: NSF under both tile selections of the short first stage (rvc_set_concurrency_hint 1: 128x64 tiles, 2: 128x128);
     MRF (BASELINE cfg 4) with fp32 and with bf16 weight storage -- its 9-harmonic source integrates 1.5 M phase increments
@@ -306,7 +268,7 @@ def test_decoder_T3198_stage_by_stage_vs_oracle(S, case):
     from oracle import rvc_oracle as O
     from rvc_amd import _native
     from rvc_amd.lib.algorithm.weights import fold_weight_norm
-    T = 3198
+    from _oracle_farm import DECODER_T as T, SeededNoise, decoder_inputs
     voc = {"nsf": "HiFi-GAN", "mrf": "MRF HiFi-GAN", "refine": "RefineGAN"}[case.split("-")[0]]
     hint = 2 if case.endswith("hint2") else 1
     bf16 = case.endswith("bf16")
@@ -316,27 +278,17 @@ def test_decoder_T3198_stage_by_stage_vs_oracle(S, case):
         w = {k: (v.float().bfloat16().float() if k.startswith("dec.") else v) for k, v in w.items()}
     rates, ksizes = cpt["config"][12], cpt["config"][14]
     upp = int(np.prod(rates))
-    gen = torch.Generator().manual_seed(17)
-    z = torch.randn(1, 192, T, generator=gen)
-    g = torch.randn(1, 256, 1, generator=gen)
-    t = torch.arange(T) / 100.0
-    f0 = (180.0 + 40.0 * torch.sin(2 * np.pi * 0.5 * t)).float().unsqueeze(0)
-    f0[:, 500:600] = 0.0                                   # an unvoiced stretch: noise-only source, phase carry restarts
-    taps = {}
-    t0 = time.time()
+    z, g, f0, gen = decoder_inputs()                       # the farm worker (tests/_oracle_farm.py::_decoder_job) draws the same
     if voc == "HiFi-GAN":
         src_rand = None
         src_randn = torch.randn(1, T * upp, 1, generator=gen)
-        ref = O.decoder_nsf(w, z, f0, g, rates, ksizes, 48000, O.ListNoise([torch.zeros(1, 1, 1), src_randn]), taps=taps).numpy()
         adain_dev = None
     elif voc == "MRF HiFi-GAN":
-        ref = O.decoder_mrf(w, z, f0, g, rates, ksizes, 48000, _SeededNoise(23), taps=taps).numpy()
-        rep = _SeededNoise(23)
+        rep = SeededNoise(23)
         src_rand, src_randn = rep.rand(1, 9), rep.randn(1, T * upp, 9)
         adain_dev = None
     else:
-        ref = O.decoder_refine(w, z, f0, g, rates, 48000, _SeededNoise(23), taps=taps).numpy()
-        rep = _SeededNoise(23)
+        rep = SeededNoise(23)
         src_rand, src_randn = rep.rand(1, 1), rep.randn(1, T * upp, 1)
         shapes, length, ch = [], T, 512
         for r in rates:
@@ -348,7 +300,8 @@ def test_decoder_T3198_stage_by_stage_vs_oracle(S, case):
             n = int(np.prod(sh))
             adain_dev[at:at + n] = rep.randn(*sh).reshape(-1).to(DEV)
             at += n
-    t_oracle = time.time() - t0
+    res = oracle_farm.get("decoder:" + case.replace("-hint1", "").replace("-hint2", ""))
+    ref, t_oracle = res["ref"], float(res["t_oracle"])
     folded = {k[4:]: v for k, v in (w if bf16 else fold_weight_norm(cpt["weight"])).items() if k.startswith("dec.")}
     dec = _native.Decoder(voc, 48000, folded, upsample_rates=rates, upsample_kernel_sizes=ksizes, **({"weight_storage": "bf16"} if bf16 else {}))
     _native.set_concurrency_hint(hint)
@@ -364,10 +317,10 @@ def test_decoder_T3198_stage_by_stage_vs_oracle(S, case):
             out = dec.forward(z.to(DEV), f0.to(DEV), g[:, :, 0].to(DEV), **kw)
             torch.cuda.synchronize()
             dec.set_tap(stage, None)
-            want = taps["har_source"].reshape(1, -1) if stage < 0 else taps[f"stage{stage}"]
-            e = rms(tap.cpu().numpy() - want.numpy())
-            print(f"{case} stage {stage}: rms err {e:.3e} (oracle rms {rms(want.numpy()):.3f})")
-            assert e <= 1e-4 * max(1.0, rms(want.numpy())), (case, stage, e)
+            want = res["har_source"].reshape(1, -1) if stage < 0 else res[f"stage{stage}"]
+            e = rms(tap.cpu().numpy() - want)
+            print(f"{case} stage {stage}: rms err {e:.3e} (oracle rms {rms(want):.3f})")
+            assert e <= 1e-4 * max(1.0, rms(want)), (case, stage, e)
     finally:
         _native.set_concurrency_hint(1)
     err = rms(out.cpu().numpy() - ref)
