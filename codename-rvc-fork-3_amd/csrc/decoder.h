@@ -62,6 +62,7 @@ struct Stage {
     int nc_rows = 0;              // nc_k padded to a multiple of 8
     DevBuf nc_w;                  // [1][nc_rows][c_out]
     std::vector<ConvW> c1, c2;    // [n_res_kernels * n_res_dilations]
+    std::vector<DevBuf16> pair;   // 32- / 64-channel stages: (c1, c2) of each entry as one slab of bf16x3 matrix-instruction fragments (resblock_bf.hip)
 };
 
 // RefineGAN-only state (refine.hip)

@@ -564,6 +564,7 @@ extern "C" int rvc_decoder_finalize(rvc_decoder *d) {
         const int nb_ = c.n_res_kernels * c.n_res_dilations;
         s.c1 = std::vector<ConvW>(nb_);
         s.c2 = std::vector<ConvW>(nb_);
+        s.pair = std::vector<DevBuf16>(nb_);
         for (int m = 0; m < c.n_res_kernels; ++m)
             for (int j = 0; j < c.n_res_dilations; ++j) {
                 std::string p1, p2;
@@ -580,6 +581,20 @@ extern "C" int rvc_decoder_finalize(rvc_decoder *d) {
                 const bool b16 = c.weight_storage == 1 && (k == 3 || k == 7 || k == 11);
                 if (build_conv(d, p1, s.c_out, s.c_out, k, true, &s.c1[m * c.n_res_dilations + j], b16)) return 1;
                 if (build_conv(d, p2, s.c_out, s.c_out, k, true, &s.c2[m * c.n_res_dilations + j], b16)) return 1;
+                if (resblock_bf_enabled() && resblock_bf_supported(s.c_out, k, 1)) {   // the fused pair on the bf16 matrix cores (K3f)
+                    const HostTensor *w1, *w2;
+                    if (need(d, p1 + ".weight", &w1, {s.c_out, s.c_out, k}) || need(d, p2 + ".weight", &w2, {s.c_out, s.c_out, k})) return 1;
+                    std::vector<float> v1(w1->data), v2(w2->data);
+                    if (b16)   // bf16 weight storage: fragments of the bf16-VALUED taps (their second and third splits are zero)
+                        for (std::vector<float> *v : {&v1, &v2})
+                            for (float &f : *v) {
+                                const uint32_t bits = (uint32_t)bf16_rne(f) << 16;
+                                memcpy(&f, &bits, 4);
+                            }
+                    std::vector<uint16_t> frags;
+                    resblock_bf_pack_host(v1.data(), v2.data(), s.c_out, k, &frags);
+                    if (s.pair[m * c.n_res_dilations + j].upload(frags)) return 1;
+                }
             }
     }
     // conv_post: [1][c_last][7]
@@ -772,6 +787,21 @@ extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const flo
         for (int m = 0; m < nk; ++m) {
             const int k = c.res_kernel_sizes[m];
             const float *xin = X;
+            if (s.pair[m * nd].p && resblock_bf_fits(s.c_out, len)) {
+                // 32- / 64-channel stages: one launch per (dilated conv, conv) pair on the bf16 matrix cores (resblock_bf.hip); blocks
+                // read their neighbours' columns, so the outputs ping-pong between Y and T1
+                for (int j = 0; j < nd; ++j) {
+                    const bool last = j + 1 == nd;
+                    float *yout = last ? cur : (j % 2 == 0 ? Y : T1);
+                    const float *acc_in = (last && m > 0) ? cur : nullptr;
+                    const float scale = (last && m + 1 == nk) ? 1.f / (float)nk : 1.f;
+                    if (launch_resblock_bf(xin, s.pair[m * nd + j].p, s.c1[m * nd + j].b.p, s.c2[m * nd + j].b.p, acc_in, yout, batch,
+                                           s.c_out, len, k, c.res_dilations[j], 0.1f, scale, stream))
+                        return 1;
+                    xin = yout;
+                }
+                continue;
+            }
             if (resblock_layer_supported(s.c_out, k) && !s.c1[m * nd].w16.p) {
                 // narrow stages: one fused launch per layer; no in-place update (blocks read neighbours' columns),
                 // so the layer outputs ping-pong between Y and T1

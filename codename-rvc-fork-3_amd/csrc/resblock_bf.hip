@@ -1,0 +1,419 @@
+// K3f -- one ResBlock (dilated conv -> conv) pair of the narrow vocoder stages in ONE launch, on the bf16 matrix cores:
+//     y = out_scale * ( conv2( leaky( conv1_d( leaky(x) ) + b1 ) ) + b2 + x [+ running sum] )        (residuals.py:75-86, one dilation)
+// for C = 32 and C = 64 channels, K = 3 / 7 / 11 taps, every fp32 operand split exactly into three bf16 (8 + 8 + 8 significand
+// bits) and the six products of order <= 2^-16 formed by v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the arithmetic of
+// gemmbf.hip / winobf.hip; dropped terms < 2^-23 of a product).
+//
+// Why this form here.  At 32 / 64 channels the contraction per tap is one or two matrix instructions deep, so the Winograd
+// kernels' per-point transforms (VALU + LDS) cost as much as the products they save, and the two convs of a pair as separate
+// launches move the activation five times (980 MB per pair at C = 32 where a fused pair moves 392 MB).  The DIRECT form needs
+// no transform at all once the operands sit in LDS as bf16 triples in [time][channel] order: the B fragment of ANY tap and
+// dilation is one 16-byte LDS read at (column + tap * d) * row stride.  The intermediate never leaves the CU.
+//
+// Block = 8 waves on one CU that it owns (every bf16 matrix kernel of the library requests the whole LDS, common.h), persistent:
+// it walks tiles of BN output columns.  Per tile:
+//   * waves 4..7 (STAGERS) fetch the NEXT tile's raw rows from HBM into registers while the compute waves run conv1, and -- once
+//     conv1 has released the x tile -- apply the leaky ReLU, split every value into three bf16 and write the x tile
+//     [time][split][channel] under the compute waves' conv2.  Their HBM loads are the only long-latency entries of their memory
+//     queue; the compute waves' queue holds tap fragments (L2), the residual (L2: the stagers fetched those rows a tile ago) and
+//     the stores, so no matrix instruction ever waits behind an HBM round trip (a wave's loads return in order).
+//   * waves 0..3 (COMPUTE) each own a 32-channel row block x 64 columns (two accumulator tiles): per (tap, 16-channel k step) the
+//     three tap fragments come L2 -> registers (ring of four groups), the six window fragments from LDS (double-buffered), twelve
+//     matrix instructions on two independent accumulators.  conv1's result gets bias, leaky ReLU, the conv's zero padding outside
+//     [0, L), the three-way split, and lands in the t tile in the same [time][split][channel] layout; conv2 reads it back.
+//   * two block barriers per tile.
+// LDS rows are 6 C + 16 bytes: an odd multiple of 16 bytes mod 256, so the 16 lanes of a ds_read_b128 group hit 16 different
+// bank quads whatever the tap offset.
+#include <stdlib.h>
+
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include "conv.h"
+
+namespace rvc {
+
+typedef __bf16 rb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 rb_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float rb_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned rb_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned rb_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RBF_NTH = 512;
+constexpr int RBF_RSRC_FLAGS = 0x00020000;
+constexpr unsigned RBF_OOB = 0x80000000u;   // a buffer offset beyond every tensor this kernel takes: loads return 0, stores are dropped
+
+struct RbfParams {
+    const float *x = nullptr;        // [batch][C][L]
+    const void *u = nullptr;         // resblock_bf_pack_host's slab
+    const float *b1 = nullptr, *b2 = nullptr;
+    const float *accin = nullptr;    // [batch][C][L] or null
+    float *y = nullptr;              // [batch][C][L], must not alias x
+    int64_t L = 0;
+    int dil = 1;
+    float slope = 1.f, out_scale = 1.f;
+    int tiles_per_row = 0, n_tiles = 0, per_xcd = 0;
+};
+
+template <int KW, int C>
+struct RbfGeom {
+    static constexpr int KS = C / 16, RB = C / 32, CG = 4 / RB;
+    static constexpr int N1 = CG * 64;                       // conv1 columns per block
+    static constexpr int H2 = (KW - 1) / 2;
+    static constexpr int BN = (N1 - (KW - 1)) / 4 * 4;       // output columns per block
+    static constexpr int ROWB = 6 * C + 16;                  // [split 3][channel C] bf16 + 16 bytes
+    static constexpr int XROWS = N1 + (KW - 1) * 5;          // dilation <= 5
+    static constexpr int TROWS = N1 + (KW - 1);
+    static constexpr int X_BYTES = XROWS * ROWB, T_BYTES = TROWS * ROWB;
+    static constexpr int XRP = (XROWS + 63) / 64 * 64;       // staged rows rounded up: a wave's 64 lanes share a channel quad
+    static constexpr int NIT = (C / 4) * XRP / 256;          // (row, channel quad) items per stager lane
+    static constexpr int NG = KW * KS;                       // (tap, k step) groups per conv
+    static constexpr int GROUP_BYTES = 3 * 1024;             // three splits of one 32 x 16 tap fragment
+    static constexpr int CONV_BYTES = NG * RB * GROUP_BYTES;
+    static constexpr int LDS_BYTES = X_BYTES + T_BYTES;
+    static_assert((C / 4) * XRP % 256 == 0, "");
+    static_assert(LDS_BYTES <= 163840, "LDS budget");
+    static_assert((ROWB / 16) % 2 == 1, "row stride must be an odd multiple of 16 bytes");
+};
+
+// v -> three bf16 whose sum is v exactly (round to nearest even each time; the remainders are exact in fp32)
+__device__ __forceinline__ void rb_split3(rb_f32x2 v, unsigned w[3]) {
+#pragma unroll
+    for (int level = 0; level < 3; ++level) {
+        const unsigned ww = __builtin_bit_cast(unsigned, __builtin_convertvector(v, rb_bf16x2));
+        w[level] = ww;
+        if (level < 2) v = v - rb_f32x2{__uint_as_float(ww << 16), __uint_as_float(ww & 0xffff0000u)};
+    }
+}
+
+template <int KW, int C>
+__global__ void __launch_bounds__(RBF_NTH) __attribute__((amdgpu_waves_per_eu(2, 2)))
+resblock_bf_kernel(const RbfParams p) {
+    using GM = RbfGeom<KW, C>;
+    constexpr int KS = GM::KS, RB = GM::RB, N1 = GM::N1, H2 = GM::H2, BN = GM::BN, ROWB = GM::ROWB, NIT = GM::NIT, XRP = GM::XRP;
+    constexpr int NG = GM::NG, PA = 4;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
+    unsigned char *const xs = rb_smem;
+    unsigned char *const ts = rb_smem + GM::X_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int d = p.dil, h1 = H2 * d, XR = N1 + 2 * h1;
+    const int64_t L = p.L;
+    const unsigned L4 = (unsigned)(L * 4);
+    const int num_bytes = (int)((int64_t)C * L * 4);
+
+    // this block's tiles: XCD x owns the contiguous range [x per_xcd, (x + 1) per_xcd) and its blocks walk it side by side, so the
+    // halo columns two neighbouring tiles share are fetched into the same L2
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int tile_end = (xcd + 1) * p.per_xcd < p.n_tiles ? (xcd + 1) * p.per_xcd : p.n_tiles;
+    int tile = xcd * p.per_xcd + slot;
+    if (tile >= tile_end) return;
+
+    if (wave >= 4) {
+        // ============================================ stagers: HBM -> registers -> bf16 triples in LDS =====================
+        const int ht = tid - 256;
+        float xr[NIT][4];
+        auto x_issue = [&](int tl) __attribute__((always_inline)) {
+            const int bb = tl / p.tiles_per_row;
+            const int64_t xt0 = (int64_t)(tl - bb * p.tiles_per_row) * BN - H2 - h1;       // time of row 0
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + (int64_t)bb * C * L), 0, num_bytes, RBF_RSRC_FLAGS);
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int idx = ht + 256 * i;
+                const int q = idx / XRP, r = idx - q * XRP;
+                const int64_t tg = xt0 + r;
+                const bool ok = r < XR && tg >= 0 && tg < L;
+                const unsigned base = (unsigned)(4 * q) * L4 + (unsigned)tg * 4u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    xr[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(ok ? base + (unsigned)e * L4 : RBF_OOB), 0, 0));
+            }
+        };
+        const float slope = p.slope;
+        auto x_write = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int idx = ht + 256 * i;
+                const int q = idx / XRP, r = idx - q * XRP;
+                if (r >= XR) continue;
+                unsigned w[2][3];
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const rb_f32x2 v = rb_f32x2{xr[i][2 * e2], xr[i][2 * e2 + 1]};
+                    const rb_f32x2 sv = v * slope;
+                    rb_split3(rb_f32x2{__builtin_fmaxf(v.x, sv.x), __builtin_fmaxf(v.y, sv.y)}, w[e2]);
+                }
+                unsigned char *o = xs + r * ROWB + q * 8;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) *reinterpret_cast<rb_u32x2 *>(o + s * 2 * C) = rb_u32x2{w[0][s], w[1][s]};
+            }
+        };
+        // rows N1 .. TROWS-1 of the t tile are read by masked output columns only and never written: give them a value once
+        for (int o = ht * 16; o < (KW - 1) * ROWB; o += 256 * 16) *reinterpret_cast<rb_u32x4 *>(ts + N1 * ROWB + o) = rb_u32x4{0u, 0u, 0u, 0u};
+        x_issue(tile);
+        x_write();
+        for (; tile < tile_end; tile += nslot) {
+            const int next = tile + nslot;
+            lds_barrier();                                    // (A) the x tile is complete
+            if (next < tile_end) x_issue(next);
+            lds_barrier();                                    // (B) conv1 has read the x tile
+            if (next < tile_end) x_write();
+        }
+        return;
+    }
+
+    // ================================================ compute waves ==========================================================
+    const int rb = RB == 1 ? 0 : (wave & 1), cg = RB == 1 ? wave : (wave >> 1);
+    const int col0 = cg * 64;
+    float bias1[16], bias2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ch = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * half;
+        bias1[r] = p.b1 ? p.b1[ch] : 0.f;
+        bias2[r] = p.b2 ? p.b2[ch] : 0.f;
+    }
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, 2 * GM::CONV_BYTES, RBF_RSRC_FLAGS);
+    const float slope = p.slope, out_scale = p.out_scale;
+    const bool has_acc = p.accin != nullptr;
+
+    rb_bf16x8 fa[PA][3];
+    rb_bf16x8 fb[2][2][3];
+    f32x16 acc[2];
+    // group g = tap * KS + ks of conv `cv`: the three splits of this wave's row block
+    auto load_a = [&](int slot_a, int cv, int g) __attribute__((always_inline)) {
+        const int soff = cv * GM::CONV_BYTES + (g * RB + rb) * GM::GROUP_BYTES;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            fa[slot_a][s] = __builtin_bit_cast(rb_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(urs, 16 * lane + s * 1024, soff, 0));
+    };
+    // one window fragment of group g: (column tile cb, split s)
+    auto load_b1 = [&](int buf, const unsigned char *src, int tapstep, int g, int cb, int s) __attribute__((always_inline)) {
+        const int tap = g / KS, ks = g - tap * KS;
+        fb[buf][cb][s] = __builtin_bit_cast(rb_bf16x8, *reinterpret_cast<const rb_u32x4 *>(src + tap * tapstep + ks * 32 + cb * 32 * ROWB + s * 2 * C));
+    };
+    auto load_a1 = [&](int slot_a, int cv, int g, int s) __attribute__((always_inline)) {
+        const int soff = cv * GM::CONV_BYTES + (g * RB + rb) * GM::GROUP_BYTES;
+        fa[slot_a][s] = __builtin_bit_cast(rb_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(urs, 16 * lane + s * 1024, soff, 0));
+    };
+    auto a_prologue = [&](int cv) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < PA - 1; ++g)
+            if (g < NG) load_a(g, cv, g);
+    };
+    constexpr int ia6[6] = {0, 1, 0, 2, 1, 0}, ib6[6] = {2, 1, 1, 0, 0, 0};   // (tap split, window split): smallest products first
+    auto conv_loop = [&](int cv, const unsigned char *src, int tapstep) __attribute__((always_inline)) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) load_b1(0, src, tapstep, 0, k & 1, 2 - (k >> 1));
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            // twelve matrix instructions; behind instruction k, pinned: one of the NEXT group's six window fragments (split 2 first:
+            // the order the products consume them), then the three tap fragments of the group three ahead
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const int k = 2 * i + cb;
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g % PA][ia6[i]], fb[g & 1][cb][ib6[i]], acc[cb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k < 6 && g + 1 < NG) load_b1((g + 1) & 1, src, tapstep, g + 1, k & 1, 2 - (k >> 1));
+                    if (k >= 6 && k < 9 && g + PA - 1 < NG) load_a1((g + PA - 1) % PA, cv, g + PA - 1, k - 6);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+    };
+    const unsigned char *const xsrc = xs + (col0 + l31) * ROWB + half * 16;
+    const unsigned char *const tsrc = ts + (col0 + l31) * ROWB + half * 16;
+    const int xstep = d * ROWB;
+
+    a_prologue(0);
+    for (; tile < tile_end; tile += nslot) {
+        const int bb = tile / p.tiles_per_row;
+        const int64_t t0 = (int64_t)(tile - bb * p.tiles_per_row) * BN;
+        lds_barrier();                                        // (A) the x tile is complete; every wave is done with the t tile
+        conv_loop(0, xsrc, xstep);
+        a_prologue(1);
+        // ---- conv1's epilogue: bias, leaky ReLU, the zero padding conv2 sees outside [0, L), split, into the t tile ----------
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int j = col0 + cb * 32 + l31;
+            const int64_t tg = t0 - H2 + j;
+            const unsigned keep = (tg >= 0 && tg < L) ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int jq = 0; jq < 4; ++jq) {
+                unsigned w[2][3];
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const int r = 4 * jq + 2 * e2;
+                    const rb_f32x2 v = rb_f32x2{acc[cb][r] + bias1[r], acc[cb][r + 1] + bias1[r + 1]};
+                    const rb_f32x2 sv = v * slope;
+                    const rb_f32x2 a = rb_f32x2{__uint_as_float(__float_as_uint(__builtin_fmaxf(v.x, sv.x)) & keep),
+                                                __uint_as_float(__float_as_uint(__builtin_fmaxf(v.y, sv.y)) & keep)};
+                    rb_split3(a, w[e2]);
+                }
+                unsigned char *o = ts + j * ROWB + (32 * rb + 8 * jq + 4 * half) * 2;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) *reinterpret_cast<rb_u32x2 *>(o + s * 2 * C) = rb_u32x2{w[0][s], w[1][s]};
+            }
+        }
+        lds_barrier();                                        // (B) the t tile is complete; the x tile is free
+        // ---- the residual: the raw rows of this tile (L2: the stagers fetched them a tile ago), requested before conv2 ---------
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + (int64_t)bb * C * L), 0, num_bytes, RBF_RSRC_FLAGS);
+        unsigned off[2];
+        float resv[2][16];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int j = col0 + cb * 32 + l31;
+            const bool ok = j < BN && t0 + j < L;
+            off[cb] = ok ? (unsigned)(32 * rb + 4 * half) * L4 + (unsigned)(t0 + j) * 4u : RBF_OOB;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                resv[cb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)(off[cb] + (unsigned)((r & 3) + 8 * (r >> 2)) * L4), 0, 0));
+        }
+        conv_loop(1, tsrc, ROWB);
+        if (tile + nslot < tile_end) a_prologue(0);           // the next tile's first tap fragments, ahead of this tile's stores
+        // ---- conv2's epilogue: bias, residual, running sum, scale, store ----------------------------------------------------------
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.y + (int64_t)bb * C * L), 0, num_bytes, RBF_RSRC_FLAGS);
+        if (has_acc) {
+            const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void *)(p.accin + (int64_t)bb * C * L), 0, num_bytes, RBF_RSRC_FLAGS);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    resv[cb][r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars, (int)(off[cb] + (unsigned)((r & 3) + 8 * (r >> 2)) * L4), 0, 0));
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = (acc[cb][r] + bias2[r] + resv[cb][r]) * out_scale;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, (int)(off[cb] + (unsigned)((r & 3) + 8 * (r >> 2)) * L4), 0, 0);
+            }
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------
+
+bool resblock_bf_enabled() {
+    static const int on = knob("RVC_RBF", 1);
+    return on != 0;
+}
+
+bool resblock_bf_supported(int c, int k, int dil) {
+    return (c == 32 || c == 64) && (k == 3 || k == 7 || k == 11) && dil >= 1 && dil <= 5;
+}
+
+bool resblock_bf_fits(int c, int64_t L) { return (int64_t)c * L * 4 < ((int64_t)1 << 31); }
+
+size_t resblock_bf_weight_bytes(int c, int k) { return (size_t)2 * k * (c / 16) * (c / 32) * 3 * 1024; }
+
+// w1, w2: [c][c][k] (PyTorch Conv1d layout) -> [conv][tap][k step][row block][split][lane][8 bf16]: lane l of a fragment holds
+// output channel 32 rb + (l & 31), input channels 16 ks + 8 (l >> 5) .. + 7
+void resblock_bf_pack_host(const float *w1, const float *w2, int c, int k, std::vector<uint16_t> *out) {
+    const int KS = c / 16, RB = c / 32;
+    out->assign(resblock_bf_weight_bytes(c, k) / 2, 0);
+    for (int cv = 0; cv < 2; ++cv) {
+        const float *w = cv ? w2 : w1;
+        for (int tap = 0; tap < k; ++tap)
+            for (int ks = 0; ks < KS; ++ks)
+                for (int rb = 0; rb < RB; ++rb)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = 32 * rb + (lane & 31), ci = 16 * ks + 8 * (lane >> 5) + e;
+                            float r = w[((size_t)co * c + ci) * k + tap];
+                            const size_t group = (((size_t)cv * k + tap) * KS + ks) * RB + rb;
+                            for (int s = 0; s < 3; ++s) {
+                                const uint16_t h = bf16_rne(r);
+                                const uint32_t bits = (uint32_t)h << 16;
+                                float f;
+                                memcpy(&f, &bits, 4);
+                                r -= f;                      // exact in fp32
+                                (*out)[(group * 3 + s) * 512 + lane * 8 + e] = h;
+                            }
+                        }
+    }
+}
+
+static int rbf_cu_count() {
+    static const int n = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        return cus > 0 ? cus : 256;
+    }();
+    return n;
+}
+
+template <int KW, int C>
+static int rbf_launch(RbfParams p, int batch, hipStream_t stream) {
+    using GM = RbfGeom<KW, C>;
+    static std::once_flag once;
+    static hipError_t err = hipSuccess;
+    std::call_once(once, [] {
+        err = hipFuncSetAttribute((const void *)resblock_bf_kernel<KW, C>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
+    });
+    if (err != hipSuccess) return fail("resblock_bf: cannot reserve %d bytes of LDS: %s", LDS_WHOLE_CU, hipGetErrorString(err));
+    p.tiles_per_row = (int)ceil_div(p.L, GM::BN);
+    p.n_tiles = p.tiles_per_row * batch;
+    p.per_xcd = (int)ceil_div(p.n_tiles, 8);
+    const int cus = rbf_cu_count() / 8 * 8;
+    const int slots = (int)std::min<int64_t>(cus / 8, p.per_xcd);           // blocks per XCD
+    hipLaunchKernelGGL((resblock_bf_kernel<KW, C>), dim3((unsigned)(slots * 8)), dim3(RBF_NTH), LDS_WHOLE_CU, stream, p);   // owns its CU (common.h)
+    RVC_LAUNCH_CHECK();
+    return 0;
+}
+
+// x, y: [batch][c][L] (must NOT alias: blocks read their neighbours' columns); u: resblock_bf_pack_host's slab on the device
+int launch_resblock_bf(const float *x, const void *u, const float *b1, const float *b2, const float *accin, float *y, int batch, int c,
+                       int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream) {
+    if (!resblock_bf_supported(c, k, dil)) return fail("resblock_bf: unsupported shape (%d channels, %d taps, dilation %d)", c, k, dil);
+    if (x == y) return fail("resblock_bf: in-place operation is not supported");
+    if (!(slope >= 0.f && slope <= 1.f)) return fail("resblock_bf: leaky slope %g outside [0, 1]", (double)slope);
+    if (!resblock_bf_fits(c, L)) return fail("resblock_bf: a %d x %lld slab exceeds the 2 GiB buffer addressing", c, (long long)L);
+    if (L <= 0 || batch <= 0) return 0;
+    if ((int64_t)ceil_div(L, 64) * batch >= ((int64_t)1 << 30)) return fail("resblock_bf: too many tiles");
+    RbfParams p;
+    p.x = x; p.u = u; p.b1 = b1; p.b2 = b2; p.accin = accin; p.y = y; p.L = L; p.dil = dil; p.slope = slope; p.out_scale = out_scale;
+#define RVC_RBF_CASE(KW, CC) if (k == KW && c == CC) return rbf_launch<KW, CC>(p, batch, stream)
+    RVC_RBF_CASE(3, 32); RVC_RBF_CASE(7, 32); RVC_RBF_CASE(11, 32);
+    RVC_RBF_CASE(3, 64); RVC_RBF_CASE(7, 64); RVC_RBF_CASE(11, 64);
+#undef RVC_RBF_CASE
+    return fail("resblock_bf: unsupported shape c=%d k=%d", c, k);
+}
+
+}  // namespace rvc
+
+using namespace rvc;
+
+extern "C" int rvc_resblock_bf16x3_weight_bytes(int c, int k, size_t *bytes) {
+    if (!bytes) return fail("rvc_resblock_bf16x3_weight_bytes: null pointer");
+    if (!resblock_bf_supported(c, k, 1)) return fail("rvc_resblock_bf16x3_weight_bytes: c must be 32 or 64, k 3, 7 or 11");
+    *bytes = resblock_bf_weight_bytes(c, k);
+    return 0;
+}
+
+extern "C" int rvc_resblock_bf16x3_pack_weight(const float *w1_host, const float *w2_host, int c, int k, void *u_dev, void *stream) {
+    if (!w1_host || !w2_host || !u_dev) return fail("rvc_resblock_bf16x3_pack_weight: null pointer");
+    size_t bytes = 0;
+    if (rvc_resblock_bf16x3_weight_bytes(c, k, &bytes)) return 1;
+    std::vector<uint16_t> u;
+    resblock_bf_pack_host(w1_host, w2_host, c, k, &u);
+    hipError_t e = hipMemcpyAsync(u_dev, u.data(), bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return fail("rvc_resblock_bf16x3_pack_weight: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int rvc_resblock_bf16x3_forward(const float *x_dev, const void *u_dev, const float *b1_dev, const float *b2_dev,
+                                           const float *acc_dev, float *y_dev, int batch, int c, int64_t length, int k, int dilation,
+                                           float slope, float out_scale, void *stream) {
+    if (!x_dev || !u_dev || !y_dev) return fail("rvc_resblock_bf16x3_forward: null pointer");
+    return launch_resblock_bf(x_dev, u_dev, b1_dev, b2_dev, acc_dev, y_dev, batch, c, length, k, dilation, slope, out_scale,
+                              (hipStream_t)stream);
+}

@@ -104,6 +104,10 @@ SYMBOLS = {
     "rvc_conv1d_winobf_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rvc_conv1d_winobf_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                           c_int64, c_int, c_int, c_float, c_float, c_void_p]),
+    "rvc_resblock_bf16x3_weight_bytes": (c_int, [c_int, c_int, POINTER(c_size_t)]),
+    "rvc_resblock_bf16x3_pack_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "rvc_resblock_bf16x3_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int,
+                                            c_int, c_float, c_float, c_void_p]),
     "rvc_gemm_bf16x3_weight_bytes": (c_int, [c_int, c_int, POINTER(c_size_t)]),
     "rvc_gemm_bf16x3_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rvc_linear_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
@@ -238,7 +242,8 @@ def knn_roofline_report(n_rows: int, n_queries: int, dim: int, seconds: float, p
     """SURVEY §8d's kNN roofline for one rvc_knn_search of (n_queries x n_rows) that took `seconds` (all launches of the
     search: query conversion, sample pass, bound, main pass, exact re-scoring).  §8d prices a pass over the index at
     n_rows * dim * 4 B (the fp32 rows the reference's algorithm reads) times ceil(Q / Qt) passes; the screened regime
-    (Qt = 256) streams an fp16 copy, so the bytes it really moves per pass are half of that -- both are stated."""
+    (Qt = 256) streams an fp16 copy, so the bytes it really moves per pass are half of that: `frac` is the physical figure
+    (bytes the passes read / time / HBM peak), `frac_8d` the formula's."""
     screened = n_queries > 64 and n_rows >= 16384 and dim % 256 == 0
     stream = n_queries <= 64
     q_tile = 256 if screened else (32 if stream else 128)
@@ -251,10 +256,13 @@ def knn_roofline_report(n_rows: int, n_queries: int, dim: int, seconds: float, p
                        ("knn_direct_kernel" if stream else "knn_partial_kernel") + " + knn_finalize_kernel"),
             "regime": "fp16-screened, exact re-scoring" if screened else ("fp32 streaming" if stream else "fp32 GEMM"),
             "shape": f"{n_queries} queries x {n_rows} rows x {dim}", "bound": "hbm", "query_tile": q_tile, "passes": passes,
-            "bytes_per_pass_8d": n_rows * dim * 4, "achieved": round(bytes_8d / seconds / 1e9, 1), "peak": peak_hbm_gbs,
-            "unit": "GB/s", "frac": round(bytes_8d / seconds / 1e9 / peak_hbm_gbs, 4),
-            "bytes_moved_per_search": bytes_moved, "moved_gbs": round(bytes_moved / seconds / 1e9, 1),
-            "moved_frac": round(bytes_moved / seconds / 1e9 / peak_hbm_gbs, 4),
+            "bytes_per_pass_8d": n_rows * dim * 4,
+            # `achieved` / `frac` are PHYSICAL: the bytes this regime's passes read (fp16 copy when screened) over the search
+            # time.  SURVEY 8d's formula figure (fp32 rows x passes, bytes the screened kernel does not read) stays as *_8d.
+            "achieved": round(bytes_moved / seconds / 1e9, 1), "peak": peak_hbm_gbs,
+            "unit": "GB/s", "frac": round(bytes_moved / seconds / 1e9 / peak_hbm_gbs, 4),
+            "bytes_moved_per_search": bytes_moved,
+            "achieved_8d": round(bytes_8d / seconds / 1e9, 1), "frac_8d": round(bytes_8d / seconds / 1e9 / peak_hbm_gbs, 4),
             "traffic": traffic, "traffic_source": traffic_source,   # measured HBM bytes per search (the caller's: profiles/pmc_knn_*.json)
             "mfma_tflops": round(flops / seconds / 1e12, 2),
             "mfma_frac": round(flops / seconds / 1e12 / (peak_f16_tflops if screened else peak_f32_tflops), 4),
@@ -566,6 +574,35 @@ def conv1d_winobf_forward(x, u_packed, bias, c_out, k, dilation=1, slope_in=1.0,
                                           res.data_ptr() if res is not None else None,
                                           acc.data_ptr() if acc is not None else None, y.data_ptr(), b, c_in, c_out, length, k,
                                           dilation, float(slope_in), float(out_scale), _stream()), "rvc_conv1d_winobf_forward")
+    return y
+
+
+# ---- K3f: fused ResBlock pair (dilated conv -> conv + residual) on the bf16 matrix cores -------------------------
+def resblock_bf16x3_pack_weight(w1: torch.Tensor, w2: torch.Tensor, device) -> torch.Tensor:
+    """The two nn.Conv1d weights [c, c, k] of one ResBlock dilation -> fragment slab on the device."""
+    w1 = w1.detach().float().cpu().contiguous()
+    w2 = w2.detach().float().cpu().contiguous()
+    c, c_in, k = w1.shape
+    if c != c_in or w2.shape != w1.shape:
+        raise NativeError(f"resblock pair: square convs of one shape expected, got {tuple(w1.shape)} and {tuple(w2.shape)}")
+    n = c_size_t()
+    _check(_lib.rvc_resblock_bf16x3_weight_bytes(c, k, ctypes.byref(n)), "rvc_resblock_bf16x3_weight_bytes")
+    u = torch.empty(n.value // 2, dtype=torch.int16, device=device)
+    _check(_lib.rvc_resblock_bf16x3_pack_weight(w1.data_ptr(), w2.data_ptr(), c, k, u.data_ptr(), _stream()), "rvc_resblock_bf16x3_pack_weight")
+    return u
+
+
+def resblock_bf16x3_forward(x, u_packed, b1, b2, k, dilation=1, slope=0.1, acc=None, out_scale=1.0, out=None):
+    """y = out_scale * (conv2(leaky(conv1_d(leaky(x)) + b1)) + b2 + x [+ acc]) for x [B, C, L] in HBM (residuals.py:75-86)."""
+    x = _dev_f32(x, "x")
+    b, c, length = x.shape
+    y = out if out is not None else torch.empty_like(x)
+    if y.data_ptr() == x.data_ptr():
+        raise NativeError("resblock pair: x and y must not alias")
+    _check(_lib.rvc_resblock_bf16x3_forward(x.data_ptr(), u_packed.data_ptr(), b1.data_ptr() if b1 is not None else None,
+                                            b2.data_ptr() if b2 is not None else None, acc.data_ptr() if acc is not None else None,
+                                            y.data_ptr(), b, c, length, k, dilation, float(slope), float(out_scale), _stream()),
+           "rvc_resblock_bf16x3_forward")
     return y
 
 

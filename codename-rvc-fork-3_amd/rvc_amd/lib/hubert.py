@@ -4,12 +4,13 @@ Replaces ``HubertModelWithFinalProj`` (rvc/lib/utils.py:31-34, a ``transformers.
 subclass) at its one call site ``model(feats)["last_hidden_state"]`` (rvc/infer/pipeline.py:450)
 and the v1-only ``model.final_proj`` (:451-453).  No ``transformers`` import: the network is
 restated functionally over a state dict in transformers naming, weight-norm of
-the positional conv folded once at load.  GEMMs (12 x attention + FFN, 445 GFLOP per 30 s clip)
-run through hipBLASLt / SDPA on the matrix cores; everything stays fp32 (README.md:22).
+the positional conv folded once at load.  On the device the feature-extractor convs 0-3 run in
+librvc_amd's K11 (gemmbf.hip) and the attention in K7b (attention.hip), both as exact bf16x3 splits
+on the bf16 matrix cores; everything stays fp32-valued (README.md:22).  CPU tensors (host-logic
+tests only) take plain torch ops.
 """
 from __future__ import annotations
 
-import os
 from typing import Dict
 
 import torch
@@ -41,9 +42,9 @@ class HubertModelWithFinalProj:
         # fp32 projections stay on the libraries, which are faster at those sizes.  K11 launches one 8-wave block per CU and asks
         # for the CU's whole LDS: a workgroup issuing bf16 matrix instructions must not share a CU with the vocoder's fp32
         # Winograd kernel (profiles/r03_mfma_cohabitation.txt), and with two utterances in flight HuBERT overlaps the other
-        # utterance's vocoder.  RVC_HUBERT_CONV=0: everything through MIOpen.
+        # utterance's vocoder.
         self._conv_bf = {}
-        if self.device.type == "cuda" and os.environ.get("RVC_HUBERT_CONV", "1") != "0":
+        if self.device.type == "cuda":
             from rvc_amd import _native
             for i in (0, 1, 2, 3):    # layer 0: 1 -> 512 channels, 10 taps, stride 5 (MIOpen: im2col + GEMM, 0.43 ms; here one k16 step)
                 cw = self.w[f"feature_extractor.conv_layers.{i}.conv.weight"]

@@ -7,7 +7,6 @@
 """
 from __future__ import annotations
 
-import os
 from typing import Dict
 
 import numpy as np
@@ -69,7 +68,7 @@ class RMVPE0Predictor:
         self.w = {k: v.to(self.device).contiguous() for k, v in w.items()}
         # K10 (conv2d.hip) taps of every 3x3 / 1x1 block conv whose input channel count the kernel takes (all but the 1 -> 16 one)
         self.wp = {}
-        if self.device.type == "cuda" and os.environ.get("RVC_NATIVE_UNET", "1") != "0":
+        if self.device.type == "cuda":
             from rvc_amd import _native
             for k, v in w.items():
                 if k.endswith((".c1.w", ".c2.w", ".sc.w", "cnn.w")) and v.shape[1] % 8 == 0:

@@ -356,6 +356,23 @@ int rvc_conv1d_winobf_forward(const float *x_dev, const void *u_dev, const float
                               const float *acc_dev, float *y_dev, int batch, int c_in, int c_out, int64_t length, int k,
                               int dilation, float slope_in, float out_scale, void *stream);
 
+/* ---- K3f: one ResBlock (dilated conv -> conv) pair of the 32- / 64-channel stages in ONE launch ------------------------------- *
+ * Replaces, per dilation d of ResBlock.forward (rvc/lib/algorithm/residuals.py:75-86; the MRF layer of
+ * rvc/lib/algorithm/generators/hifigan_mrf.py has the same body):
+ *     xt = leaky_relu(x, slope); xt = conv1_d(xt); xt = leaky_relu(xt, slope); xt = conv2(xt); x = xt + x
+ * plus the generator's running sum over its parallel ResBlocks and the final 1 / n (hifigan_nsf.py:196-205):
+ *     y = out_scale * (conv2(leaky(conv1_d(leaky(x)) + b1)) + b2 + x [+ acc])
+ * Direct form on the bf16 matrix cores, every fp32 operand (taps, activations, the intermediate) split exactly into three
+ * bf16 and the six products of order <= 2^-16 accumulated in fp32 (csrc/resblock_bf.hip); the intermediate stays in LDS.
+ * C in {32, 64}, K in {3, 7, 11}, dilation 1..5 (conv2's is 1), leaky slope in [0, 1], C * L * 4 < 2^31; x and y must not alias.
+ * u_dev: rvc_resblock_bf16x3_weight_bytes() bytes filled by rvc_resblock_bf16x3_pack_weight from the two [C][C][K] host weights.
+ * Persistent: one 8-wave workgroup per CU that requests the CU's whole LDS (the rule for every bf16 matrix kernel here). */
+int rvc_resblock_bf16x3_weight_bytes(int c, int k, size_t *bytes);
+int rvc_resblock_bf16x3_pack_weight(const float *w1_host, const float *w2_host, int c, int k, void *u_dev, void *stream);
+int rvc_resblock_bf16x3_forward(const float *x_dev, const void *u_dev, const float *b1_dev, const float *b2_dev,
+                                const float *acc_dev, float *y_dev, int batch, int c, int64_t length, int k, int dilation,
+                                float slope, float out_scale, void *stream);
+
 /* ---- K11: fp32 GEMM / strided conv1d on the bf16 matrix cores with fp32-exact operands ------------------------------------ *
  * Replaces the fp32 library GEMMs behind `transformers`' HubertModel at rvc/infer/pipeline.py:450: the attention / FFN
  * projections (nn.Linear: y = act(x W^T + b) + res, x [n_rows][in] row-major) and the stride-2 convolutions of the feature

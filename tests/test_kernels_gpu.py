@@ -120,6 +120,51 @@ def test_conv1d_winograd_bf16x3_matches_float64(native, dev, c_in, c_out, k, dil
     assert r_bf <= 1.5 * r_w
 
 
+@pytest.mark.parametrize("c,k,dil,length,batch", [
+    (32, 3, 1, 4096, 1), (32, 3, 3, 4097, 1), (32, 3, 5, 1000, 2), (32, 7, 1, 5003, 1), (32, 7, 3, 749, 2), (32, 7, 5, 16384, 1),
+    (32, 11, 1, 2051, 1), (32, 11, 3, 9999, 1), (32, 11, 5, 513, 2), (32, 11, 5, 31, 1), (32, 3, 1, 5, 1), (32, 7, 5, 244, 1),
+    (64, 3, 1, 4096, 1), (64, 3, 5, 777, 2), (64, 7, 1, 5003, 1), (64, 7, 3, 1234, 1), (64, 11, 1, 2051, 1), (64, 11, 5, 9999, 2),
+    (64, 11, 3, 117, 1), (64, 7, 5, 50, 1),
+    (32, 7, 3, 1535040, 1), (32, 11, 5, 1535040, 1), (64, 7, 1, 767520, 1), (64, 3, 5, 767520, 1),   # the benchmarked stage shapes
+])
+def test_resblock_pair_bf16x3_matches_float64(native, dev, c, k, dil, length, batch):
+    """resblock_bf.hip (K3f): one (dilated conv -> conv) pair of ResBlock.forward (residuals.py:75-86) in one launch, direct form on
+    the bf16 matrix cores with every fp32 operand -- taps, activations and the intermediate -- split exactly into three bf16.
+    Against the same pair in float64 (F.conv1d), with biases, the residual, the running sum and the final scale; every
+    dilation, lengths shorter than one tile / not a multiple of anything, several tiles per block (persistent loop), batch > 1.
+    Gate: 6e-5 at |y| ~ 1 (the single convs' gate); the relative RMS error must stay at the fp32 direct form's level."""
+    g = torch.Generator().manual_seed(c * 1000 + k * 10 + dil)
+    x = torch.randn(batch, c, length, generator=g)
+    w1 = torch.randn(c, c, k, generator=g) / (c * k) ** 0.5
+    w2 = torch.randn(c, c, k, generator=g) / (c * k) ** 0.5
+    b1, b2 = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    acc = torch.randn(batch, c, length, generator=g)
+
+    def pair64(xx, bb1, bb2):
+        t = F.conv1d(F.leaky_relu(xx.double(), 0.1), w1.double(), bb1, padding=(k - 1) // 2 * dil, dilation=dil)
+        return F.conv1d(F.leaky_relu(t, 0.1), w2.double(), bb2, padding=(k - 1) // 2) + xx.double()
+
+    u = native.resblock_bf16x3_pack_weight(w1, w2, dev)
+    xd = x.to(dev)
+    ref = (pair64(x, b1.double(), b2.double()) + acc.double()) / 3
+    got = native.resblock_bf16x3_forward(xd, u, b1.to(dev), b2.to(dev), k, dil, 0.1, acc=acc.to(dev), out_scale=1 / 3).cpu()
+    err = (got.double() - ref).abs().max().item()
+    assert err <= 6e-5, err
+    ref2 = pair64(x, None, None)
+    plain = native.resblock_bf16x3_forward(xd, u, None, None, k, dil, 0.1).cpu()
+    assert (plain.double() - ref2).abs().max().item() <= 6e-5
+    # the same pair as two launches of the fp32 direct-form kernel (conv.hip): the error level this kernel has to hold
+    pw1, pw2 = native.conv1d_pack_weight(w1, dev), native.conv1d_pack_weight(w2, dev)
+    t32 = native.conv1d_forward(xd, pw1, None, c, k, dil, 0.1)
+    d32 = native.conv1d_forward(t32, pw2, None, c, k, 1, 0.1, res=xd).cpu()
+    rel = lambda t: ((t.double() - ref2).pow(2).mean().sqrt() / ref2.pow(2).mean().sqrt()).item()
+    r_bf, r_d = rel(plain), rel(d32)
+    print(f"C {c} k {k} d {dil} L {length} B {batch}: relative RMS error vs float64: fused bf16x3 pair {r_bf:.2e}, two fp32 direct convs {r_d:.2e}")
+    assert r_bf <= 1.5 * r_d + 1e-8
+    again = native.resblock_bf16x3_forward(xd, u, None, None, k, dil, 0.1).cpu()
+    assert torch.equal(again, plain)                      # bit-reproducible
+
+
 @pytest.mark.parametrize("n_rows,k,m,act,with_res", [
     (1599, 768, 2304, "none", False), (1599, 768, 768, "none", True), (1599, 768, 3072, "gelu", False),
     (1599, 3072, 768, "none", True), (149, 768, 768, "gelu", True), (1, 512, 768, "none", False), (130, 16, 128, "none", False),
