@@ -14,20 +14,23 @@
 // it walks tiles of BN output columns.  Per tile:
 //   * waves 4..7 (STAGERS) fetch the NEXT tile's raw rows from HBM into registers while the compute waves run conv1, and -- once
 //     conv1 has released the x tile -- apply the leaky ReLU, split every value into three bf16 and write the x tile
-//     [time][split][channel] under the compute waves' conv2.  Their HBM loads are the only long-latency entries of their memory
-//     queue; the compute waves' queue holds tap fragments (L2), the residual (L2: the stagers fetched those rows a tile ago) and
-//     the stores, so no matrix instruction ever waits behind an HBM round trip (a wave's loads return in order).
+//     [time][split][channel] under the compute waves' conv2, next to the raw values of the block's own columns (the residual) in
+//     the io buffer [channel][column]; behind the next barrier they take the finished outputs out of that same buffer, add the
+//     running sum, scale, and store whole rows 16 bytes per lane.  Every HBM access of the block is theirs; the compute waves'
+//     memory queue holds nothing but tap fragments (L2), so no matrix instruction ever waits behind an HBM round trip or a
+//     store's acknowledgement (a wave's memory operations retire in order).
 //   * waves 0..3 (COMPUTE) each own a 32-channel row block x 64 columns (two accumulator tiles): per (tap, 16-channel k step) the
 //     three tap fragments come L2 -> registers (ring of four groups), the six window fragments from LDS (double-buffered), twelve
 //     matrix instructions on two independent accumulators.  conv1's result gets bias, leaky ReLU, the conv's zero padding outside
 //     [0, L), the three-way split, and lands in the t tile in the same [time][split][channel] layout; conv2 reads it back.
-//   * two block barriers per tile.
+//   * three block barriers per tile (x tile ready / outputs handed over / t tile ready).
 // LDS rows are 6 C + 16 bytes: an odd multiple of 16 bytes mod 256, so the 16 lanes of a ds_read_b128 group hit 16 different
 // bank quads whatever the tap offset.
 #include <stdlib.h>
 
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "conv.h"
@@ -56,6 +59,37 @@ struct RbfParams {
     int tiles_per_row = 0, n_tiles = 0, per_xcd = 0;
 };
 
+// Plain (unpacked) fp32 VALU for code that runs NEXT TO another wave's matrix instructions on the same SIMD: v_pk_add_f32 /
+// v_pk_mul_f32 there waited ~100 cycles each (the stagers' 60 packed operations per tile took 7 800 cycles of a 20 000-cycle tile:
+// profiles/r05_rbf_stamps.txt); inline asm, so that neither the vector types nor the SLP vectoriser can pack them again.
+__device__ __forceinline__ float rb_sub_np(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float rb_add_np(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float rb_mul_np(float a, float b) {
+    float r;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// (a, b) -> three words of two bf16 each whose sums are a and b exactly
+__device__ __forceinline__ void rb_split3_np(float a, float b, unsigned w[3]) {
+#pragma unroll
+    for (int level = 0; level < 3; ++level) {
+        const unsigned ww = __builtin_bit_cast(unsigned, __builtin_convertvector(rb_f32x2{a, b}, rb_bf16x2));
+        w[level] = ww;
+        if (level < 2) {
+            a = rb_sub_np(a, __uint_as_float(ww << 16));
+            b = rb_sub_np(b, __uint_as_float(ww & 0xffff0000u));
+        }
+    }
+}
+
 template <int KW, int C>
 struct RbfGeom {
     static constexpr int KS = C / 16, RB = C / 32, CG = 4 / RB;
@@ -71,7 +105,8 @@ struct RbfGeom {
     static constexpr int NG = KW * KS;                       // (tap, k step) groups per conv
     static constexpr int GROUP_BYTES = 3 * 1024;             // three splits of one 32 x 16 tap fragment
     static constexpr int CONV_BYTES = NG * RB * GROUP_BYTES;
-    static constexpr int LDS_BYTES = X_BYTES + T_BYTES;
+    static constexpr int R_BYTES = C * N1 * 4;               // the io buffer: residual (raw rows of the block's own columns) in, outputs out
+    static constexpr int LDS_BYTES = X_BYTES + T_BYTES + R_BYTES;
     static_assert((C / 4) * XRP % 256 == 0, "");
     static_assert(LDS_BYTES <= 163840, "LDS budget");
     static_assert((ROWB / 16) % 2 == 1, "row stride must be an odd multiple of 16 bytes");
@@ -87,7 +122,9 @@ __device__ __forceinline__ void rb_split3(rb_f32x2 v, unsigned w[3]) {
     }
 }
 
-template <int KW, int C>
+// DBG (ablation build only): 128 = wave 0 and stager wave 4 write s_memtime stamps to the buffer passed as `accin` (which is then NOT
+// added): [block][compute | stager][64], eight per tile -- tools/stamp_resblock_bf.py turns them into a per-phase breakdown
+template <int KW, int C, int DBG = 0>
 __global__ void __launch_bounds__(RBF_NTH) __attribute__((amdgpu_waves_per_eu(2, 2)))
 resblock_bf_kernel(const RbfParams p) {
     using GM = RbfGeom<KW, C>;
@@ -97,6 +134,7 @@ resblock_bf_kernel(const RbfParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
     unsigned char *const xs = rb_smem;
     unsigned char *const ts = rb_smem + GM::X_BYTES;
+    float *const io_lds = reinterpret_cast<float *>(rb_smem + GM::X_BYTES + GM::T_BYTES);   // [C][N1]: residual in, outputs out
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,12 +150,27 @@ resblock_bf_kernel(const RbfParams p) {
     const int tile_end = (xcd + 1) * p.per_xcd < p.n_tiles ? (xcd + 1) * p.per_xcd : p.n_tiles;
     int tile = xcd * p.per_xcd + slot;
     if (tile >= tile_end) return;
+    unsigned long long *const stamps = (DBG & 128) ? reinterpret_cast<unsigned long long *>(const_cast<float *>(p.accin)) + ((size_t)blockIdx.x * 2 + (wave >= 4 ? 1 : 0)) * 64 : nullptr;
+    int n_stamp = 0;
+    auto stamp = [&]() __attribute__((always_inline)) {
+        if constexpr (DBG & 128) {
+            if ((wave == 0 || wave == 4) && lane == 0 && n_stamp < 64) stamps[n_stamp] = __builtin_readcyclecounter();
+            ++n_stamp;
+        }
+    };
 
     if (wave >= 4) {
-        // ============================================ stagers: HBM -> registers -> bf16 triples in LDS =====================
-        const int ht = tid - 256;
-        float xr[NIT][4];
-        auto x_issue = [&](int tl) __attribute__((always_inline)) {
+        // ============================================ stagers: HBM <-> LDS ============================================================
+        // This wave shares its SIMD with a compute wave and, being the younger one, loses every issue arbitration to it: its few
+        // hundred instructions per tile sit on the block's critical path (the barriers), so it gets the issue slots first.
+        __builtin_amdgcn_s_setprio(1);
+        const int ht = tid - 256, sw = wave - 4;
+        // C = 32: two tiles in flight (tile i waits in set i & 1).  C = 64: one -- 48 registers per set, and its shortest conv1
+        // (three taps: 6 500 cycles with its epilogue) still covers an HBM round trip
+        constexpr int NSET = C == 32 ? 2 : 1;
+        float xr[NSET][NIT][4];
+        auto x_issue = [&](auto SET, int tl) __attribute__((always_inline)) {
+            constexpr int st = decltype(SET)::value;
             const int bb = tl / p.tiles_per_row;
             const int64_t xt0 = (int64_t)(tl - bb * p.tiles_per_row) * BN - H2 - h1;       // time of row 0
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + (int64_t)bb * C * L), 0, num_bytes, RBF_RSRC_FLAGS);
@@ -130,11 +183,12 @@ resblock_bf_kernel(const RbfParams p) {
                 const unsigned base = (unsigned)(4 * q) * L4 + (unsigned)tg * 4u;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    xr[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(ok ? base + (unsigned)e * L4 : RBF_OOB), 0, 0));
+                    xr[st][i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(ok ? base + (unsigned)e * L4 : RBF_OOB), 0, 0));
             }
         };
         const float slope = p.slope;
-        auto x_write = [&]() __attribute__((always_inline)) {
+        auto x_write = [&](auto SET) __attribute__((always_inline)) {
+            constexpr int st = decltype(SET)::value;
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
                 const int idx = ht + 256 * i;
@@ -143,26 +197,121 @@ resblock_bf_kernel(const RbfParams p) {
                 unsigned w[2][3];
 #pragma unroll
                 for (int e2 = 0; e2 < 2; ++e2) {
-                    const rb_f32x2 v = rb_f32x2{xr[i][2 * e2], xr[i][2 * e2 + 1]};
-                    const rb_f32x2 sv = v * slope;
-                    rb_split3(rb_f32x2{__builtin_fmaxf(v.x, sv.x), __builtin_fmaxf(v.y, sv.y)}, w[e2]);
+                    const float va = xr[st][i][2 * e2], vb = xr[st][i][2 * e2 + 1];
+                    rb_split3_np(__builtin_fmaxf(va, rb_mul_np(va, slope)), __builtin_fmaxf(vb, rb_mul_np(vb, slope)), w[e2]);
                 }
                 unsigned char *o = xs + r * ROWB + q * 8;
 #pragma unroll
                 for (int s = 0; s < 3; ++s) *reinterpret_cast<rb_u32x2 *>(o + s * 2 * C) = rb_u32x2{w[0][s], w[1][s]};
+                // the raw values of the block's own columns: the residual the compute waves add (lanes = consecutive columns of one row)
+                const int j = r - h1 - H2;
+                if (j >= 0 && j < N1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) io_lds[(4 * q + e) * N1 + j] = xr[st][i][e];
+                }
             }
         };
+        // ---- the finished tile: io buffer -> (+ running sum) * scale -> HBM, 16 bytes per lane, whole rows ------------------------------
+        constexpr int CHUNKS = N1 / 4, RPW = 64 / CHUNKS, PASSES = C / (4 * RPW);      // float4 per row, rows per wave and pass
+        const int chunk = lane % CHUNKS, rsub = lane / CHUNKS;
+        const float out_scale = p.out_scale;
+        const bool l4 = (L & 3) == 0;
+        auto out_store = [&](int tl, bool with_acc) __attribute__((always_inline)) {
+            const int bb = tl / p.tiles_per_row;
+            const int64_t t0 = (int64_t)(tl - bb * p.tiles_per_row) * BN;
+            const bool ok = 4 * chunk < BN && t0 + 4 * chunk < L;
+            const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.y + (int64_t)bb * C * L), 0, num_bytes, RBF_RSRC_FLAGS);
+            const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void *)((with_acc ? p.accin : p.y) + (int64_t)bb * C * L), 0, num_bytes, RBF_RSRC_FLAGS);
+            const unsigned o0 = ok ? (unsigned)(sw * RPW + rsub) * L4 + (unsigned)(t0 + 4 * chunk) * 4u : RBF_OOB;
+            constexpr int HP = PASSES / 2;                    // two halves: registers (the x sets stay live next to this)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                f32x4 v[HP], av[HP];
+#pragma unroll
+                for (int k = 0; k < HP; ++k) {
+                    const int ps = hf * HP + k;
+                    const unsigned o = o0 + (unsigned)(ps * 4 * RPW) * L4;         // (an out-of-range o0 stays out of range)
+                    av[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (with_acc) {   // the running sum of the tile's own columns (one launch in 4.5): requested first, used last
+                        if (l4) {
+                            av[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, (int)o, 0, 0));
+                        } else {      // rows not 16-byte aligned: element by element (elements past the row's end: out of range, zero)
+                            float ae[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const unsigned oe = (ok && t0 + 4 * chunk + e < L) ? o + 4u * (unsigned)e : RBF_OOB;
+                                ae[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars, (int)oe, 0, 0));
+                            }
+                            av[k] = f32x4{ae[0], ae[1], ae[2], ae[3]};
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < HP; ++k) v[k] = *reinterpret_cast<const f32x4 *>(io_lds + (((hf * HP + k) * 4 + sw) * RPW + rsub) * N1 + 4 * chunk);
+#pragma unroll
+                for (int k = 0; k < HP; ++k) {
+                    const unsigned o = o0 + (unsigned)((hf * HP + k) * 4 * RPW) * L4;
+                    float re[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+                    const float ae[4] = {av[k].x, av[k].y, av[k].z, av[k].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (with_acc) re[e] = rb_add_np(re[e], ae[e]);
+                        re[e] = rb_mul_np(re[e], out_scale);
+                    }
+                    if (l4) {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rb_u32x4, f32x4{re[0], re[1], re[2], re[3]}), yrs, (int)o, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned oe = (ok && t0 + 4 * chunk + e < L) ? o + 4u * (unsigned)e : RBF_OOB;
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, re[e]), yrs, (int)oe, 0, 0);
+                        }
+                    }
+                }
+            }
+        };
+        const bool has_acc = p.accin != nullptr && !(DBG & 128);
         // rows N1 .. TROWS-1 of the t tile are read by masked output columns only and never written: give them a value once
         for (int o = ht * 16; o < (KW - 1) * ROWB; o += 256 * 16) *reinterpret_cast<rb_u32x4 *>(ts + N1 * ROWB + o) = rb_u32x4{0u, 0u, 0u, 0u};
-        x_issue(tile);
-        x_write();
-        for (; tile < tile_end; tile += nslot) {
-            const int next = tile + nslot;
-            lds_barrier();                                    // (A) the x tile is complete
-            if (next < tile_end) x_issue(next);
+        // Tile i + 2 is requested behind barrier D of tile i and written behind barrier B of tile i + 1: a whole tile between request
+        // and use.  Never more than one set + 8 stores in flight: with two sets of a 64-channel tile -- 96 loads -- in flight at once
+        // in the prologue, the second tile of a block came out wrong on a few blocks per launch (more outstanding memory operations
+        // than the 6-bit counter counts; profiles/r05_rbf_notes.txt).
+        constexpr std::integral_constant<int, 0> S0{};
+        constexpr std::integral_constant<int, NSET - 1> SL{};   // the "other" set (the same one when there is only one)
+        x_issue(S0, tile);
+        x_write(S0);
+        if (NSET == 2 && tile + nslot < tile_end) x_issue(SL, tile + nslot);
+        int prev = -1;                                        // the tile whose outputs the compute waves hand over behind the next barrier A
+        auto phase = [&](int tl, auto SET_CUR, auto SET_NEXT) __attribute__((always_inline)) {
+            stamp();
+            lds_barrier();                                    // (A) x tile + residual complete; the compute waves swap residual <-> outputs
+            stamp();
+            lds_barrier();                                    // (D) the previous tile's outputs are in the io buffer
+            if (prev >= 0) out_store(prev, has_acc);
+            // everything older than those (at most eight) stores has returned -- it is a whole phase old -- before the next set is
+            // requested: never more than 8 + one set of memory operations in flight (see below)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (tl + NSET * nslot < tile_end) x_issue(SET_CUR, tl + NSET * nslot);   // this set left the registers before barrier A
+            stamp();
             lds_barrier();                                    // (B) conv1 has read the x tile
-            if (next < tile_end) x_write();
+            stamp();
+            if constexpr (DBG & 128) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stamps: separate the wait for the loads from the work
+            stamp();
+            if (tl + nslot < tile_end) x_write(SET_NEXT);
+            stamp();
+            n_stamp += 2;
+            prev = tl;
+        };
+        for (; tile < tile_end; tile += 2 * nslot) {
+            phase(tile, S0, SL);
+            if (tile + nslot < tile_end) phase(tile + nslot, SL, S0);
         }
+        // the last tile's outputs
+        lds_barrier();                                        // (A')
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();                                        // (D')
+        out_store(prev, has_acc);
         return;
     }
 
@@ -177,8 +326,7 @@ resblock_bf_kernel(const RbfParams p) {
         bias2[r] = p.b2 ? p.b2[ch] : 0.f;
     }
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, 2 * GM::CONV_BYTES, RBF_RSRC_FLAGS);
-    const float slope = p.slope, out_scale = p.out_scale;
-    const bool has_acc = p.accin != nullptr;
+    const float slope = p.slope;
 
     rb_bf16x8 fa[PA][3];
     rb_bf16x8 fb[2][2][3];
@@ -232,13 +380,45 @@ resblock_bf_kernel(const RbfParams p) {
     const unsigned char *const xsrc = xs + (col0 + l31) * ROWB + half * 16;
     const unsigned char *const tsrc = ts + (col0 + l31) * ROWB + half * 16;
     const int xstep = d * ROWB;
+    // The compute waves issue no memory operation but their tap-fragment loads (L2): the residual comes from, and the outputs go
+    // to, the io buffer [channel][column] in LDS, which the stagers fill and drain with 16-byte accesses of whole rows.  (Stored by
+    // these waves -- 32 four-byte stores per lane -- a tile's outputs cost their issue time plus, a wave's memory operations retiring
+    // in order, the stores' write acknowledgement in front of the next tap-fragment wait: ~3 500 cycles of a 19 500-cycle tile.)
+    // io[cb][r]: from barrier A to conv2's epilogue the residual of this tile; from there to the next barrier A its outputs.
+    float io[2][16];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) io[cb][r] = 0.f;
+    float *const io_mine = io_lds + (32 * rb + 4 * half) * N1 + col0 + l31;
+    // every element of the io buffer is read (residual) and then written (outputs of the previous tile) by the SAME lane: no barrier between
+    auto swap_io = [&]() __attribute__((always_inline)) {
+        float rsd[2][16];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rsd[cb][r] = io_mine[((r & 3) + 8 * (r >> 2)) * N1 + cb * 32];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) io_mine[((r & 3) + 8 * (r >> 2)) * N1 + cb * 32] = io[cb][r];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) io[cb][r] = rsd[cb][r];
+    };
 
     a_prologue(0);
     for (; tile < tile_end; tile += nslot) {
         const int bb = tile / p.tiles_per_row;
         const int64_t t0 = (int64_t)(tile - bb * p.tiles_per_row) * BN;
-        lds_barrier();                                        // (A) the x tile is complete; every wave is done with the t tile
+        stamp();
+        lds_barrier();                                        // (A) x tile + residual complete; every wave is done with the t tile
+        stamp();
+        swap_io();
+        lds_barrier();                                        // (D) the previous tile's outputs are in the io buffer
         conv_loop(0, xsrc, xstep);
+        stamp();
         a_prologue(1);
         // ---- conv1's epilogue: bias, leaky ReLU, the zero padding conv2 sees outside [0, L), split, into the t tile ----------
 #pragma unroll
@@ -263,40 +443,23 @@ resblock_bf_kernel(const RbfParams p) {
                 for (int s = 0; s < 3; ++s) *reinterpret_cast<rb_u32x2 *>(o + s * 2 * C) = rb_u32x2{w[0][s], w[1][s]};
             }
         }
+        stamp();
         lds_barrier();                                        // (B) the t tile is complete; the x tile is free
-        // ---- the residual: the raw rows of this tile (L2: the stagers fetched them a tile ago), requested before conv2 ---------
-        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + (int64_t)bb * C * L), 0, num_bytes, RBF_RSRC_FLAGS);
-        unsigned off[2];
-        float resv[2][16];
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const int j = col0 + cb * 32 + l31;
-            const bool ok = j < BN && t0 + j < L;
-            off[cb] = ok ? (unsigned)(32 * rb + 4 * half) * L4 + (unsigned)(t0 + j) * 4u : RBF_OOB;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                resv[cb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)(off[cb] + (unsigned)((r & 3) + 8 * (r >> 2)) * L4), 0, 0));
-        }
+        stamp();
         conv_loop(1, tsrc, ROWB);
-        if (tile + nslot < tile_end) a_prologue(0);           // the next tile's first tap fragments, ahead of this tile's stores
-        // ---- conv2's epilogue: bias, residual, running sum, scale, store ----------------------------------------------------------
-        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.y + (int64_t)bb * C * L), 0, num_bytes, RBF_RSRC_FLAGS);
-        if (has_acc) {
-            const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void *)(p.accin + (int64_t)bb * C * L), 0, num_bytes, RBF_RSRC_FLAGS);
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    resv[cb][r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars, (int)(off[cb] + (unsigned)((r & 3) + 8 * (r >> 2)) * L4), 0, 0));
-        }
+        stamp();
+        a_prologue(0);                                        // the next tile's first tap fragments (the last tile re-reads them: no branch)
+        // ---- conv2's epilogue: bias + residual (running sum and scale are the stagers') ------------------------------------------------
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = (acc[cb][r] + bias2[r] + resv[cb][r]) * out_scale;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, (int)(off[cb] + (unsigned)((r & 3) + 8 * (r >> 2)) * L4), 0, 0);
-            }
+            for (int r = 0; r < 16; ++r) io[cb][r] = acc[cb][r] + bias2[r] + io[cb][r];
+        stamp();
+        stamp();
     }
+    lds_barrier();                                            // (A') nobody reads the io buffer's residual any more
+    swap_io();                                                // (the values read back are not used)
+    lds_barrier();                                            // (D') the last tile's outputs are in the io buffer
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
@@ -350,13 +513,13 @@ static int rbf_cu_count() {
     return n;
 }
 
-template <int KW, int C>
+template <int KW, int C, int DBG = 0>
 static int rbf_launch(RbfParams p, int batch, hipStream_t stream) {
     using GM = RbfGeom<KW, C>;
     static std::once_flag once;
     static hipError_t err = hipSuccess;
     std::call_once(once, [] {
-        err = hipFuncSetAttribute((const void *)resblock_bf_kernel<KW, C>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
+        err = hipFuncSetAttribute((const void *)resblock_bf_kernel<KW, C, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
     });
     if (err != hipSuccess) return fail("resblock_bf: cannot reserve %d bytes of LDS: %s", LDS_WHOLE_CU, hipGetErrorString(err));
     p.tiles_per_row = (int)ceil_div(p.L, GM::BN);
@@ -364,7 +527,7 @@ static int rbf_launch(RbfParams p, int batch, hipStream_t stream) {
     p.per_xcd = (int)ceil_div(p.n_tiles, 8);
     const int cus = rbf_cu_count() / 8 * 8;
     const int slots = (int)std::min<int64_t>(cus / 8, p.per_xcd);           // blocks per XCD
-    hipLaunchKernelGGL((resblock_bf_kernel<KW, C>), dim3((unsigned)(slots * 8)), dim3(RBF_NTH), LDS_WHOLE_CU, stream, p);   // owns its CU (common.h)
+    hipLaunchKernelGGL((resblock_bf_kernel<KW, C, DBG>), dim3((unsigned)(slots * 8)), dim3(RBF_NTH), LDS_WHOLE_CU, stream, p);   // owns its CU (common.h)
     RVC_LAUNCH_CHECK();
     return 0;
 }
@@ -380,6 +543,12 @@ int launch_resblock_bf(const float *x, const void *u, const float *b1, const flo
     if ((int64_t)ceil_div(L, 64) * batch >= ((int64_t)1 << 30)) return fail("resblock_bf: too many tiles");
     RbfParams p;
     p.x = x; p.u = u; p.b1 = b1; p.b2 = b2; p.accin = accin; p.y = y; p.L = L; p.dil = dil; p.slope = slope; p.out_scale = out_scale;
+#ifdef RVC_ABLATE
+    static const int dbg = knob("RVC_RBF_DBG", 0);
+#define RVC_RBF_DBG_CASE(KW, CC) if (dbg == 128 && k == KW && c == CC) return rbf_launch<KW, CC, 128>(p, batch, stream)
+    RVC_RBF_DBG_CASE(3, 32); RVC_RBF_DBG_CASE(7, 32); RVC_RBF_DBG_CASE(11, 32); RVC_RBF_DBG_CASE(7, 64);
+#undef RVC_RBF_DBG_CASE
+#endif
 #define RVC_RBF_CASE(KW, CC) if (k == KW && c == CC) return rbf_launch<KW, CC>(p, batch, stream)
     RVC_RBF_CASE(3, 32); RVC_RBF_CASE(7, 32); RVC_RBF_CASE(11, 32);
     RVC_RBF_CASE(3, 64); RVC_RBF_CASE(7, 64); RVC_RBF_CASE(11, 64);

@@ -20,7 +20,7 @@ def _clean_env(**extra):
     return env
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_bench_self_launches_n_ranks(world):
     r = subprocess.run([sys.executable, BENCH, "--gpus", str(world), "--steps", "3", "--warmup", "1", "--control-flow-only"],
                        env=_clean_env(), capture_output=True, text=True, timeout=600)

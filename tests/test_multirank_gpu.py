@@ -17,9 +17,9 @@ WORKER = os.path.join(REPO, "tests", "_ranks_worker.py")
 N_UTT = 4
 
 
-def _run(world, out_dir):
+def _run(world, out_dir, n_utt=N_UTT):
     from rvc_amd.infer.distributed import spawn_ranks
-    env = {"OUT_DIR": str(out_dir), "N_UTT": str(N_UTT), "UTT_SECONDS": "3.0"}
+    env = {"OUT_DIR": str(out_dir), "N_UTT": str(n_utt), "UTT_SECONDS": "3.0"}
     if world > 1:
         env["RVC_DIST_BACKEND"] = "gloo"
     rc = spawn_ranks([sys.executable, WORKER], world, env_extra=env, timeout=900)
@@ -49,3 +49,25 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
     n_total = sum(one[f"utt{i}"].shape[0] for i in range(N_UTT))
     assert int(two[0]["total"]) == int(two[1]["total"]) == int(one["total"]) == n_total
     assert float(two[0]["t_max"]) == 2.0 and float(one["t_max"]) == 1.0
+
+
+def test_four_ranks_strided_batch_equals_one_rank(tmp_path):
+    """BASELINE cfg 3's sharding at the scale one GPU allows: a batch of 8 utterances over 4 ranks (utterance i -> rank i mod 4,
+    two per rank -- cfg 3 is 512 over 8, 64 per rank, the same striding), four processes sharing cuda:0 over gloo.  Every
+    utterance must come out of exactly one rank and equal the 1-rank job's; all four ranks hold the root's index bytes."""
+    n = 8
+    (one,) = _run(1, tmp_path, n)
+    four = _run(4, tmp_path, n)
+    assert all(bool(r["agree"]) for r in four)
+    assert all(np.array_equal(r["checksum"], one["checksum"]) for r in four)
+    worst = 0.0
+    for i in range(n):
+        holders = [r for r in range(4) if f"utt{i}" in four[r].files]
+        assert holders == [i % 4], (i, holders)
+        a, b = four[i % 4][f"utt{i}"], one[f"utt{i}"]
+        assert a.shape == b.shape and a.dtype == np.float32
+        worst = max(worst, rms(a - b))
+    print(f"4 ranks on one GPU, 8 utterances vs 1 rank: worst per-utterance waveform rms difference {worst:.2e} (gate 1e-5)")
+    assert worst <= 1e-5
+    n_total = sum(one[f"utt{i}"].shape[0] for i in range(n))
+    assert all(int(r["total"]) == n_total for r in four) and float(four[0]["t_max"]) == 4.0
