@@ -427,7 +427,7 @@ def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev, utterance):
         run_mix()
     reps = 5
     t_batches = []
-    for _ in range(3):            # MEAN of three batches (what rocprofv3 --stats averages too), each behind a device-wide synchronise
+    for _ in range(3):            # MEDIAN of three batches (one batch in ~10 runs 2.5 x the others on a freshly leased box), each behind a device-wide synchronise
         torch.cuda.synchronize()
         e0.record()
         for _ in range(reps):
@@ -435,7 +435,7 @@ def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev, utterance):
         e1.record()
         torch.cuda.synchronize()
         t_batches.append(e0.elapsed_time(e1) / (reps * mix_launches) * 1e-3)
-    t_launch = float(np.mean(t_batches))
+    t_launch = float(np.median(t_batches))
     flops_launch = mix_flops / mix_launches
     cfg2 = T == 3198 and list(rates[:2]) == [12, 10]
     exe_launch = mix_executed / mix_launches

@@ -63,6 +63,7 @@ int launch_resblock_layer(const float *x, const float *w1, const float *b1, cons
 // 64-channel stages; same semantics as launch_resblock_layer with the pair's taps packed as matrix-instruction fragments
 bool resblock_bf_enabled();   // ablation build: RVC_RBF=0 puts the stages back on the unfused kernels
 bool resblock_bf_supported(int c, int k, int dil);
+bool resblock_bf_preferred(int c, int k);   // the shapes where it beats the two launches it replaces (measured)
 bool resblock_bf_fits(int c, int64_t L);
 size_t resblock_bf_weight_bytes(int c, int k);
 void resblock_bf_pack_host(const float *w1, const float *w2, int c, int k, std::vector<uint16_t> *out);   // w: [c][c][k]

@@ -581,7 +581,7 @@ extern "C" int rvc_decoder_finalize(rvc_decoder *d) {
                 const bool b16 = c.weight_storage == 1 && (k == 3 || k == 7 || k == 11);
                 if (build_conv(d, p1, s.c_out, s.c_out, k, true, &s.c1[m * c.n_res_dilations + j], b16)) return 1;
                 if (build_conv(d, p2, s.c_out, s.c_out, k, true, &s.c2[m * c.n_res_dilations + j], b16)) return 1;
-                if (resblock_bf_enabled() && resblock_bf_supported(s.c_out, k, 1)) {   // the fused pair on the bf16 matrix cores (K3f)
+                if (resblock_bf_enabled() && resblock_bf_supported(s.c_out, k, 1) && resblock_bf_preferred(s.c_out, k)) {   // the fused pair on the bf16 matrix cores (K3f)
                     const HostTensor *w1, *w2;
                     if (need(d, p1 + ".weight", &w1, {s.c_out, s.c_out, k}) || need(d, p2 + ".weight", &w2, {s.c_out, s.c_out, k})) return 1;
                     std::vector<float> v1(w1->data), v2(w2->data);

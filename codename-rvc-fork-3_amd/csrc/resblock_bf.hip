@@ -99,13 +99,13 @@ struct RbfGeom {
     static constexpr int ROWB = 6 * C + 16;                  // [split 3][channel C] bf16 + 16 bytes
     static constexpr int XROWS = N1 + (KW - 1) * 5;          // dilation <= 5
     static constexpr int TROWS = N1 + (KW - 1);
-    static constexpr int X_BYTES = XROWS * ROWB, T_BYTES = TROWS * ROWB;
+    static constexpr int X_BYTES = (XROWS + 1) * ROWB, T_BYTES = TROWS * ROWB;   // + one row that takes the writes of items outside the tile
     static constexpr int XRP = (XROWS + 63) / 64 * 64;       // staged rows rounded up: a wave's 64 lanes share a channel quad
     static constexpr int NIT = (C / 4) * XRP / 256;          // (row, channel quad) items per stager lane
     static constexpr int NG = KW * KS;                       // (tap, k step) groups per conv
     static constexpr int GROUP_BYTES = 3 * 1024;             // three splits of one 32 x 16 tap fragment
     static constexpr int CONV_BYTES = NG * RB * GROUP_BYTES;
-    static constexpr int R_BYTES = C * N1 * 4;               // the io buffer: residual (raw rows of the block's own columns) in, outputs out
+    static constexpr int R_BYTES = C * N1 * 4 + 16;          // the io buffer (+ 4 floats that take the writes of rows outside the block's own columns): residual (raw rows of the block's own columns) in, outputs out
     static constexpr int LDS_BYTES = X_BYTES + T_BYTES + R_BYTES;
     static_assert((C / 4) * XRP % 256 == 0, "");
     static_assert(LDS_BYTES <= 163840, "LDS budget");
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(RBF_NTH) __attribute__((amdgpu_waves_per_eu(2,
 resblock_bf_kernel(const RbfParams p) {
     using GM = RbfGeom<KW, C>;
     constexpr int KS = GM::KS, RB = GM::RB, N1 = GM::N1, H2 = GM::H2, BN = GM::BN, ROWB = GM::ROWB, NIT = GM::NIT, XRP = GM::XRP;
-    constexpr int NG = GM::NG, PA = 4;
+    constexpr int NG = GM::NG, PA = 4;   // (a ring of six: no change, measured)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
     unsigned char *const xs = rb_smem;
@@ -169,46 +169,56 @@ resblock_bf_kernel(const RbfParams p) {
         // (three taps: 6 500 cycles with its epilogue) still covers an HBM round trip
         constexpr int NSET = C == 32 ? 2 : 1;
         float xr[NSET][NIT][4];
+        // item i of this wave = (channel quad q, 64-row chunk rc) with sw * NIT + i = q * RC + rc: q and rc are wave-uniform (scalar
+        // registers), a lane's row is rc * 64 + lane
+        constexpr int RC = XRP / 64;
+        static_assert((C / 4) * RC == 4 * NIT, "");
         auto x_issue = [&](auto SET, int tl) __attribute__((always_inline)) {
             constexpr int st = decltype(SET)::value;
             const int bb = tl / p.tiles_per_row;
-            const int64_t xt0 = (int64_t)(tl - bb * p.tiles_per_row) * BN - H2 - h1;       // time of row 0
+            const int xt0 = (tl - bb * p.tiles_per_row) * BN - H2 - h1;                     // time of row 0 (a row holds < 2^29 samples)
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + (int64_t)bb * C * L), 0, num_bytes, RBF_RSRC_FLAGS);
+            const unsigned Lu = (unsigned)L;
+            int sw_o = sw;                                    // opaque: the per-item scalars are recomputed here (a dozen scalar operations
+            asm volatile("" : "+s"(sw_o));                    // per item) instead of being hoisted out of the tile loop and spilled (333 of them)
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
-                const int idx = ht + 256 * i;
-                const int q = idx / XRP, r = idx - q * XRP;
-                const int64_t tg = xt0 + r;
-                const bool ok = r < XR && tg >= 0 && tg < L;
-                const unsigned base = (unsigned)(4 * q) * L4 + (unsigned)tg * 4u;
+                const int wi = sw_o * NIT + i, q = wi / RC, rc = wi - q * RC;
+                const int r = rc * 64 + lane;
+                const unsigned tg = (unsigned)(xt0 + r);                                    // negative or beyond the row: >= L as unsigned
+                const bool ok = r < XR && tg < Lu;
+                const unsigned base = (unsigned)(4 * q) * L4 + tg * 4u;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     xr[st][i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(ok ? base + (unsigned)e * L4 : RBF_OOB), 0, 0));
             }
         };
         const float slope = p.slope;
+        // no branch per item (an item outside the tile writes to the dump row): the items' dependency chains interleave
         auto x_write = [&](auto SET) __attribute__((always_inline)) {
             constexpr int st = decltype(SET)::value;
+            int sw_o = sw;
+            asm volatile("" : "+s"(sw_o));
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
-                const int idx = ht + 256 * i;
-                const int q = idx / XRP, r = idx - q * XRP;
-                if (r >= XR) continue;
+                const int wi = sw_o * NIT + i, q = wi / RC, rc = wi - q * RC;
+                const int r = rc * 64 + lane;
                 unsigned w[2][3];
 #pragma unroll
                 for (int e2 = 0; e2 < 2; ++e2) {
                     const float va = xr[st][i][2 * e2], vb = xr[st][i][2 * e2 + 1];
                     rb_split3_np(__builtin_fmaxf(va, rb_mul_np(va, slope)), __builtin_fmaxf(vb, rb_mul_np(vb, slope)), w[e2]);
                 }
-                unsigned char *o = xs + r * ROWB + q * 8;
+                unsigned char *o = xs + (r < XR ? r : GM::XROWS) * ROWB + q * 8;
 #pragma unroll
                 for (int s = 0; s < 3; ++s) *reinterpret_cast<rb_u32x2 *>(o + s * 2 * C) = rb_u32x2{w[0][s], w[1][s]};
                 // the raw values of the block's own columns: the residual the compute waves add (lanes = consecutive columns of one row)
                 const int j = r - h1 - H2;
-                if (j >= 0 && j < N1) {
+                const bool own = r < XR && j >= 0 && j < N1;
+                float *const ro = io_lds + (own ? 4 * q * N1 + j : C * N1);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) io_lds[(4 * q + e) * N1 + j] = xr[st][i][e];
-                }
+                for (int e = 0; e < 4; ++e) ro[own ? e * N1 : e] = xr[st][i][e];
+                if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two items (four chains) at a time: more of them spill
             }
         };
         // ---- the finished tile: io buffer -> (+ running sum) * scale -> HBM, 16 bytes per lane, whole rows ------------------------------
@@ -416,7 +426,9 @@ resblock_bf_kernel(const RbfParams p) {
         lds_barrier();                                        // (A) x tile + residual complete; every wave is done with the t tile
         stamp();
         swap_io();
+        stamp();
         lds_barrier();                                        // (D) the previous tile's outputs are in the io buffer
+        stamp();
         conv_loop(0, xsrc, xstep);
         stamp();
         a_prologue(1);
@@ -454,8 +466,6 @@ resblock_bf_kernel(const RbfParams p) {
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) io[cb][r] = acc[cb][r] + bias2[r] + io[cb][r];
-        stamp();
-        stamp();
     }
     lds_barrier();                                            // (A') nobody reads the io buffer's residual any more
     swap_io();                                                // (the values read back are not used)
@@ -471,6 +481,18 @@ bool resblock_bf_enabled() {
 
 bool resblock_bf_supported(int c, int k, int dil) {
     return (c == 32 || c == 64) && (k == 3 || k == 7 || k == 11) && dil >= 1 && dil <= 5;
+}
+
+// Where the decoder takes this kernel (profiles/r05_rbf_shapes.txt, us per pair at the cfg-2 lengths, against the two launches it
+// replaces): C = 32: 155-164 / 238-243 / 332-338 at 3 / 7 / 11 taps against 250-272 / 322-341 / 406-434; C = 64: 222-224 / 418-430
+// against 300-317 / 453-482 at 3 / 7 taps.  C = 64 with 11 taps stays on winobf.hip's Winograd form (637-641 against 554-566: the
+// direct form executes 2.1 x its matrix work there and only 116 of a block's 128 columns are outputs).
+bool resblock_bf_preferred(int c, int k) {
+#ifdef RVC_ABLATE
+    static const int all = knob("RVC_RBF_ALL", 0);
+    if (all) return true;
+#endif
+    return c == 32 || (c == 64 && k != 11);
 }
 
 bool resblock_bf_fits(int c, int64_t L) { return (int64_t)c * L * 4 < ((int64_t)1 << 31); }

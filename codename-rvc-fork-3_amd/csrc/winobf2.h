@@ -1,5 +1,6 @@
-// what winobf2.hip (K3y, one transform point per wave) and winobf3.hip (K3z, its balanced form) share: parameters, the input
-// transforms' coefficient tables, the block geometry in LDS
+// winobf2.hip (K3y, one transform point per wave): parameters, the input transforms' coefficient tables, the block geometry in LDS
+// (round 4's balanced form K3z, winobf3.hip, shared this header: parity-green, 19 % slower, removed in round 5 --
+// profiles/r04_winobf3_balanced_ab.txt)
 #pragma once
 #include "conv.h"
 
@@ -87,8 +88,5 @@ struct W2Geom {
     static_assert(LDS_BYTES <= 163840, "LDS budget");
 };
 
-bool winobf3_enabled();
-bool winobf3_supported(int c_in, int c_out, int k, int dil);
-int launch_winobf3_conv(const Wbf2Params &p, int k, hipStream_t stream);
 
 }  // namespace rvc

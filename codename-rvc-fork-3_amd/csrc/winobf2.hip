@@ -766,7 +766,6 @@ int launch_winobf2_conv(const float *x, const void *u, const float *bias, const 
     Wbf2Params p;
     p.x = x; p.u = u; p.bias = bias; p.res = res; p.accin = accin; p.y = y;
     p.c_in = c_in; p.c_out = c_out; p.L = L; p.dil = dil; p.slope = slope; p.out_scale = out_scale; p.batch = batch;
-    if (winobf3_enabled() && winobf3_supported(c_in, c_out, k, dil)) return launch_winobf3_conv(p, k, stream);   // the balanced form (winobf3.hip)
 #ifdef RVC_ABLATE
     if (k == 11) {   // where does the time go (tools/ablate_winobf2.sh; wrong results)
         static const int dbg = knob("RVC_W2_DBG", 0);

@@ -34,11 +34,13 @@ t = slice(1, 7)
 per_tile = m(cw[:, 2:8, 0] - cw[:, 1:7, 0])
 print(f"  one tile, barrier A to barrier A                {per_tile:8.0f}")
 print(f"  compute wave 0: waits at barrier A              {m(cw[:, t, 1] - cw[:, t, 0]):8.0f}")
-print(f"    io swap, barrier D, conv1                     {m(cw[:, t, 2] - cw[:, t, 1]):8.0f}")
-print(f"    conv1 epilogue (bias, leaky, split, LDS)      {m(cw[:, t, 3] - cw[:, t, 2]):8.0f}")
-print(f"    waits at barrier B                            {m(cw[:, t, 4] - cw[:, t, 3]):8.0f}")
-print(f"    conv2 (matrix loop)                           {m(cw[:, t, 5] - cw[:, t, 4]):8.0f}")
-print(f"    conv2 epilogue (bias, residual)               {m(cw[:, t, 6] - cw[:, t, 5]):8.0f}")
+print(f"    io swap (residual in, previous outputs out)   {m(cw[:, t, 2] - cw[:, t, 1]):8.0f}")
+print(f"    waits at barrier D                            {m(cw[:, t, 3] - cw[:, t, 2]):8.0f}")
+print(f"    conv1 (matrix loop)                           {m(cw[:, t, 4] - cw[:, t, 3]):8.0f}")
+print(f"    conv1 epilogue (bias, leaky, split, LDS)      {m(cw[:, t, 5] - cw[:, t, 4]):8.0f}")
+print(f"    waits at barrier B                            {m(cw[:, t, 6] - cw[:, t, 5]):8.0f}")
+print(f"    conv2 (matrix loop)                           {m(cw[:, t, 7] - cw[:, t, 6]):8.0f}")
+print(f"    conv2 epilogue (bias, residual)               {m(cw[:, 2:8, 0] - cw[:, 1:7, 7]):8.0f}")
 print(f"  stager wave 4: arrives at barrier A             {m(st[:, t, 0] - cw[:, t, 0]):8.0f} after compute wave 0")
 print(f"    barrier D, stores the previous tile, requests {m(st[:, t, 2] - st[:, t, 1]):8.0f}")
 print(f"    waits at barrier B                            {m(st[:, t, 3] - st[:, t, 2]):8.0f}")
