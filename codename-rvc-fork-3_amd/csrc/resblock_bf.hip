@@ -100,14 +100,15 @@ struct RbfGeom {
     static constexpr int XROWS = N1 + (KW - 1) * 5;          // dilation <= 5
     static constexpr int TROWS = N1 + (KW - 1);
     static constexpr int X_BYTES = (XROWS + 1) * ROWB, T_BYTES = TROWS * ROWB;   // + one row that takes the writes of items outside the tile
-    static constexpr int XRP = (XROWS + 63) / 64 * 64;       // staged rows rounded up: a wave's 64 lanes share a channel quad
-    static constexpr int NIT = (C / 4) * XRP / 256;          // (row, channel quad) items per stager lane
+    static constexpr int RC32 = (XROWS + 31) / 32;           // staged rows in 32-row chunks: a half-wave = one chunk of one channel quad
+    static constexpr int NIT = (C / 8) * RC32 / 4;           // (32-row chunk, channel quad pair) items per stager wave
     static constexpr int NG = KW * KS;                       // (tap, k step) groups per conv
     static constexpr int GROUP_BYTES = 3 * 1024;             // three splits of one 32 x 16 tap fragment
     static constexpr int CONV_BYTES = NG * RB * GROUP_BYTES;
     static constexpr int R_BYTES = C * N1 * 4 + 16;          // the io buffer (+ 4 floats that take the writes of rows outside the block's own columns): residual (raw rows of the block's own columns) in, outputs out
     static constexpr int LDS_BYTES = X_BYTES + T_BYTES + R_BYTES;
-    static_assert((C / 4) * XRP % 256 == 0, "");
+    static_assert((C / 8) * RC32 % 4 == 0, "the items must divide over the four stager waves");
+    static_assert(4 * NIT + 8 <= 56, "memory operations in flight per stager wave (6-bit counter)");
     static_assert(LDS_BYTES <= 163840, "LDS budget");
     static_assert((ROWB / 16) % 2 == 1, "row stride must be an odd multiple of 16 bytes");
 };
@@ -128,7 +129,7 @@ template <int KW, int C, int DBG = 0>
 __global__ void __launch_bounds__(RBF_NTH) __attribute__((amdgpu_waves_per_eu(2, 2)))
 resblock_bf_kernel(const RbfParams p) {
     using GM = RbfGeom<KW, C>;
-    constexpr int KS = GM::KS, RB = GM::RB, N1 = GM::N1, H2 = GM::H2, BN = GM::BN, ROWB = GM::ROWB, NIT = GM::NIT, XRP = GM::XRP;
+    constexpr int KS = GM::KS, RB = GM::RB, N1 = GM::N1, H2 = GM::H2, BN = GM::BN, ROWB = GM::ROWB, NIT = GM::NIT;
     constexpr int NG = GM::NG, PA = 4;   // (a ring of six: no change, measured)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
@@ -165,14 +166,14 @@ resblock_bf_kernel(const RbfParams p) {
         // hundred instructions per tile sit on the block's critical path (the barriers), so it gets the issue slots first.
         __builtin_amdgcn_s_setprio(1);
         const int ht = tid - 256, sw = wave - 4;
-        // C = 32: two tiles in flight (tile i waits in set i & 1).  C = 64: one -- 48 registers per set, and its shortest conv1
-        // (three taps: 6 500 cycles with its epilogue) still covers an HBM round trip
+        // C = 32: two tiles in flight (tile i waits in set i & 1).  C >= 64: one -- 40-48 registers per set, and the shortest conv1
+        // there (three taps at 64 channels: 6 500 cycles with its epilogue) still covers an HBM round trip
         constexpr int NSET = C == 32 ? 2 : 1;
         float xr[NSET][NIT][4];
-        // item i of this wave = (channel quad q, 64-row chunk rc) with sw * NIT + i = q * RC + rc: q and rc are wave-uniform (scalar
-        // registers), a lane's row is rc * 64 + lane
-        constexpr int RC = XRP / 64;
-        static_assert((C / 4) * RC == 4 * NIT, "");
+        // item i of this wave = (channel quad pair qp, 32-row chunk rc) with sw * NIT + i = qp * RC + rc: qp and rc are wave-uniform
+        // (scalar registers); the lower half-wave takes quad 2 qp, the upper one quad 2 qp + 1, a lane's row is rc * 32 + (lane & 31)
+        constexpr int RC = GM::RC32;
+        const int lq = lane >> 5;
         auto x_issue = [&](auto SET, int tl) __attribute__((always_inline)) {
             constexpr int st = decltype(SET)::value;
             const int bb = tl / p.tiles_per_row;
@@ -183,8 +184,8 @@ resblock_bf_kernel(const RbfParams p) {
             asm volatile("" : "+s"(sw_o));                    // per item) instead of being hoisted out of the tile loop and spilled (333 of them)
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
-                const int wi = sw_o * NIT + i, q = wi / RC, rc = wi - q * RC;
-                const int r = rc * 64 + lane;
+                const int wi = sw_o * NIT + i, qp = wi / RC, rc = wi - qp * RC;
+                const int q = 2 * qp + lq, r = rc * 32 + l31;
                 const unsigned tg = (unsigned)(xt0 + r);                                    // negative or beyond the row: >= L as unsigned
                 const bool ok = r < XR && tg < Lu;
                 const unsigned base = (unsigned)(4 * q) * L4 + tg * 4u;
@@ -201,8 +202,8 @@ resblock_bf_kernel(const RbfParams p) {
             asm volatile("" : "+s"(sw_o));
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
-                const int wi = sw_o * NIT + i, q = wi / RC, rc = wi - q * RC;
-                const int r = rc * 64 + lane;
+                const int wi = sw_o * NIT + i, qp = wi / RC, rc = wi - qp * RC;
+                const int q = 2 * qp + lq, r = rc * 32 + l31;
                 unsigned w[2][3];
 #pragma unroll
                 for (int e2 = 0; e2 < 2; ++e2) {
@@ -326,7 +327,7 @@ resblock_bf_kernel(const RbfParams p) {
     }
 
     // ================================================ compute waves ==========================================================
-    const int rb = RB == 1 ? 0 : (wave & 1), cg = RB == 1 ? wave : (wave >> 1);
+    const int rb = wave % RB, cg = wave / RB;
     const int col0 = cg * 64;
     float bias1[16], bias2[16];
 #pragma unroll
@@ -480,7 +481,7 @@ bool resblock_bf_enabled() {
 }
 
 bool resblock_bf_supported(int c, int k, int dil) {
-    return (c == 32 || c == 64) && (k == 3 || k == 7 || k == 11) && dil >= 1 && dil <= 5;
+    return ((c == 32 || c == 64) && (k == 3 || k == 7 || k == 11) || (c == 128 && (k == 3 || k == 7))) && dil >= 1 && dil <= 5;
 }
 
 // Where the decoder takes this kernel (profiles/r05_rbf_shapes.txt, us per pair at the cfg-2 lengths, against the two launches it
@@ -492,7 +493,7 @@ bool resblock_bf_preferred(int c, int k) {
     static const int all = knob("RVC_RBF_ALL", 0);
     if (all) return true;
 #endif
-    return c == 32 || (c == 64 && k != 11);
+    return c == 32 || (c == 64 && k != 11) || (c == 128 && k == 3);
 }
 
 bool resblock_bf_fits(int c, int64_t L) { return (int64_t)c * L * 4 < ((int64_t)1 << 31); }
@@ -574,6 +575,7 @@ int launch_resblock_bf(const float *x, const void *u, const float *b1, const flo
 #define RVC_RBF_CASE(KW, CC) if (k == KW && c == CC) return rbf_launch<KW, CC>(p, batch, stream)
     RVC_RBF_CASE(3, 32); RVC_RBF_CASE(7, 32); RVC_RBF_CASE(11, 32);
     RVC_RBF_CASE(3, 64); RVC_RBF_CASE(7, 64); RVC_RBF_CASE(11, 64);
+    RVC_RBF_CASE(3, 128); RVC_RBF_CASE(7, 128);
 #undef RVC_RBF_CASE
     return fail("resblock_bf: unsupported shape c=%d k=%d", c, k);
 }
@@ -584,7 +586,7 @@ using namespace rvc;
 
 extern "C" int rvc_resblock_bf16x3_weight_bytes(int c, int k, size_t *bytes) {
     if (!bytes) return fail("rvc_resblock_bf16x3_weight_bytes: null pointer");
-    if (!resblock_bf_supported(c, k, 1)) return fail("rvc_resblock_bf16x3_weight_bytes: c must be 32 or 64, k 3, 7 or 11");
+    if (!resblock_bf_supported(c, k, 1)) return fail("rvc_resblock_bf16x3_weight_bytes: c must be 32 or 64 with k 3, 7 or 11, or 128 with k 3 or 7");
     *bytes = resblock_bf_weight_bytes(c, k);
     return 0;
 }

@@ -364,7 +364,8 @@ int rvc_conv1d_winobf_forward(const float *x_dev, const void *u_dev, const float
  *     y = out_scale * (conv2(leaky(conv1_d(leaky(x)) + b1)) + b2 + x [+ acc])
  * Direct form on the bf16 matrix cores, every fp32 operand (taps, activations, the intermediate) split exactly into three
  * bf16 and the six products of order <= 2^-16 accumulated in fp32 (csrc/resblock_bf.hip); the intermediate stays in LDS.
- * C in {32, 64}, K in {3, 7, 11}, dilation 1..5 (conv2's is 1), leaky slope in [0, 1], C * L * 4 < 2^31; x and y must not alias.
+ * C in {32, 64} with K in {3, 7, 11}, or C = 128 with K in {3, 7}; dilation 1..5 (conv2's is 1), leaky slope in [0, 1],
+ * C * L * 4 < 2^31; x and y must not alias.
  * u_dev: rvc_resblock_bf16x3_weight_bytes() bytes filled by rvc_resblock_bf16x3_pack_weight from the two [C][C][K] host weights.
  * Persistent: one 8-wave workgroup per CU that requests the CU's whole LDS (the rule for every bf16 matrix kernel here). */
 int rvc_resblock_bf16x3_weight_bytes(int c, int k, size_t *bytes);

@@ -125,7 +125,8 @@ def test_conv1d_winograd_bf16x3_matches_float64(native, dev, c_in, c_out, k, dil
     (32, 11, 1, 2051, 1), (32, 11, 3, 9999, 1), (32, 11, 5, 513, 2), (32, 11, 5, 31, 1), (32, 3, 1, 5, 1), (32, 7, 5, 244, 1),
     (64, 3, 1, 4096, 1), (64, 3, 5, 777, 2), (64, 7, 1, 5003, 1), (64, 7, 3, 1234, 1), (64, 11, 1, 2051, 1), (64, 11, 5, 9999, 2),
     (64, 11, 3, 117, 1), (64, 7, 5, 50, 1),
-    (32, 7, 3, 1535040, 1), (32, 11, 5, 1535040, 1), (64, 7, 1, 767520, 1), (64, 3, 5, 767520, 1),   # the benchmarked stage shapes
+    (128, 3, 1, 4096, 1), (128, 3, 3, 1237, 2), (128, 3, 5, 61, 1), (128, 7, 1, 2051, 1), (128, 7, 5, 777, 1),
+    (32, 7, 3, 1535040, 1), (32, 11, 5, 1535040, 1), (64, 7, 1, 767520, 1), (64, 3, 5, 767520, 1), (128, 3, 3, 383760, 1),   # the benchmarked stage shapes
 ])
 def test_resblock_pair_bf16x3_matches_float64(native, dev, c, k, dil, length, batch):
     """resblock_bf.hip (K3f): one (dilated conv -> conv) pair of ResBlock.forward (residuals.py:75-86) in one launch, direct form on

@@ -9,14 +9,15 @@ import torch
 from rvc_amd import _native
 dev = "cuda:0"
 only = int(os.environ.get("BENCH_C", "0"))
-for C, L in ((32, 1535040), (64, 767520)):
+for C, L in ((32, 1535040), (64, 767520), (128, 383760)):
     if only and C != only: continue
     x = torch.randn(1, C, L, device=dev); bias = torch.zeros(C, device=dev)
     t1 = torch.empty_like(x); y = torch.empty_like(x)
     for K in tuple(int(k) for k in os.environ.get("BENCH_K", "3,7,11").split(",")):
+        if C == 128 and K == 11: continue
         w1 = torch.randn(C, C, K) * 0.03; w2 = torch.randn(C, C, K) * 0.03
         up = _native.resblock_bf16x3_pack_weight(w1, w2, dev)
-        bf = C >= 64 and K != 3
+        bf = (C >= 64 and K != 3) or C >= 128
         pk = _native.conv1d_winobf_pack_weight if bf else _native.conv1d_wino_pack_weight
         fw = _native.conv1d_winobf_forward if bf else _native.conv1d_wino_forward
         u1, u2 = pk(w1, dev), pk(w2, dev)
