@@ -1,0 +1,338 @@
+// K12 -- the GEMMs of HuBERT's transformer layers (q/k/v, attention output, feed-forward 1 / 2; 1599 frames x 768..3072) on the bf16
+// matrix cores with fp32-exact operands, BOTH operands arriving pre-split:
+//
+//   y[n][m] = epilogue( sum_k W[m][k] * x[n][k] )            W: nn.Linear weight [out][in], x: activations [frames][in]
+//
+// Same arithmetic as gemmbf.hip (every fp32 operand = three bf16, six products of order <= 2^-16, fp32 accumulate), but where
+// gemmbf.hip fetches fp32 activations and splits them between its matrix instructions -- 2.0 us per 16-deep step of a 128 x 256
+// block, 36 % of the matrix pipe, and at 1599 columns a grid that fills half the chip: slower than hipBLASLt on every HuBERT
+// projection -- this kernel's main loop contains NOTHING but LDS-DMA issue, fragment reads and matrix instructions:
+//   * the producer of an activation writes it as three bf16 planes [split][frame][feature] next to (or instead of) its fp32 form:
+//     the LayerNorm pass below, this kernel's own GELU epilogue, rvc_split_rows_bf16x3 behind the attention;
+//   * a B fragment (8 consecutive features of one frame) is 16 contiguous bytes of a plane, so a 64-frame x 8-feature piece goes
+//     HBM/L2 -> LDS by ONE buffer_load ... lds with per-lane row addresses, straight into the layout the matrix instruction reads;
+//   * weights: gemmbf.hip's fragment slab (rvc_gemm_bf16x3_pack_weight), streamed the same way;
+//   * 8 waves, 128 x 128 blocks, chunks of two 16-deep steps = 48 1 KiB pieces, requested two chunks ahead, one barrier per chunk.
+// The grid is made to fill the chip per projection (1599 frames = 13 tiles of 128):
+//   q/k/v   768 -> 2304  18 x 13 = 234 blocks                fp32 out + bias
+//   out     768 ->  768  6 x 13, K in 3 parts = 234 blocks   fp32 partial sums
+//   ff1     768 -> 3072  24 x 13 = 312 blocks                bias + GELU -> three bf16 planes
+//   ff2    3072 ->  768  6 x 13, K in 3 parts = 234 blocks   fp32 partial sums
+// and the partial sums meet in rvc_bias_residual_layernorm_bf16x3: sum of the parts + bias + residual -> LayerNorm -> fp32 AND the
+// three planes the next GEMM reads (one pass over 1599 x 768 instead of the reference graph's add + layer_norm + a split pass).
+// Replaces: the nn.Linear / LayerNorm / GELU modules of `transformers`' HubertEncoderLayer behind rvc/infer/pipeline.py:450.
+#include <stdlib.h>
+
+#include <mutex>
+#include <vector>
+
+#include "conv.h"
+
+namespace rvc {
+
+struct LinBfParams {
+    const void *a = nullptr;         // gemmbf.hip's fragment slab [M / 128][K / 16][4][3][1 KiB]
+    const void *xs = nullptr;        // [3][n_pad][K] bf16
+    const float *bias = nullptr;     // [M] or null (modes 0, 1)
+    float *y = nullptr;              // mode 0: [N][M] fp32; mode 2: [parts][N][M] fp32
+    void *ys = nullptr;              // mode 1: [3][n_pad][M] bf16
+    int M = 0, K = 0;
+    int64_t N = 0, n_pad = 0;
+    int mode = 0;                    // 0: y = acc + bias; 1: ys = split3(gelu(acc + bias)); 2: y[part] = acc
+    int steps_per_part = 0;          // 16-deep steps per K part
+    int n_col_blocks = 0;
+};
+
+constexpr int LBF_BM = 128, LBF_BN = 128, LBF_NTH = 512;
+constexpr int LBF_A_STEP = 12 * 1024;                    // one 16-deep step of the weights: [32-row block 4][split 3][1 KiB]
+constexpr int LBF_A_RING = 6;                            // steps
+constexpr int LBF_B_CHUNK = 3 * LBF_BN * 64;             // TWO steps of the activations: [split 3][row 128][32 features = 64 bytes]
+constexpr int LBF_B_RING = 3;                            // chunks
+constexpr int LBF_LDS_USED = LBF_A_RING * LBF_A_STEP + LBF_B_RING * LBF_B_CHUNK;
+static_assert(LBF_LDS_USED <= 163840, "");
+typedef float lbf_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 lbf_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 lbf_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned lbf_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned lbf_u32x4 __attribute__((ext_vector_type(4)));
+typedef void __attribute__((address_space(3))) *lbf_lptr_t;
+
+// Block = 128 output features x 128 frames, 8 waves (2 x 4) of 64 x 32.  The K loop runs in chunks of two 16-deep steps: per chunk
+// every wave issues six 1 KiB LDS-DMA pieces (24 weight fragments + 24 activation pieces of 16 frames x 64 contiguous bytes) two
+// chunks ahead, reads 18 fragments, issues 24 matrix instructions, and meets the others at one barrier.
+// Activation pieces: a frame's 32 features of a chunk are 64 contiguous bytes of a plane (half a cache line), fetched by four lanes;
+// the four 16-byte segments of a row land XOR-swizzled by (row >> 2) & 3, so the 16 lanes of a ds_read_b128 group -- 16 consecutive
+// frames, same segment -- hit 16 different bank quads.  (First form: one lane per frame and 16-deep step, 64 different cache lines
+// per DMA instruction: 1.5-2.3 us per step, slower than hipBLASLt on every projection.)
+__global__ void __launch_bounds__(LBF_NTH) __attribute__((amdgpu_waves_per_eu(2, 2)))
+linbf_kernel(const LinBfParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lbf_smem[];
+    unsigned char *const a_ring = lbf_smem;
+    unsigned char *const b_ring = lbf_smem + LBF_A_RING * LBF_A_STEP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __builtin_assume(wave >= 0 && wave < 8);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int half = lane >> 5, l31 = lane & 31;
+    // Block b runs on XCD b % 8: XCD x takes the contiguous range [x S, (x + 1) S) of the (column tile, row block) pairs, S = ceil(pairs
+    // / 8) -- consecutive pairs share a column tile, so its activations are fetched into that XCD's L2 once.  (Giving an XCD WHOLE
+    // column tiles -- 13 tiles over 8 XCDs -- left five XCDs with 36 blocks for their 32 CUs and three with 18: two rounds.)
+    const int n_m = p.M / LBF_BM;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pairs = p.n_col_blocks * n_m, per_xcd = (pairs + 7) / 8;
+    const int w = xcd * per_xcd + slot;
+    if (slot >= per_xcd || w >= pairs) return;
+    const int col_blk = w / n_m, mblk = w - col_blk * n_m, part = blockIdx.y;
+    const int m0 = mblk * LBF_BM;
+    const int64_t n0 = (int64_t)col_blk * LBF_BN;
+    const int n_chunks = p.steps_per_part / 2, s_first = part * p.steps_per_part;
+    const int K = p.K;
+
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void *)p.a, 0, (int)((int64_t)p.M * K * 6), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.xs, 0, (int)(3 * p.n_pad * K * 2), 0x00020000);
+    const int a_base = mblk * (K / 16) * LBF_A_STEP;
+    const int plane = (int)(p.n_pad * K * 2);
+    // activation piece: lane = (row r of 16, LDS segment j of 4); it fetches the row's segment j ^ ((row >> 2) & 3)
+    const int b_r = lane >> 2, b_j = lane & 3;
+    // chunk c of this block's K part: 48 pieces, six per wave (pieces 0..23: the two steps' weight fragments; 24..47: activations)
+    auto dma = [&](int c) __attribute__((always_inline)) {
+        const int sg = s_first + 2 * c;                         // first global step of the chunk
+        unsigned char *bslot = b_ring + (c % LBF_B_RING) * LBF_B_CHUNK;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int pc = wave + 8 * i;
+            if (pc < 24) {
+                const int st = pc / 12, f = pc - st * 12;
+                unsigned char *aslot = a_ring + ((2 * c + st) % LBF_A_RING) * LBF_A_STEP;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lbf_lptr_t)(aslot + f * 1024), 16, 16 * lane, a_base + (sg + st) * LBF_A_STEP + f * 1024, 0, 0);
+            } else {
+                const int q = pc - 24, sp = q >> 3, r16 = q & 7;
+                const int row = r16 * 16 + b_r;
+                const int seg = b_j ^ ((row >> 2) & 3);
+                const int voff = (int)((n0 + row) * K * 2) + seg * 16;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lbf_lptr_t)(bslot + sp * (LBF_BN * 64) + r16 * 1024), 16, voff, sp * plane + sg * 32, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+    auto rd = [&](const unsigned char *ptr) __attribute__((always_inline)) {
+        return __builtin_bit_cast(lbf_bf16x8, *reinterpret_cast<const lbf_u32x4 *>(ptr));
+    };
+    const int nrow = wn * 32 + l31;                           // this lane's frame inside the tile
+    const int b_lane = nrow * 64, b_sw = (nrow >> 2) & 3;
+
+    dma(0);
+    if (n_chunks > 1) dma(1);
+    if (n_chunks > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // chunk 0 has landed (chunk 1 may be in flight)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    for (int c = 0; c < n_chunks; ++c) {
+        if (c + 2 < n_chunks) dma(c + 2);                  // into the slots every wave finished reading before the last barrier
+        const unsigned char *bslot = b_ring + (c % LBF_B_RING) * LBF_B_CHUNK + b_lane;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const unsigned char *ab = a_ring + ((2 * c + t) % LBF_A_RING) * LBF_A_STEP + wm * 2 * 3 * 1024 + lane * 16;
+            lbf_bf16x8 fa[2][3], fb[3];
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) fb[sp] = rd(bslot + sp * (LBF_BN * 64) + (((2 * t + half) ^ b_sw) * 16));
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) fa[mi][sp] = rd(ab + (mi * 3 + sp) * 1024);
+            constexpr int ia[6] = {2, 0, 1, 1, 0, 0}, ib[6] = {0, 2, 1, 0, 1, 0};   // small terms first
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][ia[i]], fb[ib[i]], acc[mi], 0, 0, 0);
+        }
+        // everything older than chunk c + 2's pieces has landed: chunk c + 1 is in LDS
+        if (c + 2 < n_chunks) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+    }
+
+    // ---- epilogue: lane (frame n, features 4 half + 8 rg + 0..3 of each 32-row block) ------------------------------------------
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int64_t n = n0 + nrow;
+        if (n >= p.N) continue;
+        const int mb = m0 + wm * 64 + mi * 32 + 4 * half;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int m = mb + 8 * rg;
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = acc[mi][4 * rg + r];
+            if (p.mode == 2) {
+                *reinterpret_cast<f32x4 *>(p.y + ((int64_t)part * p.N + n) * p.M + m) = o;
+                continue;
+            }
+            if (p.bias) o += *reinterpret_cast<const f32x4 *>(p.bias + m);
+            if (p.mode == 0) {
+                *reinterpret_cast<f32x4 *>(p.y + n * p.M + m) = o;
+                continue;
+            }
+            // GELU (erf form, what torch.nn.functional.gelu computes), then the exact three-way split of the four values
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = 0.5f * o[r] * (1.f + erff(o[r] * 0.70710678118654752f));
+            lbf_f32x2 v0 = {o[0], o[1]}, v1 = {o[2], o[3]};
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) {
+                const unsigned w0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, lbf_bf16x2));
+                const unsigned w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, lbf_bf16x2));
+                *reinterpret_cast<lbf_u32x2 *>(reinterpret_cast<unsigned char *>(p.ys) + (((int64_t)sp * p.n_pad + n) * p.M + m) * 2) = lbf_u32x2{w0, w1};
+                v0 = v0 - lbf_f32x2{__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u)};
+                v1 = v1 - lbf_f32x2{__uint_as_float(w1 << 16), __uint_as_float(w1 & 0xffff0000u)};
+            }
+        }
+    }
+}
+
+// fp32 rows -> three bf16 planes (the exact split); one thread = four consecutive features
+__global__ void __launch_bounds__(256) split_rows_kernel(const float *__restrict__ x, unsigned char *__restrict__ xs, int64_t n_rows,
+                                                          int64_t n_pad, int k) {
+    const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total4 = n_rows * k / 4;
+    if (i4 >= total4) return;
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(x + i4 * 4);
+    lbf_f32x2 v0 = {v.x, v.y}, v1 = {v.z, v.w};
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp) {
+        const unsigned w0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, lbf_bf16x2));
+        const unsigned w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, lbf_bf16x2));
+        *reinterpret_cast<lbf_u32x2 *>(xs + ((int64_t)sp * n_pad * k + i4 * 4) * 2) = lbf_u32x2{w0, w1};
+        v0 = v0 - lbf_f32x2{__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u)};
+        v1 = v1 - lbf_f32x2{__uint_as_float(w1 << 16), __uint_as_float(w1 & 0xffff0000u)};
+    }
+}
+
+// one wave per row: v = sum of the K parts + bias + residual; LayerNorm over the row (two passes in registers, fp32 like
+// torch.nn.functional.layer_norm); fp32 out and the three planes
+template <int PER_LANE>   // M = 64 * PER_LANE, PER_LANE a multiple of 4
+__global__ void __launch_bounds__(256) ln_reduce_kernel(const float *__restrict__ parts, int n_parts, const float *__restrict__ bias,
+                                                         const float *__restrict__ res, const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta, float eps, float *__restrict__ y,
+                                                         unsigned char *__restrict__ ys, int64_t n_rows, int64_t n_pad) {
+    constexpr int M = 64 * PER_LANE, Q = PER_LANE / 4;
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_rows) return;
+    f32x4 v[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int m = (q * 64 + lane) * 4;
+        f32x4 a = bias ? *reinterpret_cast<const f32x4 *>(bias + m) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < n_parts; ++s) a += *reinterpret_cast<const f32x4 *>(parts + ((int64_t)s * n_rows + n) * M + m);
+        if (res) a += *reinterpret_cast<const f32x4 *>(res + n * M + m);
+        v[q] = a;
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) sum += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum * (1.f / M);
+    float sq = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const f32x4 d = v[q] - mean;
+        sq += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    const float rstd = 1.f / sqrtf(sq * (1.f / M) + eps);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int m = (q * 64 + lane) * 4;
+        f32x4 o = (v[q] - mean) * rstd;
+        if (gamma) o *= *reinterpret_cast<const f32x4 *>(gamma + m);
+        if (beta) o += *reinterpret_cast<const f32x4 *>(beta + m);
+        if (y) *reinterpret_cast<f32x4 *>(y + n * M + m) = o;
+        if (ys) {
+            lbf_f32x2 v0 = {o.x, o.y}, v1 = {o.z, o.w};
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) {
+                const unsigned w0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, lbf_bf16x2));
+                const unsigned w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, lbf_bf16x2));
+                *reinterpret_cast<lbf_u32x2 *>(ys + (((int64_t)sp * n_pad + n) * M + m) * 2) = lbf_u32x2{w0, w1};
+                v0 = v0 - lbf_f32x2{__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u)};
+                v1 = v1 - lbf_f32x2{__uint_as_float(w1 << 16), __uint_as_float(w1 & 0xffff0000u)};
+            }
+        }
+    }
+}
+
+static int linbf_launch(LinBfParams p, int parts, hipStream_t stream) {
+    static std::once_flag once;
+    static hipError_t err = hipSuccess;
+    std::call_once(once, [] { err = hipFuncSetAttribute((const void *)linbf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU); });
+    if (err != hipSuccess) return fail("linear bf16x3 (pre-split): cannot reserve %d bytes of LDS: %s", LDS_WHOLE_CU, hipGetErrorString(err));
+    p.n_col_blocks = (int)ceil_div(p.N, LBF_BN);
+    const int n_m = p.M / LBF_BM;
+    dim3 grid((unsigned)(ceil_div((int64_t)p.n_col_blocks * n_m, 8) * 8), (unsigned)parts, 1);
+    hipLaunchKernelGGL(linbf_kernel, grid, dim3(LBF_NTH), LDS_WHOLE_CU, stream, p);   // owns its CU (common.h)
+    RVC_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace rvc
+
+using namespace rvc;
+
+extern "C" int rvc_split_rows_bf16x3(const float *x_dev, void *xs_dev, int64_t n_rows, int64_t n_rows_padded, int k, void *stream) {
+    if (!x_dev || !xs_dev) return fail("rvc_split_rows_bf16x3: null pointer");
+    if (k % 16 || n_rows_padded < n_rows || n_rows < 0) return fail("rvc_split_rows_bf16x3: k must be a multiple of 16, n_rows_padded >= n_rows");
+    if (n_rows == 0) return 0;
+    const int64_t total4 = n_rows * k / 4;
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, (hipStream_t)stream, x_dev,
+                       reinterpret_cast<unsigned char *>(xs_dev), n_rows, n_rows_padded, k);
+    RVC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rvc_linear_bf16x3_presplit(const void *xs_dev, const void *a_dev, const float *bias_dev, float *y_dev, void *ys_dev,
+                                          int64_t n_rows, int64_t n_rows_padded, int in_features, int out_features, int mode, int k_parts,
+                                          void *stream) {
+    if (!xs_dev || !a_dev) return fail("rvc_linear_bf16x3_presplit: null pointer");
+    if (out_features % LBF_BM || in_features % 16) return fail("rvc_linear_bf16x3_presplit: out_features must be a multiple of 128, in_features of 16");
+    if (mode < 0 || mode > 2) return fail("rvc_linear_bf16x3_presplit: mode must be 0 (fp32 + bias), 1 (bias + GELU -> planes) or 2 (partial sums)");
+    if ((mode == 1) ? !ys_dev : !y_dev) return fail("rvc_linear_bf16x3_presplit: the output of mode %d is missing", mode);
+    if (k_parts < 1 || (in_features / 32) % k_parts || in_features % 32) return fail("rvc_linear_bf16x3_presplit: in_features must be a multiple of 32 and k_parts divide in_features / 32");
+    if (k_parts > 1 && mode != 2) return fail("rvc_linear_bf16x3_presplit: several K parts only produce partial sums (mode 2)");
+    if (n_rows_padded % LBF_BN || n_rows_padded < n_rows) return fail("rvc_linear_bf16x3_presplit: n_rows_padded must be a multiple of 128 and >= n_rows");
+    if ((int64_t)out_features * in_features * 6 >= ((int64_t)1 << 31) || 3 * n_rows_padded * in_features * 2 >= ((int64_t)1 << 31))
+        return fail("rvc_linear_bf16x3_presplit: an operand exceeds 2 GiB");
+    if (n_rows <= 0) return 0;
+    LinBfParams p;
+    p.a = a_dev; p.xs = xs_dev; p.bias = bias_dev; p.y = y_dev; p.ys = ys_dev;
+    p.M = out_features; p.K = in_features; p.N = n_rows; p.n_pad = n_rows_padded; p.mode = mode;
+    p.steps_per_part = in_features / 16 / k_parts;
+    return linbf_launch(p, k_parts, (hipStream_t)stream);
+}
+
+extern "C" int rvc_bias_residual_layernorm_bf16x3(const float *parts_dev, int n_parts, const float *bias_dev, const float *res_dev,
+                                                  const float *gamma_dev, const float *beta_dev, float eps, float *y_dev, void *ys_dev,
+                                                  int64_t n_rows, int64_t n_rows_padded, int features, void *stream) {
+    if (!parts_dev || (!y_dev && !ys_dev)) return fail("rvc_bias_residual_layernorm_bf16x3: null pointer");
+    if (n_parts < 1 || n_rows_padded < n_rows) return fail("rvc_bias_residual_layernorm_bf16x3: bad argument");
+    if (n_rows <= 0) return 0;
+    dim3 grid((unsigned)ceil_div(n_rows, 4));
+    unsigned char *ys = reinterpret_cast<unsigned char *>(ys_dev);
+    hipStream_t st = (hipStream_t)stream;
+    if (features == 768)
+        hipLaunchKernelGGL(ln_reduce_kernel<12>, grid, dim3(256), 0, st, parts_dev, n_parts, bias_dev, res_dev, gamma_dev, beta_dev, eps, y_dev, ys, n_rows, n_rows_padded);
+    else if (features == 1024)
+        hipLaunchKernelGGL(ln_reduce_kernel<16>, grid, dim3(256), 0, st, parts_dev, n_parts, bias_dev, res_dev, gamma_dev, beta_dev, eps, y_dev, ys, n_rows, n_rows_padded);
+    else if (features == 256)
+        hipLaunchKernelGGL(ln_reduce_kernel<4>, grid, dim3(256), 0, st, parts_dev, n_parts, bias_dev, res_dev, gamma_dev, beta_dev, eps, y_dev, ys, n_rows, n_rows_padded);
+    else
+        return fail("rvc_bias_residual_layernorm_bf16x3: features must be 256, 768 or 1024 (HuBERT-base: 768)");
+    RVC_LAUNCH_CHECK();
+    return 0;
+}

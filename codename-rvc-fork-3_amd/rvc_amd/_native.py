@@ -113,6 +113,11 @@ SYMBOLS = {
     "rvc_linear_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "rvc_conv1d_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_int, c_int,
                                   c_void_p]),
+    "rvc_split_rows_bf16x3": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "rvc_linear_bf16x3_presplit": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
+                                           c_void_p]),
+    "rvc_bias_residual_layernorm_bf16x3": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                                   c_int64, c_int64, c_int, c_void_p]),
     "rvc_conv2d_packed_floats": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
     "rvc_conv2d_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rvc_conv2d_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
@@ -632,6 +637,58 @@ def linear_bf16x3(x: torch.Tensor, a_packed: torch.Tensor, bias, out_features: i
                                   res.data_ptr() if res is not None else None, y.data_ptr(), n_rows, in_features, out_features,
                                   {"none": 0, "gelu": 1}[act], _stream()), "rvc_linear_bf16x3")
     return y
+
+
+# ---- K12: HuBERT's transformer GEMMs with both operands pre-split (csrc/linbf.hip) ---------------------------------------
+def rows_padded(n_rows: int, tile: int = 128) -> int:
+    return -(-n_rows // tile) * tile
+
+
+def planes_empty(n_rows: int, features: int, device) -> torch.Tensor:
+    """Uninitialised [3][rows_padded][features] bf16 planes (the padding rows are never read into a stored result)."""
+    return torch.empty((3, rows_padded(n_rows), features), dtype=torch.bfloat16, device=device)
+
+
+def split_rows_bf16x3(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """fp32 [n_rows, k] -> three bf16 planes whose sum is x exactly."""
+    x = _dev_f32(x, "x")
+    n_rows, k = x.shape
+    xs = out if out is not None else planes_empty(n_rows, k, x.device)
+    _check(_lib.rvc_split_rows_bf16x3(x.data_ptr(), xs.data_ptr(), n_rows, xs.shape[1], k, _stream()), "rvc_split_rows_bf16x3")
+    return xs
+
+
+def linear_bf16x3_presplit(xs: torch.Tensor, a_packed: torch.Tensor, bias, n_rows: int, out_features: int, mode: str = "f32",
+                           k_parts: int = 1, out: torch.Tensor | None = None) -> torch.Tensor:
+    """mode "f32": y [n_rows, out] = x W^T + b; "gelu_planes": planes of gelu(x W^T + b); "parts": [k_parts, n_rows, out] partial sums."""
+    _, n_pad, in_features = xs.shape
+    m = {"f32": 0, "gelu_planes": 1, "parts": 2}[mode]
+    if m == 0:
+        y = out if out is not None else torch.empty((n_rows, out_features), dtype=torch.float32, device=xs.device)
+    elif m == 1:
+        y = out if out is not None else planes_empty(n_rows, out_features, xs.device)
+    else:
+        y = out if out is not None else torch.empty((k_parts, n_rows, out_features), dtype=torch.float32, device=xs.device)
+    _check(_lib.rvc_linear_bf16x3_presplit(xs.data_ptr(), a_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                           y.data_ptr() if m != 1 else None, y.data_ptr() if m == 1 else None, n_rows, n_pad,
+                                           in_features, out_features, m, k_parts, _stream()), "rvc_linear_bf16x3_presplit")
+    return y
+
+
+def bias_residual_layernorm_bf16x3(parts: torch.Tensor, bias, res, gamma, beta, eps: float, want_planes: bool = True,
+                                   y: torch.Tensor | None = None, ys: torch.Tensor | None = None):
+    """LayerNorm(sum(parts) + bias + res) -> (fp32 [n_rows, m], planes or None)."""
+    n_parts, n_rows, m = parts.shape
+    y = y if y is not None else torch.empty((n_rows, m), dtype=torch.float32, device=parts.device)
+    if want_planes and ys is None:
+        ys = planes_empty(n_rows, m, parts.device)
+    _check(_lib.rvc_bias_residual_layernorm_bf16x3(parts.data_ptr(), n_parts, bias.data_ptr() if bias is not None else None,
+                                                   res.data_ptr() if res is not None else None,
+                                                   gamma.data_ptr() if gamma is not None else None,
+                                                   beta.data_ptr() if beta is not None else None, float(eps), y.data_ptr(),
+                                                   ys.data_ptr() if ys is not None else None, n_rows, ys.shape[1] if ys is not None else n_rows,
+                                                   m, _stream()), "rvc_bias_residual_layernorm_bf16x3")
+    return y, ys
 
 
 def conv1d_bf16x3(x: torch.Tensor, a_packed: torch.Tensor, bias, c_out: int, k: int, stride: int = 1, padding: int = 0,

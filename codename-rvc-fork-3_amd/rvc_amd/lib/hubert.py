@@ -5,9 +5,9 @@ subclass) at its one call site ``model(feats)["last_hidden_state"]`` (rvc/infer/
 and the v1-only ``model.final_proj`` (:451-453).  No ``transformers`` import: the network is
 restated functionally over a state dict in transformers naming, weight-norm of
 the positional conv folded once at load.  On the device the feature-extractor convs 0-3 run in
-librvc_amd's K11 (gemmbf.hip) and the attention in K7b (attention.hip), both as exact bf16x3 splits
-on the bf16 matrix cores; everything stays fp32-valued (README.md:22).  CPU tensors (host-logic
-tests only) take plain torch ops.
+librvc_amd's K11 (gemmbf.hip), the attention in K7b (attention.hip) and the transformer layers'
+projections + LayerNorms in K12 (linbf.hip), all as exact bf16x3 splits on the bf16 matrix cores;
+everything stays fp32-valued (README.md:22).  CPU tensors (host-logic tests only) take plain torch ops.
 """
 from __future__ import annotations
 
@@ -50,6 +50,7 @@ class HubertModelWithFinalProj:
                 cw = self.w[f"feature_extractor.conv_layers.{i}.conv.weight"]
                 if cw.shape[0] % 128 == 0 and (cw.shape[1] % 16 == 0 or (cw.shape[1] == 1 and cw.shape[2] <= 16)):
                     self._conv_bf[i] = _native.gemm_bf16x3_pack_weight(cw, self.device)
+        self._lin = {}   # K12: fragment slabs of the four projections of every layer (device only)
         self._qkv = {}
         for i in range(self.n_layers):
             L = f"encoder.layers.{i}.attention"
@@ -60,13 +61,33 @@ class HubertModelWithFinalProj:
                                        self.w[L + ".v_proj.weight"]], 0).contiguous(),
                             torch.cat([self.w[L + ".q_proj.bias"], self.w[L + ".k_proj.bias"],
                                        self.w[L + ".v_proj.bias"]], 0).contiguous(), scale)
+        self._pack_linears()
         return self
+
+    def _pack_linears(self):
+        """K12 (linbf.hip) takes the nn.Linear weights as bf16x3 matrix-instruction fragments: q/k/v (fused), attention output,
+        feed-forward 1 / 2 of every layer -- 42 MB per layer for HuBERT-base.  Shapes the kernel does not take (output features not
+        a multiple of 128, input features not a multiple of 96 = 32 x 3 K parts) leave the layer on the library GEMMs."""
+        self._lin = {}
+        if self.device.type != "cuda":
+            return
+        from rvc_amd import _native
+        for i in range(self.n_layers):
+            L = f"encoder.layers.{i}"
+            ws = [self._qkv[i][0], self.w[L + ".attention.out_proj.weight"], self.w[L + ".feed_forward.intermediate_dense.weight"],
+                  self.w[L + ".feed_forward.output_dense.weight"]]
+            d = ws[1].shape[0]
+            if any(w.shape[0] % 128 or w.shape[1] % 96 for w in ws) or d not in (256, 768, 1024):
+                self._lin = {}
+                return
+            self._lin[i] = [_native.gemm_bf16x3_pack_weight(w, self.device) for w in ws]
 
     def to(self, device):
         self.device = torch.device(device)
         self.w = {k: v.to(self.device) for k, v in self.w.items()}
         self._qkv = {i: (a.to(self.device), b.to(self.device), s) for i, (a, b, s) in self._qkv.items()}
         self._conv_bf = {i: a.to(self.device) for i, a in self._conv_bf.items()} if self.device.type == "cuda" else {}
+        self._pack_linears()
         return self
 
     def float(self):
@@ -112,6 +133,8 @@ class HubertModelWithFinalProj:
         b, t, _ = x.shape
         h = self.n_heads
         hd = d // h
+        if x.is_cuda and self._lin:
+            return {"last_hidden_state": self._encoder_native(x, b, t, d, h)}
         for i in range(self.n_layers):
             L = f"encoder.layers.{i}"
             if self.consume_layerdrop_rng:
@@ -131,3 +154,36 @@ class HubertModelWithFinalProj:
             f = F.linear(f, w[L + ".feed_forward.output_dense.weight"], w[L + ".feed_forward.output_dense.bias"])
             x = F.layer_norm(x + f, (d,), w[L + ".final_layer_norm.weight"], w[L + ".final_layer_norm.bias"], 1e-5)
         return {"last_hidden_state": x}
+
+    def _encoder_native(self, x, b, t, d, h):
+        """The twelve post-LN transformer layers (transformers' HubertEncoderLayer) in librvc_amd: activations travel as fp32 rows
+        AND as three bf16 planes (their exact split); per layer K12 q/k/v -> K7b attention -> split -> K12 out (K in 3 parts) ->
+        fused sum + bias + residual + LayerNorm (+ split) -> K12 ff1 + GELU (-> planes) -> K12 ff2 (3 parts) -> fused LayerNorm."""
+        from rvc_amd import _native as N
+        w = self.w
+        n = b * t
+        x = x.reshape(n, d).contiguous()
+        xs = N.split_rows_bf16x3(x)
+        a_s = N.planes_empty(n, d, x.device)
+        d_ff = w["encoder.layers.0.feed_forward.intermediate_dense.weight"].shape[0]
+        fs = N.planes_empty(n, d_ff, x.device)
+        parts = torch.empty((3, n, d), dtype=torch.float32, device=x.device)
+        qkv = torch.empty((n, 3 * d), dtype=torch.float32, device=x.device)
+        x1, x1s = torch.empty_like(x), N.planes_empty(n, d, x.device)
+        for i in range(self.n_layers):
+            L = f"encoder.layers.{i}"
+            if self.consume_layerdrop_rng:
+                torch.rand([])
+            a_qkv, a_o, a_1, a_2 = self._lin[i]
+            _, bqkv, scale = self._qkv[i]
+            N.linear_bf16x3_presplit(xs, a_qkv, bqkv, n, 3 * d, "f32", out=qkv)
+            a = N.attention_qkv(qkv.view(b, t, 3 * d), h, scale)
+            N.split_rows_bf16x3(a.view(n, d), out=a_s)
+            N.linear_bf16x3_presplit(a_s, a_o, None, n, d, "parts", 3, out=parts)
+            N.bias_residual_layernorm_bf16x3(parts, w[L + ".attention.out_proj.bias"], x, w[L + ".layer_norm.weight"],
+                                             w[L + ".layer_norm.bias"], 1e-5, y=x1, ys=x1s)
+            N.linear_bf16x3_presplit(x1s, a_1, w[L + ".feed_forward.intermediate_dense.bias"], n, d_ff, "gelu_planes", out=fs)
+            N.linear_bf16x3_presplit(fs, a_2, None, n, d, "parts", 3, out=parts)
+            N.bias_residual_layernorm_bf16x3(parts, w[L + ".feed_forward.output_dense.bias"], x1, w[L + ".final_layer_norm.weight"],
+                                             w[L + ".final_layer_norm.bias"], 1e-5, y=x, ys=xs)
+        return x.view(b, t, d)

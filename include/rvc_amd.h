@@ -394,6 +394,29 @@ int rvc_linear_bf16x3(const float *x_dev, const void *a_dev, const float *bias_d
 int rvc_conv1d_bf16x3(const float *x_dev, const void *a_dev, const float *bias_dev, float *y_dev, int batch, int c_in,
                       int c_out, int64_t l_in, int k, int stride, int padding, int act, void *stream);
 
+/* ---- K12: the GEMMs of HuBERT's transformer layers with BOTH operands pre-split ------------------------------------------------ *
+ * Replaces the nn.Linear / LayerNorm / GELU modules of `transformers`' HubertEncoderLayer (q/k/v, attention output, feed-forward)
+ * behind rvc/infer/pipeline.py:450.  Same exact bf16x3 arithmetic as K11; the activations arrive as three bf16 planes
+ * [split][n_rows_padded][features] (their sum is the fp32 value exactly), so the kernel's main loop is LDS-DMA + matrix
+ * instructions only (csrc/linbf.hip).  Rows n_rows .. n_rows_padded - 1 of a plane are never read into a stored result and
+ * never written: they need no initialisation.
+ * rvc_split_rows_bf16x3: fp32 [n_rows][k] -> planes.
+ * rvc_linear_bf16x3_presplit: a_dev = rvc_gemm_bf16x3_pack_weight's slab of the [out][in] weight.  mode 0: y_dev [n_rows][out]
+ *   = x W^T + bias; mode 1: ys_dev planes [3][n_rows_padded][out] of gelu(x W^T + bias) (erf form); mode 2: y_dev
+ *   [k_parts][n_rows][out] partial sums over k_parts equal slices of in_features (no bias) -- the grid filler for the 768-wide
+ *   outputs.  in_features a multiple of 32 (and of 32 k_parts), n_rows_padded a multiple of 128.  One 8-wave workgroup per CU, whole LDS.
+ * rvc_bias_residual_layernorm_bf16x3: y = LayerNorm(sum of the parts + bias + res) * gamma + beta over `features` (256, 768 or 1024),
+ *   written as fp32 (y_dev, may be NULL) and as planes (ys_dev, may be NULL): HubertEncoderLayer's `hidden = layer_norm(hidden +
+ *   dropout(attn))` / `final_layer_norm(hidden + feed_forward(hidden))` fused with the split-K reduction. */
+int rvc_split_rows_bf16x3(const float *x_dev, void *xs_dev, int64_t n_rows, int64_t n_rows_padded, int k, void *stream);
+int rvc_linear_bf16x3_presplit(const void *xs_dev, const void *a_dev, const float *bias_dev, float *y_dev, void *ys_dev,
+                               int64_t n_rows, int64_t n_rows_padded, int in_features, int out_features, int mode, int k_parts,
+                               void *stream);
+int rvc_bias_residual_layernorm_bf16x3(const float *parts_dev, int n_parts, const float *bias_dev, const float *res_dev,
+                                       const float *gamma_dev, const float *beta_dev, float eps, float *y_dev, void *ys_dev,
+                                       int64_t n_rows, int64_t n_rows_padded, int features, void *stream);
+
+
 #ifdef __cplusplus
 }
 #endif

@@ -166,6 +166,52 @@ def test_resblock_pair_bf16x3_matches_float64(native, dev, c, k, dil, length, ba
     assert torch.equal(again, plain)                      # bit-reproducible
 
 
+@pytest.mark.parametrize("n_rows,k,m,mode,k_parts", [
+    (1599, 768, 2304, "f32", 1), (1599, 768, 768, "parts", 3), (1599, 768, 3072, "gelu_planes", 1),
+    (1599, 3072, 768, "parts", 3), (149, 768, 768, "parts", 6), (1, 768, 2304, "f32", 1), (300, 256, 256, "parts", 2),
+    (4797, 768, 3072, "gelu_planes", 1), (257, 3072, 768, "f32", 1), (130, 64, 256, "parts", 1), (128, 32, 128, "f32", 1),
+])
+def test_linear_bf16x3_presplit_matches_float64(native, dev, n_rows, k, m, mode, k_parts):
+    """linbf.hip (K12): HuBERT's transformer projections (attention q/k/v + out, feed-forward; `transformers` HubertEncoderLayer behind
+    pipeline.py:450) with both operands pre-split into three bf16: plain, GELU -> planes, and split-K partial sums meeting in the
+    fused bias + residual + LayerNorm pass.  Against float64; gate and error level as the K11 test (2e-5 of the largest value,
+    relative RMS at torch's fp32 level).  Ragged row counts (1599 = 6.2 tiles of 256), a single row, three stacked utterances."""
+    g = torch.Generator().manual_seed(n_rows + k + m)
+    x = torch.randn(n_rows, k, generator=g)
+    w = torch.randn(m, k, generator=g) * k ** -0.5
+    b = torch.randn(m, generator=g)
+    xd = x.to(dev)
+    xs = native.split_rows_bf16x3(xd)
+    back = xs[:, :n_rows].float().sum(0)                       # bf16 planes: exact in fp32, and their fp32 sum is exact (24 bits)
+    assert torch.equal(back, xd), "the three planes do not sum to the fp32 input"
+    a = native.gemm_bf16x3_pack_weight(w, dev)
+    ref = x.double() @ w.double().t() + b.double()
+    lib = F.linear(xd, w.to(dev), b.to(dev)).cpu()
+    rel = lambda t, r: ((t.double() - r).pow(2).mean().sqrt() / r.pow(2).mean().sqrt()).item()
+    if mode == "f32":
+        got = native.linear_bf16x3_presplit(xs, a, b.to(dev), n_rows, m, "f32", 1).cpu()
+        assert (got.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+        assert rel(got, ref) <= max(1.5 * rel(lib, ref), 4e-7), (rel(got, ref), rel(lib, ref))
+    elif mode == "gelu_planes":
+        ys = native.linear_bf16x3_presplit(xs, a, b.to(dev), n_rows, m, "gelu_planes", 1)
+        got = ys[:, :n_rows].float().sum(0).cpu()
+        refg = F.gelu(ref)
+        assert (got.double() - refg).abs().max().item() <= 2e-5 * refg.abs().max().item()
+        assert rel(got, refg) <= max(1.5 * rel(F.gelu(lib), refg), 3e-7)
+    else:
+        parts = native.linear_bf16x3_presplit(xs, a, None, n_rows, m, "parts", k_parts)
+        res = torch.randn(n_rows, m, generator=g)
+        gamma, beta = torch.randn(m, generator=g), torch.randn(m, generator=g)
+        y, ys = native.bias_residual_layernorm_bf16x3(parts, b.to(dev), res.to(dev), gamma.to(dev), beta.to(dev), 1e-5)
+        refl = F.layer_norm(ref + res.double(), (m,), gamma.double(), beta.double(), 1e-5)
+        libl = F.layer_norm(lib.to(dev) + res.to(dev), (m,), gamma.to(dev), beta.to(dev), 1e-5).cpu()
+        assert (y.cpu().double() - refl).abs().max().item() <= 2e-5 * refl.abs().max().item()
+        assert rel(y.cpu(), refl) <= max(1.5 * rel(libl, refl), 3e-7)
+        assert torch.equal(ys[:, :n_rows].float().sum(0), y)    # the planes are the fp32 output, split exactly
+        plain = parts.sum(0).cpu() + b
+        assert (plain.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("n_rows,k,m,act,with_res", [
     (1599, 768, 2304, "none", False), (1599, 768, 768, "none", True), (1599, 768, 3072, "gelu", False),
     (1599, 3072, 768, "none", True), (149, 768, 768, "gelu", True), (1, 512, 768, "none", False), (130, 16, 128, "none", False),

@@ -25,9 +25,24 @@ for name, k, m, act in (("qkv", 768, 2304, "none"), ("out_proj", 768, 768, "none
     a = _native.gemm_bf16x3_pack_weight(w, dev)
     lib = timed(lambda: F.gelu(F.linear(x, w, b)) if act == "gelu" else F.linear(x, w, b))
     own = timed(lambda: _native.linear_bf16x3(x, a, b, m, act=act))
+    xs = _native.split_rows_bf16x3(x)
+    mode, parts = {"qkv": ("f32", 1), "out_proj": ("parts", 3), "ff1+gelu": ("gelu_planes", 1), "ff2": ("parts", 3)}[name]
+    parts = int(os.environ.get("K_PARTS", parts)) if mode == "parts" else 1
+    buf = _native.linear_bf16x3_presplit(xs, a, b if mode != "parts" else None, T, m, mode, parts)
+    pre = timed(lambda: _native.linear_bf16x3_presplit(xs, a, b if mode != "parts" else None, T, m, mode, parts, out=buf))
+    extra = ""
+    if mode == "parts":
+        res = torch.randn(T, m, device=dev); gam = torch.ones(m, device=dev)
+        y, ys = _native.bias_residual_layernorm_bf16x3(buf, b, res, gam, gam, 1e-5)
+        ln = timed(lambda: _native.bias_residual_layernorm_bf16x3(buf, b, res, gam, gam, 1e-5, y=y, ys=ys))
+        lnlib = timed(lambda: F.layer_norm(res + x[:, :m] if k >= m else res, (m,), gam, gam, 1e-5))
+        extra = f" + fused reduce/bias/residual/LayerNorm/split {ln*1e3:5.1f} us (torch add + layer_norm {lnlib*1e3:5.1f})"
     gf = 2.0 * T * k * m / 1e9
+    print(f"linear {name:9s} {T} x {k:4d} -> {m:4d}: pre-split K12 ({mode}, {parts} K part(s)) {pre*1e3:7.1f} us ({gf/pre:6.1f} TF/s fp32-equivalent, "
+          f"{6*gf/pre:7.1f} TF/s on the bf16 pipe) x{lib/pre:.2f} vs torch{extra}", flush=True)
     print(f"linear {name:9s} {T} x {k:4d} -> {m:4d}: torch fp32 {lib*1e3:7.1f} us ({gf/lib:6.1f} TF/s) | bf16x3 {own*1e3:7.1f} us ({gf/own:6.1f} TF/s fp32-equivalent, "
           f"{6*gf/own:7.1f} TF/s on the bf16 pipe) x{lib/own:.2f}", flush=True)
+if os.environ.get('LINEAR_ONLY'): sys.exit(0)
 L = 102399
 for i, (k, s) in enumerate(((3, 2), (3, 2), (3, 2), (3, 2), (2, 2), (2, 2))):
     x = torch.randn(1, 512, L, device=dev); w = torch.randn(512, 512, k, device=dev) * (512 * k) ** -0.5
