@@ -108,7 +108,7 @@ struct RbfGeom {
     static constexpr int R_BYTES = C * N1 * 4 + 16;          // the io buffer (+ 4 floats that take the writes of rows outside the block's own columns): residual (raw rows of the block's own columns) in, outputs out
     static constexpr int LDS_BYTES = X_BYTES + T_BYTES + R_BYTES;
     static_assert((C / 8) * RC32 % 4 == 0, "the items must divide over the four stager waves");
-    static_assert(4 * NIT + 8 <= 56, "memory operations in flight per stager wave (6-bit counter)");
+    static_assert(4 * NIT + 8 <= 56, "memory operations in flight per stager wave (kept below the 6-bit counter's range: see the stager's prologue)");
     static_assert(LDS_BYTES <= 163840, "LDS budget");
     static_assert((ROWB / 16) % 2 == 1, "row stride must be an odd multiple of 16 bytes");
 };
@@ -285,9 +285,11 @@ resblock_bf_kernel(const RbfParams p) {
         // rows N1 .. TROWS-1 of the t tile are read by masked output columns only and never written: give them a value once
         for (int o = ht * 16; o < (KW - 1) * ROWB; o += 256 * 16) *reinterpret_cast<rb_u32x4 *>(ts + N1 * ROWB + o) = rb_u32x4{0u, 0u, 0u, 0u};
         // Tile i + 2 is requested behind barrier D of tile i and written behind barrier B of tile i + 1: a whole tile between request
-        // and use.  Never more than one set + 8 stores in flight: with two sets of a 64-channel tile -- 96 loads -- in flight at once
-        // in the prologue, the second tile of a block came out wrong on a few blocks per launch (more outstanding memory operations
-        // than the 6-bit counter counts; profiles/r05_rbf_notes.txt).
+        // and use.  Never more than one set + 8 stores in flight per wave, and tile 0 is written before tile 1 is requested: with the
+        // prologue order (request 0, request 1, write 0) -- 96 loads in flight at C = 64 -- the SECOND tile of 4-18 blocks per launch
+        // came out wrong in its last columns (errors ~1e-2, non-deterministic; profiles/r05_rbf_notes.txt).  The cause was not
+        // isolated: a bare wave with 120 loads in flight reads correct data (tools/micro/vmcnt_burst.hip), so it is not the 6-bit
+        // counter by itself.  The order below passed every repetition since.
         constexpr std::integral_constant<int, 0> S0{};
         constexpr std::integral_constant<int, NSET - 1> SL{};   // the "other" set (the same one when there is only one)
         x_issue(S0, tile);
