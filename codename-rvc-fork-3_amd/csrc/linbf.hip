@@ -43,13 +43,9 @@ struct LinBfParams {
     int n_col_blocks = 0;
 };
 
-constexpr int LBF_BM = 128, LBF_BN = 128, LBF_NTH = 512;
-constexpr int LBF_A_STEP = 12 * 1024;                    // one 16-deep step of the weights: [32-row block 4][split 3][1 KiB]
-constexpr int LBF_A_RING = 6;                            // steps
+constexpr int LBF_BN = 128, LBF_NTH = 512;
+constexpr int LBF_SLAB_STEP = 12 * 1024;                 // one 16-deep step of a 128-row block of the weight slab: [32-row block 4][split 3][1 KiB]
 constexpr int LBF_B_CHUNK = 3 * LBF_BN * 64;             // TWO steps of the activations: [split 3][row 128][32 features = 64 bytes]
-constexpr int LBF_B_RING = 3;                            // chunks
-constexpr int LBF_LDS_USED = LBF_A_RING * LBF_A_STEP + LBF_B_RING * LBF_B_CHUNK;
-static_assert(LBF_LDS_USED <= 163840, "");
 typedef float lbf_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 lbf_bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 lbf_bf16x8 __attribute__((ext_vector_type(8)));
@@ -57,18 +53,36 @@ typedef unsigned lbf_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned lbf_u32x4 __attribute__((ext_vector_type(4)));
 typedef void __attribute__((address_space(3))) *lbf_lptr_t;
 
-// Block = 128 output features x 128 frames, 8 waves (2 x 4) of 64 x 32.  The K loop runs in chunks of two 16-deep steps: per chunk
-// every wave issues six 1 KiB LDS-DMA pieces (24 weight fragments + 24 activation pieces of 16 frames x 64 contiguous bytes) two
-// chunks ahead, reads 18 fragments, issues 24 matrix instructions, and meets the others at one barrier.
+// MI = 32-row blocks per wave: 2 -> 128 output features per block, chunks requested two ahead; 3 -> 192 per block (16 x 13 = 208
+// blocks for the 3072-wide feed-forward instead of 24 x 13 = 312 on 256 CUs), chunks requested one ahead (LDS: 18 KiB of weights
+// per step).
+template <int MI>
+struct LbfGeom {
+    static constexpr int BM = 64 * MI;
+    static constexpr int A_STEP = 2 * MI * 3 * 1024;     // [32-row block 2 MI][split 3][1 KiB]
+    static constexpr int D = MI == 2 ? 2 : 1;            // chunks in flight ahead of the one being multiplied
+    static constexpr int A_RING = 2 * (D + 1), B_RING = D + 1;
+    static constexpr int NPIECE = 2 * 2 * MI * 3 + 24;   // 1 KiB pieces per chunk: two steps of weights + the activation chunk
+    static constexpr int UPW = (NPIECE + 7) / 8;         // per wave (the overhang repeats one of the wave's own pieces)
+    static constexpr int LDS_USED = A_RING * A_STEP + B_RING * LBF_B_CHUNK;
+    static_assert(LDS_USED <= 163840, "");
+};
+
+// Block = 64 MI output features x 128 frames, 8 waves (2 x 4) of 32 MI x 32.  The K loop runs in chunks of two 16-deep steps: per
+// chunk every wave issues its share of the chunk's 1 KiB LDS-DMA pieces (weight fragments + 24 activation pieces of 16 frames x 64
+// contiguous bytes) D chunks ahead, reads 6 (MI + 1) fragments, issues 12 MI matrix instructions, and meets the others at one barrier.
 // Activation pieces: a frame's 32 features of a chunk are 64 contiguous bytes of a plane (half a cache line), fetched by four lanes;
 // the four 16-byte segments of a row land XOR-swizzled by (row >> 2) & 3, so the 16 lanes of a ds_read_b128 group -- 16 consecutive
 // frames, same segment -- hit 16 different bank quads.  (First form: one lane per frame and 16-deep step, 64 different cache lines
 // per DMA instruction: 1.5-2.3 us per step, slower than hipBLASLt on every projection.)
+template <int MI>
 __global__ void __launch_bounds__(LBF_NTH) __attribute__((amdgpu_waves_per_eu(2, 2)))
 linbf_kernel(const LinBfParams p) {
+    using GM = LbfGeom<MI>;
+    constexpr int BM = GM::BM, A_STEP = GM::A_STEP, D = GM::D, A_RING = GM::A_RING, B_RING = GM::B_RING, NPIECE = GM::NPIECE, UPW = GM::UPW;
     extern __shared__ __attribute__((aligned(16))) unsigned char lbf_smem[];
     unsigned char *const a_ring = lbf_smem;
-    unsigned char *const b_ring = lbf_smem + LBF_A_RING * LBF_A_STEP;
+    unsigned char *const b_ring = lbf_smem + A_RING * A_STEP;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     __builtin_assume(wave >= 0 && wave < 8);
@@ -77,36 +91,39 @@ linbf_kernel(const LinBfParams p) {
     // Block b runs on XCD b % 8: XCD x takes the contiguous range [x S, (x + 1) S) of the (column tile, row block) pairs, S = ceil(pairs
     // / 8) -- consecutive pairs share a column tile, so its activations are fetched into that XCD's L2 once.  (Giving an XCD WHOLE
     // column tiles -- 13 tiles over 8 XCDs -- left five XCDs with 36 blocks for their 32 CUs and three with 18: two rounds.)
-    const int n_m = p.M / LBF_BM;
+    const int n_m = p.M / BM;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int pairs = p.n_col_blocks * n_m, per_xcd = (pairs + 7) / 8;
     const int w = xcd * per_xcd + slot;
     if (slot >= per_xcd || w >= pairs) return;
     const int col_blk = w / n_m, mblk = w - col_blk * n_m, part = blockIdx.y;
-    const int m0 = mblk * LBF_BM;
+    const int m0 = mblk * BM;
     const int64_t n0 = (int64_t)col_blk * LBF_BN;
     const int n_chunks = p.steps_per_part / 2, s_first = part * p.steps_per_part;
     const int K = p.K;
 
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void *)p.a, 0, (int)((int64_t)p.M * K * 6), 0x00020000);
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.xs, 0, (int)(3 * p.n_pad * K * 2), 0x00020000);
-    const int a_base = mblk * (K / 16) * LBF_A_STEP;
+    const int slab_row = (K / 16) * LBF_SLAB_STEP;           // bytes of one 128-row block of the slab
     const int plane = (int)(p.n_pad * K * 2);
     // activation piece: lane = (row r of 16, LDS segment j of 4); it fetches the row's segment j ^ ((row >> 2) & 3)
     const int b_r = lane >> 2, b_j = lane & 3;
-    // chunk c of this block's K part: 48 pieces, six per wave (pieces 0..23: the two steps' weight fragments; 24..47: activations)
+    // chunk c of this block's K part: pieces 0 .. 12 MI - 1: the two steps' weight fragments; then 24 activation pieces
     auto dma = [&](int c) __attribute__((always_inline)) {
         const int sg = s_first + 2 * c;                         // first global step of the chunk
-        unsigned char *bslot = b_ring + (c % LBF_B_RING) * LBF_B_CHUNK;
+        unsigned char *bslot = b_ring + (c % B_RING) * LBF_B_CHUNK;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int pc = wave + 8 * i;
-            if (pc < 24) {
-                const int st = pc / 12, f = pc - st * 12;
-                unsigned char *aslot = a_ring + ((2 * c + st) % LBF_A_RING) * LBF_A_STEP;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lbf_lptr_t)(aslot + f * 1024), 16, 16 * lane, a_base + (sg + st) * LBF_A_STEP + f * 1024, 0, 0);
+        for (int i = 0; i < UPW; ++i) {
+            int pc = wave + 8 * i;
+            if (pc >= NPIECE) pc -= 8;                          // same bytes to the same place
+            if (pc < 12 * MI) {
+                const int st = pc / (6 * MI), f = pc - st * (6 * MI);     // step of the chunk, fragment (32-row block, split)
+                const int rb = (m0 >> 5) + f / 3, sp = f - (f / 3) * 3;   // global 32-row block
+                unsigned char *aslot = a_ring + ((2 * c + st) % A_RING) * A_STEP;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lbf_lptr_t)(aslot + f * 1024), 16, 16 * lane,
+                                                         (rb >> 2) * slab_row + (sg + st) * LBF_SLAB_STEP + ((rb & 3) * 3 + sp) * 1024, 0, 0);
             } else {
-                const int q = pc - 24, sp = q >> 3, r16 = q & 7;
+                const int q = pc - 12 * MI, sp = q >> 3, r16 = q & 7;
                 const int row = r16 * 16 + b_r;
                 const int seg = b_j ^ ((row >> 2) & 3);
                 const int voff = (int)((n0 + row) * K * 2) + seg * 16;
@@ -115,9 +132,9 @@ linbf_kernel(const LinBfParams p) {
         }
     };
 
-    f32x16 acc[2];
+    f32x16 acc[MI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
     auto rd = [&](const unsigned char *ptr) __attribute__((always_inline)) {
@@ -126,43 +143,49 @@ linbf_kernel(const LinBfParams p) {
     const int nrow = wn * 32 + l31;                           // this lane's frame inside the tile
     const int b_lane = nrow * 64, b_sw = (nrow >> 2) & 3;
 
-    dma(0);
-    if (n_chunks > 1) dma(1);
-    if (n_chunks > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // chunk 0 has landed (chunk 1 may be in flight)
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Chunks are requested D ahead into a ring of D + 1: chunk c + D goes into the slots chunk c - 1 left at the last barrier.
+    auto wait_newer = [&](int newer) __attribute__((always_inline)) {   // everything but the `newer` most recent chunk requests has landed
+        if (newer >= 1 && D >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    static_assert(D <= 2, "wait_newer distinguishes 0 and 1 newer requests");
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+        if (c < n_chunks) dma(c);
+    wait_newer((n_chunks - 1 < D - 1) ? n_chunks - 1 : D - 1);
     lds_barrier();
     for (int c = 0; c < n_chunks; ++c) {
-        if (c + 2 < n_chunks) dma(c + 2);                  // into the slots every wave finished reading before the last barrier
-        const unsigned char *bslot = b_ring + (c % LBF_B_RING) * LBF_B_CHUNK + b_lane;
+        if (c + D < n_chunks) dma(c + D);
+        const unsigned char *bslot = b_ring + (c % B_RING) * LBF_B_CHUNK + b_lane;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const unsigned char *ab = a_ring + ((2 * c + t) % LBF_A_RING) * LBF_A_STEP + wm * 2 * 3 * 1024 + lane * 16;
-            lbf_bf16x8 fa[2][3], fb[3];
+            const unsigned char *ab = a_ring + ((2 * c + t) % A_RING) * A_STEP + wm * MI * 3 * 1024 + lane * 16;
+            lbf_bf16x8 fa[MI][3], fb[3];
 #pragma unroll
             for (int sp = 0; sp < 3; ++sp) fb[sp] = rd(bslot + sp * (LBF_BN * 64) + (((2 * t + half) ^ b_sw) * 16));
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int sp = 0; sp < 3; ++sp) fa[mi][sp] = rd(ab + (mi * 3 + sp) * 1024);
             constexpr int ia[6] = {2, 0, 1, 1, 0, 0}, ib[6] = {0, 2, 1, 0, 1, 0};   // small terms first
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
                     acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][ia[i]], fb[ib[i]], acc[mi], 0, 0, 0);
         }
-        // everything older than chunk c + 2's pieces has landed: chunk c + 1 is in LDS
-        if (c + 2 < n_chunks) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // chunk c + 1 has landed (requests of chunks c + 2 .. c + D may stay in flight); one barrier says that to every wave and frees chunk c's slots
+        const int newer = (n_chunks - 2 - c) < (D - 1) ? (n_chunks - 2 - c) : (D - 1);
+        wait_newer(newer);
         lds_barrier();
     }
 
     // ---- epilogue: lane (frame n, features 4 half + 8 rg + 0..3 of each 32-row block) ------------------------------------------
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
         const int64_t n = n0 + nrow;
         if (n >= p.N) continue;
-        const int mb = m0 + wm * 64 + mi * 32 + 4 * half;
+        const int mb = m0 + wm * 32 * MI + mi * 32 + 4 * half;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             const int m = mb + 8 * rg;
@@ -268,15 +291,16 @@ __global__ void __launch_bounds__(256) ln_reduce_kernel(const float *__restrict_
     }
 }
 
+template <int MI>
 static int linbf_launch(LinBfParams p, int parts, hipStream_t stream) {
     static std::once_flag once;
     static hipError_t err = hipSuccess;
-    std::call_once(once, [] { err = hipFuncSetAttribute((const void *)linbf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU); });
+    std::call_once(once, [] { err = hipFuncSetAttribute((const void *)linbf_kernel<MI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU); });
     if (err != hipSuccess) return fail("linear bf16x3 (pre-split): cannot reserve %d bytes of LDS: %s", LDS_WHOLE_CU, hipGetErrorString(err));
     p.n_col_blocks = (int)ceil_div(p.N, LBF_BN);
-    const int n_m = p.M / LBF_BM;
+    const int n_m = p.M / LbfGeom<MI>::BM;
     dim3 grid((unsigned)(ceil_div((int64_t)p.n_col_blocks * n_m, 8) * 8), (unsigned)parts, 1);
-    hipLaunchKernelGGL(linbf_kernel, grid, dim3(LBF_NTH), LDS_WHOLE_CU, stream, p);   // owns its CU (common.h)
+    hipLaunchKernelGGL(linbf_kernel<MI>, grid, dim3(LBF_NTH), LDS_WHOLE_CU, stream, p);   // owns its CU (common.h)
     RVC_LAUNCH_CHECK();
     return 0;
 }
@@ -300,7 +324,7 @@ extern "C" int rvc_linear_bf16x3_presplit(const void *xs_dev, const void *a_dev,
                                           int64_t n_rows, int64_t n_rows_padded, int in_features, int out_features, int mode, int k_parts,
                                           void *stream) {
     if (!xs_dev || !a_dev) return fail("rvc_linear_bf16x3_presplit: null pointer");
-    if (out_features % LBF_BM || in_features % 16) return fail("rvc_linear_bf16x3_presplit: out_features must be a multiple of 128, in_features of 16");
+    if (out_features % 128 || in_features % 16) return fail("rvc_linear_bf16x3_presplit: out_features must be a multiple of 128, in_features of 16");
     if (mode < 0 || mode > 2) return fail("rvc_linear_bf16x3_presplit: mode must be 0 (fp32 + bias), 1 (bias + GELU -> planes) or 2 (partial sums)");
     if ((mode == 1) ? !ys_dev : !y_dev) return fail("rvc_linear_bf16x3_presplit: the output of mode %d is missing", mode);
     if (k_parts < 1 || (in_features / 32) % k_parts || in_features % 32) return fail("rvc_linear_bf16x3_presplit: in_features must be a multiple of 32 and k_parts divide in_features / 32");
@@ -313,7 +337,14 @@ extern "C" int rvc_linear_bf16x3_presplit(const void *xs_dev, const void *a_dev,
     p.a = a_dev; p.xs = xs_dev; p.bias = bias_dev; p.y = y_dev; p.ys = ys_dev;
     p.M = out_features; p.K = in_features; p.N = n_rows; p.n_pad = n_rows_padded; p.mode = mode;
     p.steps_per_part = in_features / 16 / k_parts;
-    return linbf_launch(p, k_parts, (hipStream_t)stream);
+    // 192-row blocks where they fill the chip better in one round than 128-row blocks do (HuBERT's 3072-wide feed-forward at 1599
+    // frames: 208 blocks against 312 for 256 CUs)
+    const int64_t cols = ceil_div(n_rows, LBF_BN);
+    const int64_t b128 = cols * (out_features / 128) * k_parts, b192 = out_features % 192 == 0 ? cols * (out_features / 192) * k_parts : 0;
+    const int cus = 256;
+    auto rounds = [&](int64_t b) { return (double)ceil_div(b, cus); };
+    const bool use192 = b192 > 0 && rounds(b192) * 1.5 * 0.85 < rounds(b128);   // a 192-row block works 1.5 x as long, at ~0.85 of the bytes per product
+    return use192 ? linbf_launch<3>(p, k_parts, (hipStream_t)stream) : linbf_launch<2>(p, k_parts, (hipStream_t)stream);
 }
 
 extern "C" int rvc_bias_residual_layernorm_bf16x3(const float *parts_dev, int n_parts, const float *bias_dev, const float *res_dev,
