@@ -57,7 +57,9 @@ def pmc_traffic(symbol_key, field="bytes_per_launch"):
         with open(path) as fh:
             d = json.load(fh)
         return float(d[field]), f"profiles/pmc_{symbol_key}.json: " + d.get("source", "")
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError, KeyError) as e:
+        print(f"bench.py: no PMC traffic figure for '{symbol_key}' ({path}: {type(e).__name__}); `traffic` is null -- "
+              "tools/collect_profiles_r05.sh regenerates it", file=sys.stderr)
         return None, None
 
 

@@ -38,6 +38,8 @@ struct GemmBfParams {
     int y_mode = 0;                  // 0: y[n][m] row-major (ldy); 1: y[m][n] channel-major (ldy)
     int64_t ldy = 0;
     int act = 0;                     // 0 none, 1 GELU (erf form)
+    int one_channel = 0;             // conv mode: ONE input channel, the step's 16 pseudo-channels are 16 consecutive samples (ldx is then 1
+                                     // by construction; the flag, not ldx == 1, selects the clamped path: l_in == 1 is a legal multi-channel input)
     int batch = 1;
     int64_t x_bstride = 0, y_bstride = 0;
     int n_col_blocks = 0;
@@ -124,7 +126,7 @@ gemmbf_kernel(const GemmBfParams p) {
         if constexpr (XMODE == 0) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(lx_src + 4 * e);
             xv[4 * e] = v.x; xv[4 * e + 1] = v.y; xv[4 * e + 2] = v.z; xv[4 * e + 3] = v.w;
-        } else if (p.ldx == 1) {
+        } else if (p.one_channel) {
             // one input channel: the step's 16 pseudo-channels are consecutive samples; the taps beyond k carry zero weights, so
             // the last columns' tail is clamped into x instead of being read past its end
             const int64_t at = (lx_src - x) + e;
@@ -416,7 +418,7 @@ extern "C" int rvc_conv1d_bf16x3(const float *x_dev, const void *a_dev, const fl
     p.a = a_dev; p.x = x_dev; p.y = y_dev; p.bias = bias_dev;
     p.M = c_out; p.K = k * c_in; p.c_in = c_in; p.N = l_out;
     p.x_mode = 1; p.ldx = l_in; p.l_in = l_in; p.stride = stride; p.dil = 1; p.pad = padding;
-    if (one_channel) { p.K = 16; p.c_in = 16; p.ldx = 1; }   // one tap of 16 pseudo-channels; weights beyond k are zero
+    if (one_channel) { p.K = 16; p.c_in = 16; p.ldx = 1; p.one_channel = 1; }   // one tap of 16 pseudo-channels; weights beyond k are zero
     p.y_mode = 1; p.ldy = l_out; p.act = act; p.batch = batch;
     p.x_bstride = (int64_t)c_in * l_in; p.y_bstride = (int64_t)c_out * l_out;
     return gemmbf_launch(p, (hipStream_t)stream);

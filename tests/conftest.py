@@ -81,6 +81,9 @@ def pytest_collection_finish(session):
         return
     from _oracle_farm import Farm, draw_index_on_device
     _FARM = Farm()
+    # the pytest process computes float64 / oracle references of its own on the host: keep it to a quarter of the cores while
+    # the farm's workers (6 x 32 threads) are busy, instead of torch's default of one thread per core on top of them
+    torch.set_num_threads(max(8, min(64, (os.cpu_count() or 8) // 4)))
     index_file = None
     if "peaked:cfg5" in keys:        # cfg 5's 2 M rows are drawn on the device as bench.py draws them; the worker maps the host copy
         index_file = os.path.join(_FARM.dir, "cfg5_index.npy")

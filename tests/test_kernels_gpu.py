@@ -26,6 +26,25 @@ def dev():
     return torch.device("cuda:0")
 
 
+def conv1d_f64(x, w, b=None, padding=0, dilation=1, stride=1):
+    """F.conv1d in float64, evaluated on the device as one float64 matrix product per tap (rocBLAS dgemm): the same sums as
+    F.conv1d(x.double(), w.double(), ...) on the host, which takes 20-45 s per full-length shape on the box's cores and was a
+    third of this file's run time.  Returns a float64 tensor on the host."""
+    dev0 = torch.device("cuda:0")
+    xd, wd = x.to(dev0).double(), w.to(dev0).double()
+    batch, c_in, length = xd.shape
+    c_out, _, k = wd.shape
+    xp = F.pad(xd, (padding, padding))
+    l_out = (length + 2 * padding - dilation * (k - 1) - 1) // stride + 1
+    y = torch.zeros(batch, c_out, l_out, dtype=torch.float64, device=dev0)
+    for t in range(k):
+        seg = xp[:, :, t * dilation: t * dilation + (l_out - 1) * stride + 1: stride]
+        y += torch.matmul(wd[:, :, t], seg)
+    if b is not None:
+        y += b.to(dev0).double()[None, :, None]
+    return y.cpu()
+
+
 # ---- K3 conv1d ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("c_in,c_out,k,dil,length,batch", [
     (32, 32, 3, 1, 1000, 1), (32, 32, 11, 5, 1537, 2), (64, 64, 7, 3, 700, 1), (128, 128, 11, 5, 513, 1),
@@ -47,7 +66,7 @@ def test_conv1d_matches_torch_fp32(native, dev, c_in, c_out, k, dil, length, bat
     assert err <= 2e-5, err  # fp32 fma chain vs float64 reference, |ref| ~ 1
     # plain conv: no activation, no residual
     y2 = native.conv1d_forward(x.to(dev), wp, None, c_out, k, dil, 1.0)
-    ref2 = F.conv1d(x.double(), w.double(), None, padding=(k - 1) // 2 * dil, dilation=dil)
+    ref2 = conv1d_f64(x, w, None, padding=(k - 1) // 2 * dil, dilation=dil)
     assert (y2.cpu().double() - ref2).abs().max().item() <= 2e-5
 
 
@@ -66,14 +85,14 @@ def test_conv1d_winograd_matches_float64(native, dev, c_in, c_out, k, dil, lengt
     b = torch.randn(c_out, generator=g)
     res = torch.randn(batch, c_out, length, generator=g)
     acc = torch.randn(batch, c_out, length, generator=g)
-    ref = (F.conv1d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), padding=(k - 1) // 2 * dil, dilation=dil) + res.double()
+    ref = (conv1d_f64(F.leaky_relu(x.double(), 0.1), w, b, padding=(k - 1) // 2 * dil, dilation=dil) + res.double()
            + acc.double()) / 3
     u = native.conv1d_wino_pack_weight(w, dev)
     got = native.conv1d_wino_forward(x.to(dev), u, b.to(dev), c_out, k, dil, 0.1, res=res.to(dev), acc=acc.to(dev), out_scale=1 / 3).cpu()
     err = (got.double() - ref).abs().max().item()
     assert err <= 6e-5, err                         # |y| ~ 1, up to 2816 terms: a few fp32 ulps through the transforms
     plain = native.conv1d_wino_forward(x.to(dev), u, None, c_out, k, dil, 1.0).cpu()
-    ref2 = F.conv1d(x.double(), w.double(), None, padding=(k - 1) // 2 * dil, dilation=dil)
+    ref2 = conv1d_f64(x, w, None, padding=(k - 1) // 2 * dil, dilation=dil)
     assert (plain.double() - ref2).abs().max().item() <= 6e-5
     direct = native.conv1d_forward(x.to(dev), native.conv1d_pack_weight(w, dev), None, c_out, k, dil, 1.0).cpu()
     assert (plain - direct).abs().max().item() <= 6e-5
@@ -102,13 +121,13 @@ def test_conv1d_winograd_bf16x3_matches_float64(native, dev, c_in, c_out, k, dil
     b = torch.randn(c_out, generator=g)
     res = torch.randn(batch, c_out, length, generator=g)
     acc = torch.randn(batch, c_out, length, generator=g)
-    ref = (F.conv1d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), padding=(k - 1) // 2 * dil, dilation=dil) + res.double()
+    ref = (conv1d_f64(F.leaky_relu(x.double(), 0.1), w, b, padding=(k - 1) // 2 * dil, dilation=dil) + res.double()
            + acc.double()) / 3
     u = native.conv1d_winobf_pack_weight(w, dev)
     got = native.conv1d_winobf_forward(x.to(dev), u, b.to(dev), c_out, k, dil, 0.1, res=res.to(dev), acc=acc.to(dev), out_scale=1 / 3).cpu()
     err = (got.double() - ref).abs().max().item()
     assert err <= 6e-5, err
-    ref2 = F.conv1d(x.double(), w.double(), None, padding=(k - 1) // 2 * dil, dilation=dil)
+    ref2 = conv1d_f64(x, w, None, padding=(k - 1) // 2 * dil, dilation=dil)
     plain = native.conv1d_winobf_forward(x.to(dev), u, None, c_out, k, dil, 1.0).cpu()
     assert (plain.double() - ref2).abs().max().item() <= 6e-5
     fp32w = native.conv1d_wino_forward(x.to(dev), native.conv1d_wino_pack_weight(w, dev), None, c_out, k, dil, 1.0).cpu()
@@ -142,8 +161,8 @@ def test_resblock_pair_bf16x3_matches_float64(native, dev, c, k, dil, length, ba
     acc = torch.randn(batch, c, length, generator=g)
 
     def pair64(xx, bb1, bb2):
-        t = F.conv1d(F.leaky_relu(xx.double(), 0.1), w1.double(), bb1, padding=(k - 1) // 2 * dil, dilation=dil)
-        return F.conv1d(F.leaky_relu(t, 0.1), w2.double(), bb2, padding=(k - 1) // 2) + xx.double()
+        t = conv1d_f64(F.leaky_relu(xx.double(), 0.1), w1, bb1, padding=(k - 1) // 2 * dil, dilation=dil)
+        return conv1d_f64(F.leaky_relu(t, 0.1), w2, bb2, padding=(k - 1) // 2) + xx.double()
 
     u = native.resblock_bf16x3_pack_weight(w1, w2, dev)
     xd = x.to(dev)
@@ -247,13 +266,14 @@ def test_linear_bf16x3_matches_float64(native, dev, n_rows, k, m, act, with_res)
 @pytest.mark.parametrize("c_in,c_out,k,stride,length,batch,act", [
     (512, 512, 3, 2, 5119, 1, "gelu"), (512, 512, 2, 2, 640, 2, "gelu"), (64, 128, 3, 1, 300, 1, "none"), (512, 512, 3, 2, 4, 1, "none"),
     (1, 512, 10, 5, 16000, 1, "none"), (1, 512, 10, 5, 4003, 1, "none"),      # HuBERT's first layer: one input channel, 10 taps, stride 5
+    (32, 128, 1, 1, 1, 1, "none"),                                               # l_in = 1 with several channels (not the one-channel path)
 ])
 def test_conv1d_bf16x3_matches_float64(native, dev, c_in, c_out, k, stride, length, batch, act):
     """gemmbf.hip, conv mode: HuBERT's feature-extractor convs (Conv1d(512, 512, k in {3, 2}, stride 2, no padding) + GELU)."""
     g = torch.Generator().manual_seed(c_in + c_out + k + length)
     x = torch.randn(batch, c_in, length, generator=g)
     w = torch.randn(c_out, c_in, k, generator=g) / (c_in * k) ** 0.5
-    ref = F.conv1d(x.double(), w.double(), None, stride=stride)
+    ref = conv1d_f64(x, w, None, stride=stride)
     if act == "gelu":
         ref = F.gelu(ref)
     a = native.gemm_bf16x3_pack_weight(w, dev)
@@ -599,12 +619,13 @@ def test_decoder_full_synth_golden(native, dev, ref_inputs):
     assert rms(out - g["o"]) <= 5e-5, rms(out - g["o"])
 
 
-@pytest.mark.parametrize("co", ["gemmbf", "winobf2", "knn_screen", "attention_bf"])
+@pytest.mark.parametrize("co", ["gemmbf", "winobf2", "knn_screen", "attention_bf", "resblock_bf", "linear_presplit"])
 @pytest.mark.parametrize("k,c", [(11, 128), (3, 64), (7, 32)])
 def test_fp32_winograd_next_to_the_bf16_gemm_is_bit_exact(native, dev, k, c, co):
     """Regression test of profiles/r03_mfma_cohabitation.txt / r04_mfma_cohabitation.txt: while one thread launches a kernel that
     issues bf16 / fp16 matrix instructions in a loop on its own stream -- gemmbf.hip, winobf2.hip, the kNN screening pass, HuBERT's
     bf16x3 attention -- the
+    bf16x3 attention, the fused ResBlock pair (K3f), HuBERT's pre-split projections (K12) -- the
     fp32 Winograd kernel on another stream must return bit-identical results every time.  It does because every such kernel asks
     for a CU's whole LDS (common.h: LDS_WHOLE_CU) and so never shares one; next to gemmbf's first form (two 60 KiB blocks per CU)
     300 of 300 runs of this loop came back wrong by up to 2.2."""
@@ -618,6 +639,13 @@ def test_fp32_winograd_next_to_the_bf16_gemm_is_bit_exact(native, dev, k, c, co)
         bb = torch.zeros(128, device=dev)
     if co == "attention_bf":
         qkv = (torch.randn(1, 1599, 3 * 12 * 64, generator=g) * 1.5).to(dev)
+    if co == "resblock_bf":
+        up = native.resblock_bf16x3_pack_weight(torch.randn(32, 32, 7, generator=g) * 0.03, torch.randn(32, 32, 7, generator=g) * 0.03, dev)
+        xp = torch.randn(1, 32, 400000, generator=g).to(dev)
+        yp = torch.empty_like(xp)
+    if co == "linear_presplit":
+        al = native.gemm_bf16x3_pack_weight(torch.randn(3072, 768, generator=g) * 0.03, dev)
+        xl = native.split_rows_bf16x3(torch.randn(1599, 768, generator=g).to(dev))
     if co == "knn_screen":
         index = torch.randn(50000, 768, generator=g).to(dev)
         norms = native.knn_index_norms(index)
@@ -641,6 +669,10 @@ def test_fp32_winograd_next_to_the_bf16_gemm_is_bit_exact(native, dev, k, c, co)
                     native.conv1d_winobf_forward(xb, ub, bb, 128, 11, 1, 0.1)
                 elif co == "attention_bf":
                     native.attention_qkv(qkv, 12, 0.125)
+                elif co == "resblock_bf":
+                    native.resblock_bf16x3_forward(xp, up, None, None, 7, 3, 0.1, out=yp)
+                elif co == "linear_presplit":
+                    native.linear_bf16x3_presplit(xl, al, None, 1599, 3072, "gelu_planes")
                 else:
                     native.knn_search(index, norms, q)
                 st.synchronize()

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(REPO, "tests", "_ranks_worker.py")
-N_UTT = 4
+N_UTT = 8      # both tests: the 2-rank job takes four each, the 4-rank job two each; ONE 1-rank job serves as the expected value of both
 
 
 def _run(world, out_dir, n_utt=N_UTT):
@@ -27,8 +27,14 @@ def _run(world, out_dir, n_utt=N_UTT):
     return [np.load(os.path.join(out_dir, f"rank{r}_of{world}.npz")) for r in range(world)]
 
 
-def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
-    (one,) = _run(1, tmp_path)
+@pytest.fixture(scope="module")
+def one_rank(tmp_path_factory):
+    (one,) = _run(1, tmp_path_factory.mktemp("one_rank"))
+    return one
+
+
+def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, one_rank):
+    one = one_rank
     two = _run(2, tmp_path)
     # every rank holds the root's bytes: device-side checksums equal each other and the 1-rank job's
     assert all(bool(r["agree"]) for r in two)
@@ -51,12 +57,12 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
     assert float(two[0]["t_max"]) == 2.0 and float(one["t_max"]) == 1.0
 
 
-def test_four_ranks_strided_batch_equals_one_rank(tmp_path):
+def test_four_ranks_strided_batch_equals_one_rank(tmp_path, one_rank):
     """BASELINE cfg 3's sharding at the scale one GPU allows: a batch of 8 utterances over 4 ranks (utterance i -> rank i mod 4,
     two per rank -- cfg 3 is 512 over 8, 64 per rank, the same striding), four processes sharing cuda:0 over gloo.  Every
     utterance must come out of exactly one rank and equal the 1-rank job's; all four ranks hold the root's index bytes."""
-    n = 8
-    (one,) = _run(1, tmp_path, n)
+    n = N_UTT
+    one = one_rank
     four = _run(4, tmp_path, n)
     assert all(bool(r["agree"]) for r in four)
     assert all(np.array_equal(r["checksum"], one["checksum"]) for r in four)

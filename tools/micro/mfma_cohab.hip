@@ -267,6 +267,59 @@ int main(int argc, char **argv) {
     add_wino("W11 library wino_conv_kernel, 11 taps, C = 128", 128, 11, 60000);
     add_wino("X3 library wino_conv_kernel, 3 taps, C = 64, no residual", 64, 3, 200000, false);
 
+    // ---- round 5: the library's OTHER fp32-matrix kernels as victims (verdict of round 4: only wino_conv_kernel had been tried) ----
+    auto frand = [](std::vector<float> &v, float scale) { for (auto &e : v) e = (rand() / (float)RAND_MAX - 0.5f) * scale; };
+    auto dev_copy = [](const std::vector<float> &h) { float *d; CK(hipMalloc(&d, h.size() * 4)); CK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice)); return d; };
+    {   // conv_mfma_kernel: the direct-form conv (upsamplers, conv_pre, fall-back of every ResBlock layer), 11 taps, C = 128
+        const int C = 128, K = 11; const int64_t L = 60000;
+        std::vector<float> w((size_t)C * C * K), x((size_t)C * L), b(C);
+        frand(w, 0.1f); frand(x, 2.f); frand(b, 1.f);
+        float *dx = dev_copy(x), *db = dev_copy(b), *dw, *y;
+        CK(hipMalloc(&dw, w.size() * 4)); CK(hipMalloc(&y, x.size() * 4));
+        if (rvc_conv1d_pack_weight(w.data(), C, C, K, dw, nullptr)) { fprintf(stderr, "pack: %s\n", rvc_last_error()); exit(1); }
+        victims.push_back({"D11 library conv_mfma_kernel (direct form), 11 taps, C = 128", [=](hipStream_t st) {
+            if (rvc_conv1d_forward(dx, dw, db, dx, nullptr, y, 1, C, C, L, K, 1, 0.1f, 1.f, st)) { fprintf(stderr, "conv: %s\n", rvc_last_error()); exit(1); }
+        }, y, (size_t)C * L, C});
+    }
+    {   // conv2d_mfma_kernel: an RMVPE U-Net block conv, 3 x 3, 64 -> 64 channels on a 32 x 3232 map
+        const int C = 64, H = 32, W = 3232;
+        std::vector<float> w((size_t)C * C * 9), x((size_t)C * H * W), b(C);
+        frand(w, 0.1f); frand(x, 2.f); frand(b, 1.f);
+        float *dx = dev_copy(x), *db = dev_copy(b), *dw, *y; void *ws;
+        size_t nw = 0, nws = 0;
+        if (rvc_conv2d_packed_floats(C, C, 3, 3, &nw) || rvc_conv2d_workspace_bytes(1, C, C, H, W, 3, 3, &nws)) { fprintf(stderr, "conv2d: %s\n", rvc_last_error()); exit(1); }
+        CK(hipMalloc(&dw, nw * 4)); CK(hipMalloc(&y, x.size() * 4)); CK(hipMalloc(&ws, nws ? nws : 16));
+        if (rvc_conv2d_pack_weight(w.data(), C, C, 3, 3, dw, nullptr)) { fprintf(stderr, "pack2d: %s\n", rvc_last_error()); exit(1); }
+        victims.push_back({"C2D library conv2d_mfma_kernel, 3 x 3, 64 -> 64 channels, 32 x 3232", [=](hipStream_t st) {
+            if (rvc_conv2d_forward(dx, dw, db, dx, y, 1, C, C, H, W, 3, 3, 1, ws, nws, st)) { fprintf(stderr, "conv2d: %s\n", rvc_last_error()); exit(1); }
+        }, y, (size_t)C * H * W, C});
+    }
+    {   // attention_qkv_kernel<96>: the TextEncoder's relative-position attention (fp32 matrix instruction), 2 heads x 96, 3198 frames
+        const int T = 3198, Hh = 2, D = 96;
+        std::vector<float> q((size_t)T * 3 * Hh * D), ek((size_t)21 * D), ev((size_t)21 * D);
+        frand(q, 2.f); frand(ek, 0.5f); frand(ev, 0.5f);
+        float *dq = dev_copy(q), *dk = dev_copy(ek), *dv = dev_copy(ev), *y; void *ws; size_t nws = 0;
+        if (rvc_attention_workspace_bytes(1, T, Hh, D, &nws)) { fprintf(stderr, "att: %s\n", rvc_last_error()); exit(1); }
+        CK(hipMalloc(&y, (size_t)T * Hh * D * 4)); CK(hipMalloc(&ws, nws ? nws : 16));
+        victims.push_back({"A96 library attention_qkv_kernel<96> (TextEncoder, relative positions), 3198 frames", [=](hipStream_t st) {
+            if (rvc_attention_qkv_f32(dq, dk, dv, y, 1, T, Hh, D, 0.1f, ws, nws, st)) { fprintf(stderr, "att: %s\n", rvc_last_error()); exit(1); }
+        }, y, (size_t)T * Hh * D, 0});
+    }
+    {   // knn_partial_kernel: the exact fp32 regime of the top-8 search (mode 1), 1599 queries x 50 000 rows
+        const int64_t N = 50000, Q = 1599; const int D = 768;
+        std::vector<float> idx((size_t)N * D), qs((size_t)Q * D);
+        frand(idx, 2.f); frand(qs, 2.f);
+        float *di = dev_copy(idx), *dq = dev_copy(qs), *d2; int64_t *ids; void *aux, *ws; size_t na = 0, nws = 0;
+        rvc_knn_set_mode(1);
+        if (rvc_knn_index_aux_bytes(N, D, &na) || rvc_knn_workspace_bytes(N, Q, D, 8, &nws)) { fprintf(stderr, "knn: %s\n", rvc_last_error()); exit(1); }
+        CK(hipMalloc(&aux, na)); CK(hipMalloc(&ws, nws)); CK(hipMalloc(&d2, Q * 8 * 4)); CK(hipMalloc(&ids, Q * 8 * 8));
+        if (rvc_knn_index_build(di, N, D, aux, na, nullptr)) { fprintf(stderr, "knn build: %s\n", rvc_last_error()); exit(1); }
+        CK(hipDeviceSynchronize());
+        victims.push_back({"KNN library knn_partial_kernel (exact fp32 regime), 1599 x 50 000", [=](hipStream_t st) {
+            if (rvc_knn_search(di, aux, N, D, dq, Q, 8, d2, ids, ws, nws, st)) { fprintf(stderr, "knn: %s\n", rvc_last_error()); exit(1); }
+        }, d2, (size_t)Q * 8, 0});
+    }
+
     // round 3's gemmbf_kernel<1, DBG> (HuBERT conv layer 1: 512 -> 512 channels, 3 taps, stride 2, 51 000 samples in)
     rvc_r03::GemmBfParams gp;
     {
