@@ -374,6 +374,8 @@ extern "C" int rvc_conv2d_packed_floats(int c_out, int c_in, int kh, int kw, siz
 
 extern "C" int rvc_conv2d_workspace_bytes(int batch, int c_in, int c_out, int height, int width, int kh, int kw, size_t *out) {
     if (!out) return fail("rvc_conv2d_workspace_bytes: null pointer");
+    if (width < 4 || width > 128 || (width & (width - 1)) || height <= 0 || batch <= 0 || c_in <= 0 || c_out <= 0)
+        return fail("rvc_conv2d_workspace_bytes: row length %d unsupported (a power of two in 4..128), or an empty map", width);
     *out = conv2d_workspace_bytes(batch, c_in, c_out, height, width, kh * kw);
     return 0;
 }

@@ -270,6 +270,7 @@ int main(int argc, char **argv) {
     // ---- round 5: the library's OTHER fp32-matrix kernels as victims (verdict of round 4: only wino_conv_kernel had been tried) ----
     auto frand = [](std::vector<float> &v, float scale) { for (auto &e : v) e = (rand() / (float)RAND_MAX - 0.5f) * scale; };
     auto dev_copy = [](const std::vector<float> &h) { float *d; CK(hipMalloc(&d, h.size() * 4)); CK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice)); return d; };
+    fprintf(stderr, "[setup] wino victims ready\n");
     {   // conv_mfma_kernel: the direct-form conv (upsamplers, conv_pre, fall-back of every ResBlock layer), 11 taps, C = 128
         const int C = 128, K = 11; const int64_t L = 60000;
         std::vector<float> w((size_t)C * C * K), x((size_t)C * L), b(C);
@@ -281,8 +282,9 @@ int main(int argc, char **argv) {
             if (rvc_conv1d_forward(dx, dw, db, dx, nullptr, y, 1, C, C, L, K, 1, 0.1f, 1.f, st)) { fprintf(stderr, "conv: %s\n", rvc_last_error()); exit(1); }
         }, y, (size_t)C * L, C});
     }
+    fprintf(stderr, "[setup] D11 ready\n");
     {   // conv2d_mfma_kernel: an RMVPE U-Net block conv, 3 x 3, 64 -> 64 channels on a 32 x 3232 map
-        const int C = 64, H = 32, W = 3232;
+        const int C = 64, H = 3232, W = 32;     // [channel][frame][mel bin]
         std::vector<float> w((size_t)C * C * 9), x((size_t)C * H * W), b(C);
         frand(w, 0.1f); frand(x, 2.f); frand(b, 1.f);
         float *dx = dev_copy(x), *db = dev_copy(b), *dw, *y; void *ws;
@@ -290,10 +292,11 @@ int main(int argc, char **argv) {
         if (rvc_conv2d_packed_floats(C, C, 3, 3, &nw) || rvc_conv2d_workspace_bytes(1, C, C, H, W, 3, 3, &nws)) { fprintf(stderr, "conv2d: %s\n", rvc_last_error()); exit(1); }
         CK(hipMalloc(&dw, nw * 4)); CK(hipMalloc(&y, x.size() * 4)); CK(hipMalloc(&ws, nws ? nws : 16));
         if (rvc_conv2d_pack_weight(w.data(), C, C, 3, 3, dw, nullptr)) { fprintf(stderr, "pack2d: %s\n", rvc_last_error()); exit(1); }
-        victims.push_back({"C2D library conv2d_mfma_kernel, 3 x 3, 64 -> 64 channels, 32 x 3232", [=](hipStream_t st) {
+        victims.push_back({"C2D library conv2d_mfma_kernel, 3 x 3, 64 -> 64 channels, 3232 frames x 32 bins", [=](hipStream_t st) {
             if (rvc_conv2d_forward(dx, dw, db, dx, y, 1, C, C, H, W, 3, 3, 1, ws, nws, st)) { fprintf(stderr, "conv2d: %s\n", rvc_last_error()); exit(1); }
         }, y, (size_t)C * H * W, C});
     }
+    fprintf(stderr, "[setup] C2D ready\n");
     {   // attention_qkv_kernel<96>: the TextEncoder's relative-position attention (fp32 matrix instruction), 2 heads x 96, 3198 frames
         const int T = 3198, Hh = 2, D = 96;
         std::vector<float> q((size_t)T * 3 * Hh * D), ek((size_t)21 * D), ev((size_t)21 * D);
@@ -305,6 +308,7 @@ int main(int argc, char **argv) {
             if (rvc_attention_qkv_f32(dq, dk, dv, y, 1, T, Hh, D, 0.1f, ws, nws, st)) { fprintf(stderr, "att: %s\n", rvc_last_error()); exit(1); }
         }, y, (size_t)T * Hh * D, 0});
     }
+    fprintf(stderr, "[setup] A96 ready\n");
     {   // knn_partial_kernel: the exact fp32 regime of the top-8 search (mode 1), 1599 queries x 50 000 rows
         const int64_t N = 50000, Q = 1599; const int D = 768;
         std::vector<float> idx((size_t)N * D), qs((size_t)Q * D);
@@ -320,6 +324,7 @@ int main(int argc, char **argv) {
         }, d2, (size_t)Q * 8, 0});
     }
 
+    fprintf(stderr, "[setup] KNN ready\n");
     // round 3's gemmbf_kernel<1, DBG> (HuBERT conv layer 1: 512 -> 512 channels, 3 taps, stride 2, 51 000 samples in)
     rvc_r03::GemmBfParams gp;
     {
