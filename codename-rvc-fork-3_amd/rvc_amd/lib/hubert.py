@@ -29,6 +29,7 @@ class HubertModelWithFinalProj:
         # reference-RNG compatibility: transformers' encoder draws torch.rand([]) per layer for LayerDrop even
         # in eval mode, advancing the CPU generator the Synthesizer's noise comes from afterwards
         self.consume_layerdrop_rng = False
+        self.native_min_rows = 900      # frames from which the transformer layers run on K12 (linbf.hip); tests set it to 1
         if state_dict is not None:
             self.load_state_dict(state_dict)
 
@@ -133,7 +134,10 @@ class HubertModelWithFinalProj:
         b, t, _ = x.shape
         h = self.n_heads
         hd = d // h
-        if x.is_cuda and self._lin:
+        # K12 fills the chip from ~900 frames up (18 s of audio; 1599 frames: 1.23-1.37 x hipBLASLt per projection); below that its
+        # 128-frame tiles leave most CUs idle and every launch costs its 24-chunk K loop whatever the frame count, so short clips
+        # keep the library GEMMs (cfg 1's 599 frames: 13.8 against 12.9 ms per utterance)
+        if x.is_cuda and self._lin and b * t >= self.native_min_rows:
             return {"last_hidden_state": self._encoder_native(x, b, t, d, h)}
         for i in range(self.n_layers):
             L = f"encoder.layers.{i}"

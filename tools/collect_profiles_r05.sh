@@ -42,8 +42,10 @@ for k, d in agg.items():
     m = {n: sum(v) / len(v) for n, v in d.items()}
     for n, v in sorted(m.items()): print(f"    {n:28s} {v:.4e}")
     if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "GRBM_GUI_ACTIVE" in m:
-        print(f"    -> matrix pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) = {m['SQ_VALU_MFMA_BUSY_CYCLES'] / (m['GRBM_GUI_ACTIVE'] * 1024):.3f}; "
-              f"effective clock {m['GRBM_GUI_ACTIVE'] / (sum(dur[k]) / len(dur[k])):.2f} GHz")
+        clk = m['GRBM_GUI_ACTIVE'] / 8 / (sum(dur[k]) / len(dur[k]))          # the counter is summed over the 8 XCDs
+        busy = m['SQ_VALU_MFMA_BUSY_CYCLES'] / (m['GRBM_GUI_ACTIVE'] / 8 * 1024)
+        print(f"    -> effective clock {clk:.2f} GHz; matrix pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) = {busy:.3f} of the cycles "
+              f"at that clock = {busy * clk / 2.4:.3f} of the 2.4 GHz peak the roofline is quoted against")
 PY
 # kNN: kernel stats + HBM traffic of one search at 100 k and 2 M rows
 (cd $R && bash tools/profile_knn.sh) > $O/knn_profile.log 2>&1
