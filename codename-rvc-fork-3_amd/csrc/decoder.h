@@ -2,6 +2,7 @@
 #pragma once
 #include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -65,6 +66,20 @@ struct Stage {
     std::vector<DevBuf16> pair;   // 32- / 64-channel stages: (c1, c2) of each entry as one slab of bf16x3 matrix-instruction fragments (resblock_bf.hip)
 };
 
+// One forward call's side streams: the ResBlock branches of a stage (resblocks[i * nk + m], m = 0..nk-1: hifigan_nsf.py:195-203 sums
+// them) depend on the stage's input only, so branch m > 0 runs on side stream m - 1 next to branch 0 on the caller's stream.  A
+// whole-CU kernel whose grid is 1.17 rounds of the 256 CUs (stage 0 of the 48 k vocoder: 300 blocks) leaves most of the chip idle
+// through its second round; the next branch's blocks take those CUs.
+constexpr int MAX_BRANCH_LANES = 7;
+struct BranchLanes {
+    hipStream_t side[MAX_BRANCH_LANES] = {};
+    hipEvent_t fork = nullptr;
+    hipEvent_t last[MAX_BRANCH_LANES + 1] = {};   // the branch's last launch (it adds into the running sum after its predecessor's)
+    int n_side = 0;
+    int create(int n);
+    ~BranchLanes();
+};
+
 // RefineGAN-only state (refine.hip)
 struct RefineStage {
     int ch_in = 0, ch_out = 0, rate = 0, down_c = 0, down_k = 0, down_stride = 0, down_pad = 0;
@@ -96,6 +111,11 @@ struct rvc_decoder {
     rvc::ConvW mel;                // mel_conv k7 192 -> 256
     std::vector<rvc::RefineStage> rstages;
     std::atomic<int> concurrency{0};   // rvc_decoder_set_concurrency_hint (0 = process default)
+    // rvc_decoder_set_branch_parallel: ResBlock branches of a short stage on this many side streams (NSF / MRF schedules); -1 = one per branch after the first
+    std::atomic<int> branch_parallel{0};
+    std::mutex lanes_mu;
+    std::map<hipStream_t, rvc::BranchLanes *> lanes;  // per caller stream (utterances in flight on different streams must not queue behind each other's branches)
+    ~rvc_decoder() { for (auto &kv : lanes) delete kv.second; }
     // debug tap
     int tap_stage = -2;
     float *tap_dev = nullptr;

@@ -624,9 +624,18 @@ struct Carve {
     size_t take(size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; }
 };
 struct Layout {
-    size_t har, carry, biasp, V, p1, p2, wraps, buf[4], total;
+    size_t har, carry, biasp, V, p1, p2, wraps, buf[2 + 2 * (MAX_BRANCH_LANES + 1)], total;
+    int n_buf;
     int64_t max_cl;
 };
+// a stage at most this long (batch x channels x samples) runs its ResBlock branches side by side: 3 rounds of K3y's 128 x 256 blocks
+constexpr int64_t BRANCH_PARALLEL_MAX_ELEMS = (int64_t)3 * 256 * 128 * 256;
+// branches on side streams: every lane owns its two ping-pong buffers
+int branch_lanes_wanted(const rvc_decoder *d) {
+    const int nk = d->cfg.n_res_kernels, want = d->branch_parallel.load(std::memory_order_relaxed);
+    const int most = nk - 1 < MAX_BRANCH_LANES ? nk - 1 : MAX_BRANCH_LANES;
+    return want < 0 || want > most ? most : want;
+}
 Layout make_layout(const rvc_decoder *d, int batch, int64_t T) {
     Layout l;
     Carve c;
@@ -647,7 +656,8 @@ Layout make_layout(const rvc_decoder *d, int batch, int64_t T) {
     l.p1 = c.take(scan * 8);
     l.p2 = c.take(scan * 8);
     l.wraps = c.take(scan * 4);
-    for (int i = 0; i < 4; ++i) l.buf[i] = c.take((size_t)batch * max_cl * 4);
+    l.n_buf = 2 + 2 * (branch_lanes_wanted(d) + 1);
+    for (int i = 0; i < l.n_buf; ++i) l.buf[i] = c.take((size_t)batch * max_cl * 4);
     l.total = c.off;
     l.max_cl = max_cl;
     return l;
@@ -665,6 +675,40 @@ extern "C" int rvc_decoder_set_tap(rvc_decoder *dec, int stage, float *tap_dev) 
     if (!dec) return fail("rvc_decoder_set_tap: null decoder");
     dec->tap_stage = tap_dev ? stage : -2;
     dec->tap_dev = tap_dev;
+    return 0;
+}
+
+int rvc::BranchLanes::create(int n) {
+    n_side = n;
+    for (int i = 0; i < n; ++i) RVC_HIP(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
+    RVC_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    for (int i = 0; i <= MAX_BRANCH_LANES; ++i) RVC_HIP(hipEventCreateWithFlags(&last[i], hipEventDisableTiming));   // one per BRANCH
+    return 0;
+}
+rvc::BranchLanes::~BranchLanes() {
+    for (int i = 0; i < n_side; ++i) if (side[i]) { (void)hipStreamSynchronize(side[i]); (void)hipStreamDestroy(side[i]); }
+    if (fork) (void)hipEventDestroy(fork);
+    for (int i = 0; i <= MAX_BRANCH_LANES; ++i) if (last[i]) (void)hipEventDestroy(last[i]);
+}
+
+namespace {
+// the caller stream's lanes (created on first use, kept for the life of the handle)
+int lanes_for(rvc_decoder *d, hipStream_t stream, int n_side, BranchLanes **out) {
+    std::lock_guard<std::mutex> g(d->lanes_mu);
+    BranchLanes *&l = d->lanes[stream];
+    if (l && l->n_side != n_side) { delete l; l = nullptr; }
+    if (!l) {
+        l = new BranchLanes();
+        if (l->create(n_side)) { delete l; l = nullptr; return 1; }
+    }
+    *out = l;
+    return 0;
+}
+}  // namespace
+
+extern "C" int rvc_decoder_set_branch_parallel(rvc_decoder *dec, int side_streams) {
+    if (!dec) return fail("rvc_decoder_set_branch_parallel: null decoder");
+    dec->branch_parallel.store(side_streams, std::memory_order_relaxed);
     return 0;
 }
 
@@ -696,8 +740,11 @@ extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const flo
     float *carry = (float *)(ws + lay.carry);
     float *biasp = (float *)(ws + lay.biasp);
     float *V = (float *)(ws + lay.V);
-    float *buf[4];
-    for (int i = 0; i < 4; ++i) buf[i] = (float *)(ws + lay.buf[i]);
+    float *buf[2 + 2 * (MAX_BRANCH_LANES + 1)];
+    for (int i = 0; i < lay.n_buf; ++i) buf[i] = (float *)(ws + lay.buf[i]);
+    const int n_side = (lay.n_buf - 4) / 2;
+    BranchLanes *lanes = nullptr;
+    if (n_side > 0 && lanes_for(d, stream, n_side, &lanes)) return 1;
     const int64_t L = T * d->upp;
     const float sr = (float)c.sample_rate;
 
@@ -755,7 +802,7 @@ extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const flo
                                s.S, s.P, s.vk, s.vk_rows, nq, V);
             RVC_LAUNCH_CHECK();
         }
-        float *X = buf[1], *Y = buf[2], *T1 = buf[3];
+        float *X = buf[1];
         {
             ConvParams p;
             p.x1 = cur; p.c1 = s.c_in; p.slope1 = 0.1f; p.x1_bstride = (int64_t)s.c_in * len;
@@ -784,22 +831,50 @@ extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const flo
         }
         len = len_out;
         const int64_t bs = (int64_t)s.c_out * len;
-        for (int m = 0; m < nk; ++m) {
+        // The branches all read X; the last launch of a branch adds into the running sum `cur` after its predecessor's has.
+        // A SHORT stage (its whole-CU kernels are a few rounds of the 256 CUs: 300 blocks = 1.17 rounds in stage 0 of a 30 s clip at
+        // 48 k, where each launch leaves most of the chip idle through its second round) can run its branches next to each other
+        // on the handle's side streams (rvc_decoder_set_branch_parallel; off by default: profiles/r05_branch_streams.txt).
+        const bool short_stage = (int64_t)batch * bs <= BRANCH_PARALLEL_MAX_ELEMS;
+        const bool par = lanes && short_stage;
+        if (par) {
+            RVC_HIP(hipEventRecord(lanes->fork, stream));
+            for (int q = 0; q < n_side; ++q) RVC_HIP(hipStreamWaitEvent(lanes->side[q], lanes->fork, 0));
+        }
+        const hipStream_t main_stream = stream;
+        for (int r = 0; r < nk; ++r) {
+            const int m = r;
+            const bool first_branch = r == 0, final_branch = r + 1 == nk;
             const int k = c.res_kernel_sizes[m];
             const float *xin = X;
+            // with fewer side streams than branches the first (short) branches share the caller's stream
+            const int off = nk - 1 - n_side;
+            const int lane = par && r > off ? r - off : 0, lane_prev = par && r - 1 > off ? r - 1 - off : 0;
+            const hipStream_t stream = lane > 0 ? lanes->side[lane - 1] : main_stream;
+            float *const Y = buf[2 + 2 * lane], *const T1 = buf[3 + 2 * lane];
+            auto before_last = [&]() -> int {
+                if (par && r > 0 && lane_prev != lane) RVC_HIP(hipStreamWaitEvent(stream, lanes->last[r - 1], 0));
+                return 0;
+            };
+            auto after_last = [&]() -> int {
+                if (par) RVC_HIP(hipEventRecord(lanes->last[r], stream));
+                return 0;
+            };
             if (s.pair[m * nd].p && resblock_bf_fits(s.c_out, len)) {
                 // 32- / 64-channel stages: one launch per (dilated conv, conv) pair on the bf16 matrix cores (resblock_bf.hip); blocks
                 // read their neighbours' columns, so the outputs ping-pong between Y and T1
                 for (int j = 0; j < nd; ++j) {
                     const bool last = j + 1 == nd;
                     float *yout = last ? cur : (j % 2 == 0 ? Y : T1);
-                    const float *acc_in = (last && m > 0) ? cur : nullptr;
-                    const float scale = (last && m + 1 == nk) ? 1.f / (float)nk : 1.f;
+                    const float *acc_in = (last && !first_branch) ? cur : nullptr;
+                    const float scale = (last && final_branch) ? 1.f / (float)nk : 1.f;
+                    if (last && before_last()) return 1;
                     if (launch_resblock_bf(xin, s.pair[m * nd + j].p, s.c1[m * nd + j].b.p, s.c2[m * nd + j].b.p, acc_in, yout, batch,
                                            s.c_out, len, k, c.res_dilations[j], 0.1f, scale, stream))
                         return 1;
                     xin = yout;
                 }
+                if (after_last()) return 1;
                 continue;
             }
             if (resblock_layer_supported(s.c_out, k) && !s.c1[m * nd].w16.p) {
@@ -808,14 +883,16 @@ extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const flo
                 for (int j = 0; j < nd; ++j) {
                     const bool last = j + 1 == nd;
                     float *yout = last ? cur : (j % 2 == 0 ? Y : T1);
-                    const float *acc_in = (last && m > 0) ? cur : nullptr;
-                    const float scale = (last && m + 1 == nk) ? 1.f / (float)nk : 1.f;
+                    const float *acc_in = (last && !first_branch) ? cur : nullptr;
+                    const float scale = (last && final_branch) ? 1.f / (float)nk : 1.f;
+                    if (last && before_last()) return 1;
                     if (launch_resblock_layer(xin, s.c1[m * nd + j].w.p, s.c1[m * nd + j].b.p, s.c2[m * nd + j].w.p,
                                               s.c2[m * nd + j].b.p, acc_in, yout, batch, s.c_out, len, k, c.res_dilations[j], 0.1f,
                                               scale, stream))
                         return 1;
                     xin = yout;
                 }
+                if (after_last()) return 1;
                 continue;
             }
             for (int j = 0; j < nd; ++j) {
@@ -833,18 +910,21 @@ extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const flo
                 q.w_wino16 = reinterpret_cast<const uint32_t *>(s.c2[m * nd + j].wu16.p);
                 q.res = xin;
                 q.y_bstride = bs; q.m_total = s.c_out; q.c_out = s.c_out; q.n_cols = len; q.l_out = len;
-                q.kw = k; q.dil = 1; q.padl = (k - 1) / 2; q.batch = batch;
+                q.kw = k; q.dil = 1; q.padl = (k - 1) / 2;  q.batch = batch;
                 if (j + 1 < nd) {
                     q.y = Y;
                 } else {  // last layer of the branch: add into the running sum, scale the last one by 1/nk
                     q.y = cur;
-                    q.accin = (m > 0) ? cur : nullptr;
-                    q.out_scale = (m + 1 == nk) ? 1.f / (float)nk : 1.f;
+                    q.accin = first_branch ? nullptr : cur;
+                    q.out_scale = final_branch ? 1.f / (float)nk : 1.f;
+                    if (before_last()) return 1;
                 }
                 if (launch_conv(q, stream)) return 1;
                 xin = Y;
             }
+            if (after_last()) return 1;
         }
+        if (par) RVC_HIP(hipStreamWaitEvent(main_stream, lanes->last[nk - 1], 0));   // (transitively every branch: each last launch waited for its predecessor's)
         if (d->tap_stage == i && d->tap_dev)
             RVC_HIP(hipMemcpyAsync(d->tap_dev, cur, (size_t)batch * bs * 4, hipMemcpyDeviceToDevice, stream));
     }

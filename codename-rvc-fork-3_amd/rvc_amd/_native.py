@@ -94,6 +94,7 @@ SYMBOLS = {
                                     c_void_p, c_void_p, c_size_t, c_void_p]),
     "rvc_decoder_set_tap": (c_int, [c_void_p, c_int, c_void_p]),
     "rvc_decoder_set_concurrency_hint": (c_int, [c_void_p, c_int]),
+    "rvc_decoder_set_branch_parallel": (c_int, [c_void_p, c_int]),
     "rvc_conv1d_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rvc_conv1d_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_int64, c_int, c_int, c_float, c_float, c_void_p]),
@@ -782,6 +783,11 @@ class Decoder:
 
     def set_concurrency_hint(self, utterances_in_flight: int):
         _check(_lib.rvc_decoder_set_concurrency_hint(self._h, int(utterances_in_flight)), "rvc_decoder_set_concurrency_hint")
+
+    def set_branch_parallel(self, side_streams: int):
+        """ResBlock branches of a short stage on this many side streams of the handle (-1: one per branch after the first;
+        0, the default: every launch on the caller's stream)."""
+        _check(_lib.rvc_decoder_set_branch_parallel(self._h, int(side_streams)), "rvc_decoder_set_branch_parallel")
 
     def set_tap(self, stage: int, tap: torch.Tensor | None):
         _check(_lib.rvc_decoder_set_tap(self._h, stage, tap.data_ptr() if tap is not None else None),

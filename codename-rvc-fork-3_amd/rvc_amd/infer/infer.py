@@ -46,6 +46,7 @@ class VoiceConverter:
         self.use_f0 = None
         self.loaded_model = None
         self.dec_weight_dtype = "f32"   # "bf16": the vocoder's conv weights are stored as bf16 in HBM (BASELINE cfg 4)
+        self.branch_streams = None      # None: convert_batch decides (side streams only with one utterance at a time); an int pins Decoder.set_branch_parallel
 
     # ---- embedder (infer.py:64-74; file layout rvc/lib/utils.py:96-146) ----
     def load_hubert(self, embedder_model: str, embedder_model_custom: str = None):
@@ -219,6 +220,9 @@ class VoiceConverter:
                 errors.append(error)
 
         self.net_g.dec.set_concurrency_hint(n_workers)   # per decoder handle: other converters in the process are unaffected
+        # one utterance at a time: nothing else fills the CUs a short vocoder stage leaves idle, so its ResBlock branches run side
+        # by side (-0.3 ms of 32.9 per 30 s utterance; with two in flight it measures level or worse: profiles/r05_branch_streams.txt)
+        self.net_g.dec.set_branch_parallel((-1 if n_workers == 1 else 0) if self.branch_streams is None else self.branch_streams)
         threads = [threading.Thread(target=work, args=(t,)) for t in range(n_workers)]
         try:
             for t in threads:

@@ -270,6 +270,17 @@ int rvc_decoder_forward(rvc_decoder *dec, const float *z_dev, const float *f0_de
  * forwards of this handle are running on other threads: it only affects forwards that start afterwards. */
 int rvc_decoder_set_concurrency_hint(rvc_decoder *dec, int utterances_in_flight);
 
+/* The ResBlock branches of a stage (`xs += self.resblocks[i * self.num_kernels + j](x)`, hifigan_nsf.py:195-203 /
+ * hifigan_mrf.py:353-361) depend on the stage's input only.  With side_streams > 0 (or -1: one per branch after the first) a
+ * SHORT stage (batch x channels x samples <= 3 rounds of the 256 CUs' 128 x 256 blocks; stage 0 of a 30 s clip at 48 k is
+ * 1.17 rounds, so every launch leaves most of the chip idle through its second round) runs its branches side by side on
+ * streams owned by the handle, each branch's last launch adding into the running sum after its predecessor's; the caller's
+ * stream waits for the last one, so the call is ordered on `stream` exactly as before and results are bit-identical.
+ * Default 0 (every launch on the caller's stream): one forward on an idle device gets 5 % (30 s) to 27 % (3 s) shorter, a
+ * pipeline that already keeps two utterances in flight does not (profiles/r05_branch_streams.txt).
+ * Changes the workspace size (every stream owns two ping-pong buffers): query rvc_decoder_workspace_bytes afterwards. */
+int rvc_decoder_set_branch_parallel(rvc_decoder *dec, int side_streams);
+
 /* Debug hook for the parity tests: after stage `stage` of the next forward calls, copy that stage's output
  * ([batch][C_stage][L_stage], the mean of the three ResBlocks) to tap_dev; stage -1 = har_source [batch][T*upp].
  * tap_dev = NULL switches it off. */

@@ -728,6 +728,48 @@ def test_decoder_forwards_on_two_streams_are_bit_exact(native, dev):
     assert bad == [0, 0], f"decoder outputs changed under concurrency in {bad} of 25 runs per thread"
 
 
+@pytest.mark.parametrize("voc", ["HiFi-GAN", "MRF HiFi-GAN"])
+def test_decoder_branches_on_side_streams_are_bit_exact(native, dev, voc):
+    """rvc_decoder_set_branch_parallel: the ResBlock branches of a short stage on 1 or 2 side streams of the handle
+    (hifigan_nsf.py:195-203 sums them; they depend on the stage's input only) must give the one-stream waveform BIT FOR BIT --
+    same kernels, same order of the additions -- from one thread and from two threads on their own streams."""
+    import threading
+    from rvc_amd.lib import synthetic as S
+    from rvc_amd.lib.algorithm.weights import fold_weight_norm
+    cpt = S.make_synth_checkpoint(48000, voc, seed=0)
+    folded = {k[4:]: v for k, v in fold_weight_norm(cpt["weight"]).items() if k.startswith("dec.")}
+    dec = native.Decoder(voc, 48000, folded)
+    dim = 9 if voc.startswith("MRF") else 1
+    ins = []
+    for i, T in enumerate((301, 1000)):       # 301: every stage short; 1000: the last two stages stay on one stream
+        g = torch.Generator(device=dev).manual_seed(i)
+        ins.append((torch.randn(1, 192, T, device=dev, generator=g), torch.full((1, T), 220.0, device=dev),
+                    torch.randn(1, 256, device=dev, generator=g), torch.randn(1, T * 480, dim, device=dev, generator=g),
+                    torch.rand(1, dim, device=dev, generator=g)))
+    refs = [dec.forward(z, f0, gv, src_randn=nz, src_rand=rnd).clone() for z, f0, gv, nz, rnd in ins]
+    for n_side in (1, 2, -1):
+        dec.set_branch_parallel(n_side)
+        for (z, f0, gv, nz, rnd), ref in zip(ins, refs):
+            for _ in range(3):
+                assert torch.equal(dec.forward(z, f0, gv, src_randn=nz, src_rand=rnd), ref), f"{n_side} side stream(s), T = {z.shape[2]}"
+    bad = [0, 0]
+
+    def worker(i):
+        st = torch.cuda.Stream(device=dev)
+        z, f0, gv, nz, rnd = ins[i]
+        with torch.cuda.stream(st):
+            for _ in range(15):
+                out = dec.forward(z, f0, gv, src_randn=nz, src_rand=rnd)
+                st.synchronize()
+                bad[i] += int((out != refs[i]).any().item())
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    dec.set_branch_parallel(0)
+    assert bad == [0, 0], f"outputs changed with the branches on side streams in {bad} of 15 runs per thread"
+
+
 @pytest.mark.parametrize("b,c,length", [(1, 512, 95999), (2, 64, 1003), (1, 8, 4)])
 def test_rownorm_gelu_matches_float64(native, dev, b, c, length):
     """rvc_rownorm_gelu_f32 vs float64 GroupNorm(num_groups = channels) + exact GELU (HuBERT's first layer, pipeline.py:450)."""
