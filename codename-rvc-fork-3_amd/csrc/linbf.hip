@@ -38,7 +38,11 @@ struct LinBfParams {
     void *ys = nullptr;              // mode 1: [3][n_pad][M] bf16
     int M = 0, K = 0;
     int64_t N = 0, n_pad = 0;
-    int mode = 0;                    // 0: y = acc + bias; 1: ys = split3(gelu(acc + bias)); 2: y[part] = acc
+    int mode = 0;                    // 0: y = acc + bias; 1: ys = split3(gelu(acc + bias)); 2: y[part] = acc; 3: y = gelu(acc + bias)
+    // the activation planes as the kernel addresses them: GEMM row n starts x_row_stride elements after row n - 1 (a linear layer:
+    // K; a strided conv over time-major frames: stride x channels, its K = taps x channels window being contiguous), x_plane
+    // elements per split plane
+    int64_t x_row_stride = 0, x_plane = 0;
     int steps_per_part = 0;          // 16-deep steps per K part
     int n_col_blocks = 0;
 };
@@ -55,7 +59,7 @@ typedef void __attribute__((address_space(3))) *lbf_lptr_t;
 
 // MI = 32-row blocks per wave: 2 -> 128 output features per block, chunks requested two ahead; 3 -> 192 per block (16 x 13 = 208
 // blocks for the 3072-wide feed-forward instead of 24 x 13 = 312 on 256 CUs), chunks requested one ahead (LDS: 18 KiB of weights
-// per step).
+// per step); 4 -> 256 per block (the long layers of the feature extractor: 0.75 of the bytes per product), one ahead, 24 KiB per step.
 template <int MI>
 struct LbfGeom {
     static constexpr int BM = 64 * MI;
@@ -103,9 +107,10 @@ linbf_kernel(const LinBfParams p) {
     const int K = p.K;
 
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void *)p.a, 0, (int)((int64_t)p.M * K * 6), 0x00020000);
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.xs, 0, (int)(3 * p.n_pad * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.xs, 0, (int)(3 * p.x_plane * 2), 0x00020000);
     const int slab_row = (K / 16) * LBF_SLAB_STEP;           // bytes of one 128-row block of the slab
-    const int plane = (int)(p.n_pad * K * 2);
+    const int plane = (int)(p.x_plane * 2);
+    const int row_bytes = (int)(p.x_row_stride * 2);
     // activation piece: lane = (row r of 16, LDS segment j of 4); it fetches the row's segment j ^ ((row >> 2) & 3)
     const int b_r = lane >> 2, b_j = lane & 3;
     // chunk c of this block's K part: pieces 0 .. 12 MI - 1: the two steps' weight fragments; then 24 activation pieces
@@ -126,7 +131,7 @@ linbf_kernel(const LinBfParams p) {
                 const int q = pc - 12 * MI, sp = q >> 3, r16 = q & 7;
                 const int row = r16 * 16 + b_r;
                 const int seg = b_j ^ ((row >> 2) & 3);
-                const int voff = (int)((n0 + row) * K * 2) + seg * 16;
+                const int voff = (int)(n0 + row) * row_bytes + seg * 16;   // (rows of the last tile past the planes' end: plane 0 / 1 read into the next plane, plane 2 reads zeros; their results are not stored)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lbf_lptr_t)(bslot + sp * (LBF_BN * 64) + r16 * 1024), 16, voff, sp * plane + sg * 32, 0, 0);
             }
         }
@@ -204,6 +209,10 @@ linbf_kernel(const LinBfParams p) {
             // GELU (erf form, what torch.nn.functional.gelu computes), then the exact three-way split of the four values
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = 0.5f * o[r] * (1.f + erff(o[r] * 0.70710678118654752f));
+            if (p.mode == 3) {
+                *reinterpret_cast<f32x4 *>(p.y + n * p.M + m) = o;
+                continue;
+            }
             lbf_f32x2 v0 = {o[0], o[1]}, v1 = {o[2], o[3]};
 #pragma unroll
             for (int sp = 0; sp < 3; ++sp) {
@@ -320,31 +329,60 @@ extern "C" int rvc_split_rows_bf16x3(const float *x_dev, void *xs_dev, int64_t n
     return 0;
 }
 
-extern "C" int rvc_linear_bf16x3_presplit(const void *xs_dev, const void *a_dev, const float *bias_dev, float *y_dev, void *ys_dev,
-                                          int64_t n_rows, int64_t n_rows_padded, int in_features, int out_features, int mode, int k_parts,
-                                          void *stream) {
-    if (!xs_dev || !a_dev) return fail("rvc_linear_bf16x3_presplit: null pointer");
-    if (out_features % 128 || in_features % 16) return fail("rvc_linear_bf16x3_presplit: out_features must be a multiple of 128, in_features of 16");
-    if (mode < 0 || mode > 2) return fail("rvc_linear_bf16x3_presplit: mode must be 0 (fp32 + bias), 1 (bias + GELU -> planes) or 2 (partial sums)");
-    if ((mode == 1) ? !ys_dev : !y_dev) return fail("rvc_linear_bf16x3_presplit: the output of mode %d is missing", mode);
-    if (k_parts < 1 || (in_features / 32) % k_parts || in_features % 32) return fail("rvc_linear_bf16x3_presplit: in_features must be a multiple of 32 and k_parts divide in_features / 32");
-    if (k_parts > 1 && mode != 2) return fail("rvc_linear_bf16x3_presplit: several K parts only produce partial sums (mode 2)");
-    if (n_rows_padded % LBF_BN || n_rows_padded < n_rows) return fail("rvc_linear_bf16x3_presplit: n_rows_padded must be a multiple of 128 and >= n_rows");
-    if ((int64_t)out_features * in_features * 6 >= ((int64_t)1 << 31) || 3 * n_rows_padded * in_features * 2 >= ((int64_t)1 << 31))
-        return fail("rvc_linear_bf16x3_presplit: an operand exceeds 2 GiB");
+namespace {
+int linbf_dispatch(const char *who, const void *xs_dev, int64_t x_row_stride, int64_t x_plane, const void *a_dev, const float *bias_dev,
+                   float *y_dev, void *ys_dev, int64_t n_rows, int64_t n_rows_padded, int in_features, int out_features, int mode,
+                   int k_parts, void *stream) {
+    if (!xs_dev || !a_dev) return fail("%s: null pointer", who);
+    if (out_features % 128 || in_features % 16) return fail("%s: out_features must be a multiple of 128, in_features of 16", who);
+    if (mode < 0 || mode > 3) return fail("%s: mode must be 0 (fp32 + bias), 1 (bias + GELU -> planes), 2 (partial sums) or 3 (bias + GELU -> fp32)", who);
+    if ((mode == 1) ? !ys_dev : !y_dev) return fail("%s: the output of mode %d is missing", who, mode);
+    if (k_parts < 1 || (in_features / 32) % k_parts || in_features % 32) return fail("%s: in_features must be a multiple of 32 and k_parts divide in_features / 32", who);
+    if (k_parts > 1 && mode != 2) return fail("%s: several K parts only produce partial sums (mode 2)", who);
+    if (n_rows_padded % LBF_BN || n_rows_padded < n_rows) return fail("%s: n_rows_padded must be a multiple of 128 and >= n_rows", who);
+    if ((int64_t)out_features * in_features * 6 >= ((int64_t)1 << 31) || 3 * x_plane * 2 >= ((int64_t)1 << 31) ||
+        (n_rows_padded + LBF_BN) * x_row_stride * 2 >= ((int64_t)1 << 31))
+        return fail("%s: an operand exceeds 2 GiB", who);
+    if (x_row_stride % 8) return fail("%s: rows must start on 16-byte boundaries", who);
     if (n_rows <= 0) return 0;
     LinBfParams p;
     p.a = a_dev; p.xs = xs_dev; p.bias = bias_dev; p.y = y_dev; p.ys = ys_dev;
     p.M = out_features; p.K = in_features; p.N = n_rows; p.n_pad = n_rows_padded; p.mode = mode;
+    p.x_row_stride = x_row_stride; p.x_plane = x_plane;
     p.steps_per_part = in_features / 16 / k_parts;
-    // 192-row blocks where they fill the chip better in one round than 128-row blocks do (HuBERT's 3072-wide feed-forward at 1599
-    // frames: 208 blocks against 312 for 256 CUs)
+    // Block height: 128 output features unless taller blocks need fewer ROUNDS of the 256 CUs at their relative block time -- a
+    // 192-row block works 1.5 x as long at ~0.85 of the bytes per product (HuBERT's 3072-wide feed-forward at 1599 frames: 208
+    // blocks in one round against 312 in two), a 256-row block 1.85 x as long (measured: 0.75 of the bytes per product, but its
+    // 24 KiB steps leave room for one chunk in flight instead of two; the feature extractor's 47 999-frame layer: 750 blocks = 3
+    // rounds, 586 us, against 1500 = 6 rounds, 642 us): the kernel runs at the CU's ingest rate, so bytes per product are time
     const int64_t cols = ceil_div(n_rows, LBF_BN);
-    const int64_t b128 = cols * (out_features / 128) * k_parts, b192 = out_features % 192 == 0 ? cols * (out_features / 192) * k_parts : 0;
     const int cus = 256;
-    auto rounds = [&](int64_t b) { return (double)ceil_div(b, cus); };
-    const bool use192 = b192 > 0 && rounds(b192) * 1.5 * 0.85 < rounds(b128);   // a 192-row block works 1.5 x as long, at ~0.85 of the bytes per product
+    auto cost = [&](int rows_per_block, double rel) {
+        if (out_features % rows_per_block) return 1e30;
+        return (double)ceil_div(cols * (out_features / rows_per_block) * k_parts, cus) * rel;
+    };
+    const double c128 = cost(128, 1.0), c192 = cost(192, 1.5 * 0.85), c256 = cost(256, 1.85);
+    if (c256 < c128 && c256 <= c192) return linbf_launch<4>(p, k_parts, (hipStream_t)stream);
+    const bool use192 = c192 < c128;
     return use192 ? linbf_launch<3>(p, k_parts, (hipStream_t)stream) : linbf_launch<2>(p, k_parts, (hipStream_t)stream);
+}
+}  // namespace
+
+extern "C" int rvc_linear_bf16x3_presplit(const void *xs_dev, const void *a_dev, const float *bias_dev, float *y_dev, void *ys_dev,
+                                          int64_t n_rows, int64_t n_rows_padded, int in_features, int out_features, int mode, int k_parts,
+                                          void *stream) {
+    return linbf_dispatch("rvc_linear_bf16x3_presplit", xs_dev, in_features, n_rows_padded * in_features, a_dev, bias_dev, y_dev, ys_dev,
+                          n_rows, n_rows_padded, in_features, out_features, mode, k_parts, stream);
+}
+
+extern "C" int rvc_conv1d_frames_bf16x3(const void *xs_dev, int64_t n_frames_in, int64_t n_frames_in_padded, int channels, int taps,
+                                        int stride, const void *a_dev, const float *bias_dev, float *y_dev, void *ys_dev,
+                                        int64_t n_frames_out_padded, int out_channels, int mode, void *stream) {
+    if (taps < 1 || stride < 1 || channels < 8 || n_frames_in_padded < n_frames_in) return fail("rvc_conv1d_frames_bf16x3: bad argument");
+    if (mode == 2) return fail("rvc_conv1d_frames_bf16x3: modes 0 (fp32 + bias), 1 (bias + GELU -> planes), 3 (bias + GELU -> fp32)");
+    const int64_t n_out = n_frames_in >= taps ? (n_frames_in - taps) / stride + 1 : 0;
+    return linbf_dispatch("rvc_conv1d_frames_bf16x3", xs_dev, (int64_t)stride * channels, n_frames_in_padded * channels, a_dev, bias_dev,
+                          y_dev, ys_dev, n_out, n_frames_out_padded, taps * channels, out_channels, mode, 1, stream);
 }
 
 extern "C" int rvc_bias_residual_layernorm_bf16x3(const float *parts_dev, int n_parts, const float *bias_dev, const float *res_dev,

@@ -95,6 +95,11 @@ SYMBOLS = {
     "rvc_decoder_set_tap": (c_int, [c_void_p, c_int, c_void_p]),
     "rvc_decoder_set_concurrency_hint": (c_int, [c_void_p, c_int]),
     "rvc_decoder_set_branch_parallel": (c_int, [c_void_p, c_int]),
+    "rvc_hubert_conv0_workspace_bytes": (c_int, [c_int, POINTER(c_size_t)]),
+    "rvc_hubert_conv0_frames_bf16x3": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p,
+                                               c_size_t, c_void_p, c_int64, c_void_p]),
+    "rvc_conv1d_frames_bf16x3": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                         c_int, c_int, c_void_p]),
     "rvc_conv1d_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rvc_conv1d_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_int64, c_int, c_int, c_float, c_float, c_void_p]),
@@ -663,8 +668,8 @@ def linear_bf16x3_presplit(xs: torch.Tensor, a_packed: torch.Tensor, bias, n_row
                            k_parts: int = 1, out: torch.Tensor | None = None) -> torch.Tensor:
     """mode "f32": y [n_rows, out] = x W^T + b; "gelu_planes": planes of gelu(x W^T + b); "parts": [k_parts, n_rows, out] partial sums."""
     _, n_pad, in_features = xs.shape
-    m = {"f32": 0, "gelu_planes": 1, "parts": 2}[mode]
-    if m == 0:
+    m = {"f32": 0, "gelu_planes": 1, "parts": 2, "gelu_f32": 3}[mode]
+    if m in (0, 3):
         y = out if out is not None else torch.empty((n_rows, out_features), dtype=torch.float32, device=xs.device)
     elif m == 1:
         y = out if out is not None else planes_empty(n_rows, out_features, xs.device)
@@ -674,6 +679,43 @@ def linear_bf16x3_presplit(xs: torch.Tensor, a_packed: torch.Tensor, bias, n_row
                                            y.data_ptr() if m != 1 else None, y.data_ptr() if m == 1 else None, n_rows, n_pad,
                                            in_features, out_features, m, k_parts, _stream()), "rvc_linear_bf16x3_presplit")
     return y
+
+
+def hubert_conv0_frames_bf16x3(wav: torch.Tensor, w: torch.Tensor, gamma, beta, eps: float, stride: int = 5) -> tuple[torch.Tensor, int]:
+    """HuBERT's first feature-extractor layer (Conv1d(1, C, 10, stride 5) -> GroupNorm(C, C) -> GELU) of ONE clip wav [n] ->
+    (time-major planes [3, frames_padded, C], frames)."""
+    wav = _dev_f32(wav, "wav")
+    w2 = _dev_f32(w.reshape(w.shape[0], -1), "w")
+    c, taps = w2.shape
+    n = wav.numel()
+    frames = (n - taps) // stride + 1
+    ys = planes_empty(frames, c, wav.device)
+    need = c_size_t()
+    _check(_lib.rvc_hubert_conv0_workspace_bytes(c, ctypes.byref(need)), "rvc_hubert_conv0_workspace_bytes")
+    ws = _ws.get("hubert_conv0", need.value, wav.device)
+    _check(_lib.rvc_hubert_conv0_frames_bf16x3(wav.data_ptr(), n, w2.data_ptr(), c, taps, stride,
+                                               gamma.data_ptr() if gamma is not None else None,
+                                               beta.data_ptr() if beta is not None else None, float(eps), ws.data_ptr(), ws.numel(),
+                                               ys.data_ptr(), ys.shape[1], _stream()), "rvc_hubert_conv0_frames_bf16x3")
+    return ys, frames
+
+
+def conv1d_frames_bf16x3(xs: torch.Tensor, n_frames_in: int, a_packed: torch.Tensor, bias, out_channels: int, taps: int, stride: int,
+                         mode: str = "gelu_planes") -> tuple[torch.Tensor, int]:
+    """nn.Conv1d(C, out, taps, stride, no padding) (+ GELU) over time-major planes xs [3, frames_in_padded, C] ->
+    (planes [3, frames_out_padded, out] or fp32 [frames_out, out], frames_out).  a_packed: gemm_bf16x3_pack_weight of
+    conv.weight.permute(0, 2, 1).reshape(out, taps * C)."""
+    _, n_pad_in, c = xs.shape
+    m = {"f32": 0, "gelu_planes": 1, "gelu_f32": 3}[mode]
+    frames = (n_frames_in - taps) // stride + 1
+    if frames <= 0:
+        raise NativeError("conv1d_frames_bf16x3: the input is shorter than one window")
+    y = planes_empty(frames, out_channels, xs.device) if m == 1 else torch.empty((frames, out_channels), dtype=torch.float32, device=xs.device)
+    _check(_lib.rvc_conv1d_frames_bf16x3(xs.data_ptr(), n_frames_in, n_pad_in, c, taps, stride, a_packed.data_ptr(),
+                                         bias.data_ptr() if bias is not None else None, y.data_ptr() if m != 1 else None,
+                                         y.data_ptr() if m == 1 else None, rows_padded(frames), out_channels, m, _stream()),
+           "rvc_conv1d_frames_bf16x3")
+    return y, frames
 
 
 def bias_residual_layernorm_bf16x3(parts: torch.Tensor, bias, res, gamma, beta, eps: float, want_planes: bool = True,

@@ -30,6 +30,8 @@ class HubertModelWithFinalProj:
         # in eval mode, advancing the CPU generator the Synthesizer's noise comes from afterwards
         self.consume_layerdrop_rng = False
         self.native_min_rows = 900      # frames from which the transformer layers run on K12 (linbf.hip); tests set it to 1
+        self.frame_convs = True         # feature extractor on time-major frames (K13 + K12) for single clips; tests compare both routes
+        self.frame_convs_min_samples = 400   # (the receptive field of one output frame)
         if state_dict is not None:
             self.load_state_dict(state_dict)
 
@@ -51,6 +53,7 @@ class HubertModelWithFinalProj:
                 cw = self.w[f"feature_extractor.conv_layers.{i}.conv.weight"]
                 if cw.shape[0] % 128 == 0 and (cw.shape[1] % 16 == 0 or (cw.shape[1] == 1 and cw.shape[2] <= 16)):
                     self._conv_bf[i] = _native.gemm_bf16x3_pack_weight(cw, self.device)
+        self._pack_frame_convs()
         self._lin = {}   # K12: fragment slabs of the four projections of every layer (device only)
         self._qkv = {}
         for i in range(self.n_layers):
@@ -64,6 +67,38 @@ class HubertModelWithFinalProj:
                                        self.w[L + ".v_proj.bias"]], 0).contiguous(), scale)
         self._pack_linears()
         return self
+
+    def _pack_frame_convs(self):
+        """Feature-extractor layers 1-6 as K12 GEMMs over time-major frames (rvc_conv1d_frames_bf16x3): the slab of
+        W[o][k * C + c] = conv.weight[o][c][k]; layer 0 runs in K13 from its fp32 taps.  One clip at a time (batch 1)."""
+        self._conv_fr = {}
+        if self.device.type != "cuda":
+            return
+        from rvc_amd import _native
+        n = len(CONV_STRIDES)
+        ws = [self.w[f"feature_extractor.conv_layers.{i}.conv.weight"] for i in range(n)]
+        c = ws[0].shape[0]
+        ok = ws[0].shape[1] == 1 and ws[0].shape[2] == 10 and c % 128 == 0 and \
+            all(w.shape[0] == c and w.shape[1] == c and (w.shape[2] * c) % 32 == 0 for w in ws[1:]) and \
+            not any(f"feature_extractor.conv_layers.{i}.conv.bias" in self.w for i in range(n))
+        if not ok:
+            return
+        for i in range(1, n):
+            self._conv_fr[i] = _native.gemm_bf16x3_pack_weight(ws[i].permute(0, 2, 1).reshape(c, -1).contiguous(), self.device)
+
+    def _features_native(self, wav):
+        """conv_layers[0..6] of one clip -> [1, frames, C] fp32, time-major (what feature_projection consumes)."""
+        from rvc_amd import _native as N
+        w = self.w
+        xs, n = N.hubert_conv0_frames_bf16x3(wav[0], w["feature_extractor.conv_layers.0.conv.weight"],
+                                             w["feature_extractor.conv_layers.0.layer_norm.weight"],
+                                             w["feature_extractor.conv_layers.0.layer_norm.bias"], 1e-5, stride=CONV_STRIDES[0])
+        last = len(CONV_STRIDES) - 1
+        for i in range(1, last + 1):
+            cw = w[f"feature_extractor.conv_layers.{i}.conv.weight"]
+            xs, n = N.conv1d_frames_bf16x3(xs, n, self._conv_fr[i], None, cw.shape[0], cw.shape[2], CONV_STRIDES[i],
+                                           "gelu_planes" if i < last else "gelu_f32")
+        return xs[None]
 
     def _pack_linears(self):
         """K12 (linbf.hip) takes the nn.Linear weights as bf16x3 matrix-instruction fragments: q/k/v (fused), attention output,
@@ -88,6 +123,7 @@ class HubertModelWithFinalProj:
         self.w = {k: v.to(self.device) for k, v in self.w.items()}
         self._qkv = {i: (a.to(self.device), b.to(self.device), s) for i, (a, b, s) in self._qkv.items()}
         self._conv_bf = {i: a.to(self.device) for i, a in self._conv_bf.items()} if self.device.type == "cuda" else {}
+        self._pack_frame_convs()
         self._pack_linears()
         return self
 
@@ -103,6 +139,8 @@ class HubertModelWithFinalProj:
     @torch.no_grad()
     def __call__(self, wav: torch.Tensor):
         w = self.w
+        if wav.is_cuda and wav.shape[0] == 1 and self._conv_fr and self.frame_convs and wav.shape[1] >= self.frame_convs_min_samples:
+            return self._encode(self._features_native(wav))
         x = wav[:, None, :]
         for i, s in enumerate(CONV_STRIDES):
             cw = w[f"feature_extractor.conv_layers.{i}.conv.weight"]
@@ -122,7 +160,11 @@ class HubertModelWithFinalProj:
                 x = F.group_norm(x, x.shape[1], w["feature_extractor.conv_layers.0.layer_norm.weight"],
                                  w["feature_extractor.conv_layers.0.layer_norm.bias"], 1e-5)
             x = F.gelu(x)
-        x = x.transpose(1, 2)
+        return self._encode(x.transpose(1, 2))
+
+    def _encode(self, x):
+        """feature_projection + encoder of transformers' HubertModel on [batch, frames, C] features."""
+        w = self.w
         x = F.layer_norm(x, (x.shape[-1],), w["feature_projection.layer_norm.weight"],
                          w["feature_projection.layer_norm.bias"], 1e-5)
         x = F.linear(x, w["feature_projection.projection.weight"], w["feature_projection.projection.bias"])

@@ -415,7 +415,8 @@ int rvc_conv1d_bf16x3(const float *x_dev, const void *a_dev, const float *bias_d
  * rvc_linear_bf16x3_presplit: a_dev = rvc_gemm_bf16x3_pack_weight's slab of the [out][in] weight.  mode 0: y_dev [n_rows][out]
  *   = x W^T + bias; mode 1: ys_dev planes [3][n_rows_padded][out] of gelu(x W^T + bias) (erf form); mode 2: y_dev
  *   [k_parts][n_rows][out] partial sums over k_parts equal slices of in_features (no bias) -- the grid filler for the 768-wide
- *   outputs.  in_features a multiple of 32 (and of 32 k_parts), n_rows_padded a multiple of 128.  One 8-wave workgroup per CU, whole LDS.
+ *   outputs; mode 3: y_dev [n_rows][out] = gelu(x W^T + bias).  in_features a multiple of 32 (and of 32 k_parts), n_rows_padded a
+ *   multiple of 128.  One 8-wave workgroup per CU, whole LDS.
  * rvc_bias_residual_layernorm_bf16x3: y = LayerNorm(sum of the parts + bias + res) * gamma + beta over `features` (256, 768 or 1024),
  *   written as fp32 (y_dev, may be NULL) and as planes (ys_dev, may be NULL): HubertEncoderLayer's `hidden = layer_norm(hidden +
  *   dropout(attn))` / `final_layer_norm(hidden + feed_forward(hidden))` fused with the split-K reduction. */
@@ -426,6 +427,31 @@ int rvc_linear_bf16x3_presplit(const void *xs_dev, const void *a_dev, const floa
 int rvc_bias_residual_layernorm_bf16x3(const float *parts_dev, int n_parts, const float *bias_dev, const float *res_dev,
                                        const float *gamma_dev, const float *beta_dev, float eps, float *y_dev, void *ys_dev,
                                        int64_t n_rows, int64_t n_rows_padded, int features, void *stream);
+
+/* ---- K12 / K13: HuBERT's feature extractor on time-major frames ---------------------------------------------------------------- *
+ * Replaces `transformers`' HubertFeatureEncoder behind rvc/infer/pipeline.py:450 (conv_layers[0] = HubertGroupNormConvLayer:
+ * Conv1d(1, 512, 10, stride 5, bias = False) -> GroupNorm(512, 512) -> GELU; conv_layers[1..6] = HubertNoLayerNormConvLayer:
+ * Conv1d(512, 512, 3 or 2, stride 2, bias = False) -> GELU) for batch 1.  The activations travel TIME-MAJOR, [frame][channel], as
+ * three bf16 planes [split][frames_padded][channels]: the window of a strided conv -- taps x channels values -- is then one
+ * contiguous run starting stride x channels after its predecessor's, i.e. the conv IS K12's GEMM with a different row stride
+ * and needs no im2col, no transposes and no fp32 copy of the 196 MB first-layer output.
+ * rvc_hubert_conv0_frames_bf16x3 (csrc/hubert_front.hip): layer 0 from the 16 kHz samples; the conv is evaluated twice (float64
+ *   statistics over the clip, then normalise + GELU + split) instead of being stored.  w_dev [channels][taps] fp32, taps = 10,
+ *   channels a multiple of 64; workspace of rvc_hubert_conv0_workspace_bytes(channels); ys_dev planes with
+ *   n_frames_padded >= (n_samples - taps) / stride + 1 rows.
+ * rvc_conv1d_frames_bf16x3 (csrc/linbf.hip): xs_dev planes [3][n_frames_in_padded][channels]; a_dev = rvc_gemm_bf16x3_pack_weight's
+ *   slab of the [out][taps * channels] matrix W[o][k * channels + c] = conv.weight[o][c][k]; output frames (n_frames_in - taps) /
+ *   stride + 1; modes 0 / 1 / 3 of rvc_linear_bf16x3_presplit (ys_dev planes [3][n_frames_out_padded][out_channels] or y_dev
+ *   [frames_out][out_channels] fp32).  taps * channels a multiple of 32, stride * channels of 8, out_channels of 128,
+ *   n_frames_out_padded of 128.  Rows of the last 128-frame tile beyond the input are read (inside the planes' allocation, or
+ *   as zeros beyond it) but their results are not stored. */
+int rvc_hubert_conv0_workspace_bytes(int channels, size_t *bytes);
+int rvc_hubert_conv0_frames_bf16x3(const float *wav_dev, int64_t n_samples, const float *w_dev, int channels, int taps, int stride,
+                                   const float *gamma_dev, const float *beta_dev, float eps, void *workspace_dev,
+                                   size_t workspace_bytes, void *ys_dev, int64_t n_frames_padded, void *stream);
+int rvc_conv1d_frames_bf16x3(const void *xs_dev, int64_t n_frames_in, int64_t n_frames_in_padded, int channels, int taps, int stride,
+                             const void *a_dev, const float *bias_dev, float *y_dev, void *ys_dev, int64_t n_frames_out_padded,
+                             int out_channels, int mode, void *stream);
 
 
 #ifdef __cplusplus

@@ -231,6 +231,61 @@ def test_linear_bf16x3_presplit_matches_float64(native, dev, n_rows, k, m, mode,
         assert (plain.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("frames_in,c,taps,stride,m,mode", [
+    (95999, 512, 3, 2, 512, "gelu_planes"), (2999, 512, 2, 2, 512, "gelu_f32"), (11999, 512, 3, 2, 512, "gelu_planes"),
+    (131, 64, 3, 2, 128, "f32"), (3, 512, 3, 2, 512, "gelu_f32"), (257, 128, 2, 1, 256, "gelu_planes"), (1000, 32, 5, 3, 128, "f32"),
+])
+def test_conv1d_frames_bf16x3_matches_float64(native, dev, frames_in, c, taps, stride, m, mode):
+    """K12 as a strided conv over TIME-MAJOR frames (rvc_conv1d_frames_bf16x3: HuBERT's feature-extractor layers 1-6,
+    `transformers` HubertNoLayerNormConvLayer behind pipeline.py:450): the window of output frame t is the contiguous run of
+    taps x channels values starting at frame t * stride.  Against float64 F.conv1d on the channel-major tensor; the error level of
+    torch's fp32 conv on the same operands.  The 30 s clip's first and sixth layers, a clip of one output frame, odd shapes."""
+    g = torch.Generator().manual_seed(frames_in + c + taps)
+    x = torch.randn(frames_in, c, generator=g)                       # [frame][channel]
+    w = torch.randn(m, c, taps, generator=g) * (c * taps) ** -0.5
+    b = torch.randn(m, generator=g)
+    xd = x.to(dev)
+    xs = native.split_rows_bf16x3(xd)
+    a = native.gemm_bf16x3_pack_weight(w.permute(0, 2, 1).reshape(m, -1).contiguous(), dev)
+    ref = F.conv1d(x.t().double()[None], w.double(), b.double(), stride=stride)[0].t()       # [frames_out][m]
+    lib = F.conv1d(xd.t()[None], w.to(dev), b.to(dev), stride=stride)[0].t().cpu()
+    if mode != "f32":
+        ref, lib = F.gelu(ref), F.gelu(lib)
+    y, n_out = native.conv1d_frames_bf16x3(xs, frames_in, a, b.to(dev), m, taps, stride, mode)
+    assert n_out == ref.shape[0] == (frames_in - taps) // stride + 1
+    got = (y[:, :n_out].float().sum(0) if mode == "gelu_planes" else y).cpu()
+    assert got.shape == ref.shape
+    rel = lambda t, r: ((t.double() - r).pow(2).mean().sqrt() / r.pow(2).mean().sqrt()).item()
+    err = (got.double() - ref).abs().max().item()
+    print(f"conv over frames [{frames_in} x {c}] k{taps} s{stride} -> {m} ({mode}): max abs err {err:.2e}, rel rms {rel(got, ref):.2e} (torch fp32 {rel(lib, ref):.2e})")
+    assert err <= 2e-5 * ref.abs().max().item()
+    assert rel(got, ref) <= max(1.5 * rel(lib, ref), 6e-7)      # (one output frame = 512 values: the ratio is noisy there)
+    y2, _ = native.conv1d_frames_bf16x3(xs, frames_in, a, b.to(dev), m, taps, stride, mode)
+    assert torch.equal(y2[:, :n_out] if mode == "gelu_planes" else y2, y[:, :n_out] if mode == "gelu_planes" else y)
+
+
+@pytest.mark.parametrize("n_samples", [480000, 16000, 410, 47999])
+def test_hubert_conv0_frames_matches_float64(native, dev, n_samples):
+    """K13 (hubert_front.hip): Conv1d(1, 512, 10, stride 5, no bias) -> GroupNorm(512, 512) -> GELU (transformers'
+    HubertGroupNormConvLayer behind pipeline.py:450) written as time-major bf16x3 planes.  Against the float64 graph; the error level
+    of torch's fp32 graph on the same input.  30 s, 1 s, a clip of 81 frames, an odd length."""
+    g = torch.Generator().manual_seed(n_samples)
+    wav = torch.randn(n_samples, generator=g) * 0.3
+    w = torch.randn(512, 1, 10, generator=g) * 0.4
+    gamma, beta = torch.randn(512, generator=g), torch.randn(512, generator=g)
+    ref = F.gelu(F.group_norm(F.conv1d(wav.double()[None, None], w.double(), stride=5), 512, gamma.double(), beta.double(), 1e-5))[0].t()
+    wd = wav.to(dev)
+    lib = F.gelu(F.group_norm(F.conv1d(wd[None, None], w.to(dev), stride=5), 512, gamma.to(dev), beta.to(dev), 1e-5))[0].t().cpu()
+    ys, frames = native.hubert_conv0_frames_bf16x3(wd, w.to(dev), gamma.to(dev), beta.to(dev), 1e-5, stride=5)
+    assert frames == ref.shape[0] and ys.shape[1] % 128 == 0 and ys.shape[1] >= frames
+    got = ys[:, :frames].float().sum(0).cpu()
+    err, err_lib = (got.double() - ref).abs().max().item(), (lib.double() - ref).abs().max().item()
+    print(f"HuBERT layer 0 on {n_samples} samples: max abs err vs float64 {err:.2e} (torch fp32 graph: {err_lib:.2e})")
+    assert err <= max(2.0 * err_lib, 2e-6 * ref.abs().max().item())
+    ys2, _ = native.hubert_conv0_frames_bf16x3(wd, w.to(dev), gamma.to(dev), beta.to(dev), 1e-5, stride=5)
+    assert torch.equal(ys2[:, :frames], ys[:, :frames])
+
+
 @pytest.mark.parametrize("n_rows,k,m,act,with_res", [
     (1599, 768, 2304, "none", False), (1599, 768, 768, "none", True), (1599, 768, 3072, "gelu", False),
     (1599, 3072, 768, "none", True), (149, 768, 768, "gelu", True), (1, 512, 768, "none", False), (130, 16, 128, "none", False),
