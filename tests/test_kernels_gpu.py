@@ -247,7 +247,7 @@ def test_conv1d_frames_bf16x3_matches_float64(native, dev, frames_in, c, taps, s
     xd = x.to(dev)
     xs = native.split_rows_bf16x3(xd)
     a = native.gemm_bf16x3_pack_weight(w.permute(0, 2, 1).reshape(m, -1).contiguous(), dev)
-    ref = F.conv1d(x.t().double()[None], w.double(), b.double(), stride=stride)[0].t()       # [frames_out][m]
+    ref = conv1d_f64(x.t()[None], w, b, stride=stride)[0].t()                                # [frames_out][m], float64 on the host
     lib = F.conv1d(xd.t()[None], w.to(dev), b.to(dev), stride=stride)[0].t().cpu()
     if mode != "f32":
         ref, lib = F.gelu(ref), F.gelu(lib)

@@ -51,5 +51,20 @@ for i, (k, s) in enumerate(((3, 2), (3, 2), (3, 2), (3, 2), (2, 2), (2, 2))):
     own = timed(lambda: _native.conv1d_bf16x3(x, a, None, 512, k, stride=s, act="gelu"))
     Lo = (L - k) // s + 1
     gf = 2.0 * 512 * 512 * k * Lo / 1e9
-    print(f"conv layer {i + 1} 512->512 k {k} s {s} L {L:6d}: torch fp32 conv + gelu {lib*1e3:7.1f} us ({gf/lib:6.1f} TF/s) | bf16x3 {own*1e3:7.1f} us ({gf/own:6.1f} TF/s fp32-equivalent) x{lib/own:.2f}", flush=True)
+    # K12 over time-major frames (rvc_conv1d_frames_bf16x3): planes in, GELU + planes out
+    xs = _native.split_rows_bf16x3(x[0].t().contiguous())
+    af = _native.gemm_bf16x3_pack_weight(w.permute(0, 2, 1).reshape(512, -1).contiguous(), dev)
+    fr = timed(lambda: _native.conv1d_frames_bf16x3(xs, L, af, None, 512, k, s, "gelu_planes"))
+    print(f"conv layer {i + 1} 512->512 k {k} s {s} L {L:6d}: torch fp32 conv + gelu {lib*1e3:7.1f} us ({gf/lib:6.1f} TF/s) | K11 channel-major {own*1e3:7.1f} us ({gf/own:6.1f} TF/s fp32-equivalent) x{lib/own:.2f}"
+          f" | K12 over time-major frames {fr*1e3:7.1f} us ({gf/fr:6.1f} TF/s fp32-equivalent, {6*gf/fr:6.1f} on the bf16 pipe) x{lib/fr:.2f}", flush=True)
     L = Lo
+# layer 0: conv + GroupNorm + GELU
+wav = torch.randn(1, 1, 512000, device=dev) * 0.3
+w0 = torch.randn(512, 1, 10, device=dev) * 0.4
+gam = torch.randn(512, device=dev)
+a0 = _native.gemm_bf16x3_pack_weight(w0, dev)
+lib0 = timed(lambda: F.gelu(F.group_norm(F.conv1d(wav, w0, None, stride=5), 512, gam, gam, 1e-5)))
+old0 = timed(lambda: _native.rownorm_gelu_(_native.conv1d_bf16x3(wav, a0, None, 512, 10, stride=5, act="none"), gam, gam, 1e-5))
+new0 = timed(lambda: _native.hubert_conv0_frames_bf16x3(wav[0, 0], w0, gam, gam, 1e-5, stride=5))
+print(f"layer 0 (conv 1->512 k 10 s 5 + GroupNorm + GELU) on 512000 samples: torch {lib0*1e3:7.1f} us | K11 + K8 (channel-major fp32) {old0*1e3:7.1f} us | "
+      f"K13 (time-major planes, conv evaluated twice) {new0*1e3:7.1f} us", flush=True)
