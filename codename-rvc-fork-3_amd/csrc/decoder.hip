@@ -271,51 +271,78 @@ cond_bias_kernel(const float *__restrict__ pre_b, const float *__restrict__ cond
 }
 
 // out[b][t] = tanh(bias + sum_{ci,k} w[ci][k] * leaky(x[b][ci][t + k - 3], slope))   (hifigan_nsf.py:204-205)
-// One lane = 4 consecutive outputs: per input channel three aligned 16-byte loads cover x[t-4 .. t+7] (unconditional:
-// loads inside divergent bounds checks are waited for one by one), 28 FMAs.  Blocks that touch either end of the
-// signal, and lengths that are not a multiple of 4, take the scalar path.
+// One lane = 4 consecutive outputs: per input channel three aligned 16-byte loads cover x[t-4 .. t+7] (unconditional: loads inside
+// divergent bounds checks are waited for one by one), 28 FMAs; four channels' loads are requested before the first is used.
+// (8 outputs per lane -- lanes 32 bytes apart, four half-coalesced loads per channel -- measured 262 us against 125.)  Blocks that
+// touch either end of the signal, and lengths that are not a multiple of 4, take the scalar path.  The sums run channel by channel,
+// tap by tap, in both paths.
+constexpr int POST_OUT = 4;      // outputs per lane
 __global__ void __launch_bounds__(256)
 conv_post_kernel(const float *__restrict__ x, const float *__restrict__ w, float bias, int c_in, int64_t L, float slope,
                  float *__restrict__ out) {
     const int64_t b = blockIdx.y;
-    const int64_t t0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    const int64_t blk0 = (int64_t)blockIdx.x * blockDim.x * 4;
+    const int64_t t0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * POST_OUT;
+    const int64_t blk0 = (int64_t)blockIdx.x * blockDim.x * POST_OUT;
     const float *xb = x + b * c_in * L;
-    const bool fast = (L & 3) == 0 && blk0 >= 4 && blk0 + (int64_t)blockDim.x * 4 + 4 <= L;   // block-uniform
+    const bool fast = (L & 3) == 0 && (c_in & 3) == 0 && blk0 >= 4 && blk0 + (int64_t)blockDim.x * POST_OUT + 4 <= L;   // block-uniform
     if (fast) {
-        f32x4 acc = {bias, bias, bias, bias};
-        for (int ci = 0; ci < c_in; ++ci) {
-            const f32x4 *xr = reinterpret_cast<const f32x4 *>(xb + (int64_t)ci * L + t0 - 4);
-            const f32x4 a = xr[0], m = xr[1], c = xr[2];
-            float v[12] = {a[0], a[1], a[2], a[3], m[0], m[1], m[2], m[3], c[0], c[1], c[2], c[3]};
+        float acc[POST_OUT];
 #pragma unroll
-            for (int i = 1; i < 11; ++i) v[i] = lrelu(v[i], slope);
+        for (int o = 0; o < POST_OUT; ++o) acc[o] = bias;
+        for (int c0 = 0; c0 < c_in; c0 += 4) {
+            f32x4 q[4][3];
 #pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                const float wk = w[ci * 7 + k];
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 *xr = reinterpret_cast<const f32x4 *>(xb + (int64_t)(c0 + u) * L + t0 - 4);
 #pragma unroll
-                for (int o = 0; o < 4; ++o) acc[o] = fmaf(wk, v[o + k + 1], acc[o]);
+                for (int j = 0; j < 3; ++j) q[u][j] = xr[j];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float v[12];
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * j + e] = q[u][j][e];
+#pragma unroll
+                for (int i = 1; i < 11; ++i) v[i] = lrelu(v[i], slope);
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    const float wk = w[(c0 + u) * 7 + k];
+#pragma unroll
+                    for (int o = 0; o < POST_OUT; ++o) acc[o] = fmaf(wk, v[o + k + 1], acc[o]);
+                }
             }
         }
-        f32x4 r = {tanhf(acc[0]), tanhf(acc[1]), tanhf(acc[2]), tanhf(acc[3])};
-        *reinterpret_cast<f32x4 *>(out + b * L + t0) = r;
+        *reinterpret_cast<f32x4 *>(out + b * L + t0) = f32x4{tanhf(acc[0]), tanhf(acc[1]), tanhf(acc[2]), tanhf(acc[3])};
         return;
     }
-    for (int o = 0; o < 4; ++o) {
-        const int64_t t = t0 + o;
-        if (t >= L) return;
-        float acc = bias;
-        for (int ci = 0; ci < c_in; ++ci) {
-            const float *xr = xb + (int64_t)ci * L;
+    // edge blocks / odd lengths: the same sums from clamped, unconditional scalar loads (a load behind a per-element bounds check is
+    // waited for on its own: 896 serial round trips per lane made these two blocks most of the launch's duration)
+    if (t0 >= L) return;
+    float acc[POST_OUT];
 #pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                const int64_t tt = t + k - 3;
-                const float v = (tt >= 0 && tt < L) ? lrelu(xr[tt], slope) : 0.f;
-                acc = fmaf(w[ci * 7 + k], v, acc);
-            }
+    for (int o = 0; o < POST_OUT; ++o) acc[o] = bias;
+    for (int ci = 0; ci < c_in; ++ci) {
+        const float *xr = xb + (int64_t)ci * L;
+        float v[POST_OUT + 6];
+#pragma unroll
+        for (int i = 0; i < POST_OUT + 6; ++i) {
+            const int64_t tt = t0 + i - 3;
+            const int64_t tc = tt < 0 ? 0 : (tt >= L ? L - 1 : tt);
+            const float raw = xr[tc];
+            v[i] = (tt >= 0 && tt < L) ? lrelu(raw, slope) : 0.f;
         }
-        out[b * L + t] = tanhf(acc);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const float wk = w[ci * 7 + k];
+#pragma unroll
+            for (int o = 0; o < POST_OUT; ++o) acc[o] = fmaf(wk, v[o + k], acc[o]);
+        }
     }
+#pragma unroll
+    for (int o = 0; o < POST_OUT; ++o)
+        if (t0 + o < L) out[b * L + t0 + o] = tanhf(acc[o]);
 }
 
 int launch_unfold_src(const float *har, int batch, int64_t L, int64_t S, int64_t P, int k_valid, int k_rows, int64_t nq, float *V,
@@ -335,7 +362,7 @@ int launch_cond_bias(const float *pre_b, const float *cond_w, const float *cond_
 
 int launch_conv_post(const float *x, const float *w, float bias, int batch, int c_in, int64_t L, float slope, float *out,
                      hipStream_t stream) {
-    hipLaunchKernelGGL(conv_post_kernel, dim3((unsigned)ceil_div(L, 1024), batch), dim3(256), 0, stream, x, w, bias, c_in, L, slope,
+    hipLaunchKernelGGL(conv_post_kernel, dim3((unsigned)ceil_div(L, 256 * POST_OUT), batch), dim3(256), 0, stream, x, w, bias, c_in, L, slope,
                        out);
     RVC_LAUNCH_CHECK();
     return 0;
