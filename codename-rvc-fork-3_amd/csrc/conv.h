@@ -34,6 +34,7 @@ struct ConvParams {
     int64_t l_out = 0;
     int kw = 1, dil = 1, padl = 0;
     int up_stride = 0, up_pad = 0;
+    int up_interleave = 0;   // polyphase rows ordered (channel, phase) instead of (phase, channel): even up_stride only -- a lane's neighbouring phases of one channel are 8 (rate % 4: 16) contiguous bytes of the output
     float out_scale = 1.f;
     int batch = 1;
     const uint32_t *w_wino16 = nullptr;   // ... stored as bf16 pairs (with w16)

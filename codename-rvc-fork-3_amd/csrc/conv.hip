@@ -307,6 +307,51 @@ conv_mfma_kernel(const ConvParams p) {
         const float out_scale = p.out_scale;
         const int64_t cbase = col0 + wn * NT * 32 + l31;
         const float *bsrc = bias ? bias : p.w;  // always a valid address: the loads below stay unconditional
+        if (p.up_interleave) {
+            // rows = (channel, phase), phase innermost, even rate: registers r, r + 1 of a lane (r even) are two neighbouring phases
+            // of one channel at one input column, i.e. outputs t, t + 1 -- one 8-byte store; with rate % 4 == 0 the four
+            // registers of a group are four neighbouring phases -- one 16-byte store.  (The (phase, channel) order below writes
+            // single floats `rate` floats apart and comes back for the gaps rate - 1 times.)
+            typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+            const bool quad = (up_stride & 3) == 0;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int row = m0 + wm * MT * 32 + m * 32 + mfma32_row(r, lane);
+                    const int co = row / up_stride, ph = row - co * up_stride;
+                    float bv = bsrc[co];
+                    bv = bias ? bv : 0.f;
+                    float *q = y + (int64_t)co * l_out + ph - up_pad;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int64_t col = cbase + n * 32;
+                        const int64_t t = col * up_stride + ph - up_pad;
+                        const float v0 = (acc[m][n][r] + bv) * out_scale, v1 = (acc[m][n][r + 1] + bv) * out_scale;
+                        if (col >= n_cols) continue;
+                        if (quad) {
+                            if ((r & 2) == 0) {
+                                const float v2 = (acc[m][n][r + 2] + bv) * out_scale, v3 = (acc[m][n][r + 3] + bv) * out_scale;
+                                if (t >= 0 && t + 3 < l_out) {
+                                    *reinterpret_cast<f32x4u *>(q + col * up_stride) = f32x4u{v0, v1, v2, v3};
+                                } else {
+                                    const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        if (t + e >= 0 && t + e < l_out) q[col * up_stride + e] = vv[e];
+                                }
+                            }
+                        } else if (t >= 0 && t + 1 < l_out) {
+                            *reinterpret_cast<f32x2u *>(q + col * up_stride) = f32x2u{v0, v1};
+                        } else {
+                            if (t >= 0 && t < l_out) q[col * up_stride] = v0;
+                            if (t + 1 >= 0 && t + 1 < l_out) q[col * up_stride + 1] = v1;
+                        }
+                    }
+                }
+            return;
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll

@@ -52,6 +52,7 @@ struct ConvW {
 struct Stage {
     int c_in = 0, c_out = 0, rate = 0, ksize = 0, pad = 0, opad = 0;
     int taps = 0;                 // polyphase taps J = ceil(k / rate)
+    bool interleave = false;      // GEMM rows ordered (channel, phase): even rates
     int nc_stride = 0, nc_k = 0, nc_pad = 0;
     int vk = 0, vk_rows = 0;      // folded noise-conv rows: valid, padded to a multiple of 8
     int64_t S = 0, P = 0;         // V[k][q] = har[q*S + k - P]

@@ -557,6 +557,9 @@ extern "C" int rvc_decoder_finalize(rvc_decoder *d) {
         // as GEMM taps with dil = 1, padl = taps-1: tap' = taps-1-j.  Noise rows only on the offset-0 tap.
         const int ctot = s.c_in + s.vk_rows;
         const int m_total = s.rate * s.c_out;
+        // GEMM row of (phase, channel): phase-major, or channel-major for even rates (ConvParams::up_interleave: 8- / 16-byte output stores)
+        s.interleave = s.rate % 2 == 0;
+        auto mrow = [&](int ph, int co) { return s.interleave ? co * s.rate + ph : ph * s.c_out + co; };
         std::vector<float> packed((size_t)s.taps * ctot * m_total, 0.f);
         for (int tp = 0; tp < s.taps; ++tp) {
             const int j = s.taps - 1 - tp;
@@ -565,7 +568,7 @@ extern "C" int rvc_decoder_finalize(rvc_decoder *d) {
                     const int kk = ph + j * s.rate;
                     if (kk >= s.ksize) continue;
                     for (int co = 0; co < s.c_out; ++co)
-                        packed[((size_t)tp * ctot + ci) * m_total + ph * s.c_out + co] =
+                        packed[((size_t)tp * ctot + ci) * m_total + mrow(ph, co)] =
                             uw->data[((size_t)ci * s.c_out + co) * s.ksize + kk];
                 }
         }
@@ -575,7 +578,7 @@ extern "C" int rvc_decoder_finalize(rvc_decoder *d) {
                 const int k = kq - ph * s.nc_stride;
                 if (k < 0 || k >= s.nc_k) continue;
                 for (int co = 0; co < s.c_out; ++co)
-                    packed[((size_t)tp0 * ctot + s.c_in + kq) * m_total + ph * s.c_out + co] = nw->data[(size_t)co * s.nc_k + k];
+                    packed[((size_t)tp0 * ctot + s.c_in + kq) * m_total + mrow(ph, co)] = nw->data[(size_t)co * s.nc_k + k];
             }
         if (s.w.upload(packed)) return 1;
         if (s.nc_rows) {
@@ -841,7 +844,7 @@ extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const flo
             p.y = X; p.y_bstride = (int64_t)s.c_out * len_out;
             p.m_total = s.rate * s.c_out; p.c_out = s.c_out; p.n_cols = nq; p.l_out = len_out;
             p.kw = s.taps; p.dil = 1; p.padl = s.taps - 1;
-            p.up_stride = s.rate; p.up_pad = s.pad; p.batch = batch;
+            p.up_stride = s.rate; p.up_pad = s.pad; p.up_interleave = s.interleave ? 1 : 0; p.batch = batch;
             p.l_in2 = nq;
             if (launch_conv(p, stream)) return 1;
         }
