@@ -18,15 +18,19 @@ namespace rvc {
 // ----------------------------------------------------------------------------------------------------------
 
 // hifigan.py:172-177: carry[i] = fmod(cumsum_{i' < i}(fmod(f0[i']/sr*upp + 0.5, 1) - 0.5), 1).
-// torch's CPU cumsum accumulates in double and rounds every prefix to float; so does this.
-// The double prefix must be added in index order to round like the reference, so one lane adds -- but only adds:
-// the per-frame terms are computed by the whole block into LDS first, and the float conversion + fmod of every
-// prefix is done by the whole block afterwards (0.86 ms as a plain sequential loop over global memory, ~0.02 ms so).
+// torch's CPU cumsum accumulates in double and rounds every prefix to float; so does this.  The double prefix needs no particular
+// order: every term fmodf(x + 0.5f, 1) - 0.5f with x >= 0 is a multiple of 2^-24 of magnitude <= 0.5 (x + 0.5f >= 0.5 has an ulp
+// >= 2^-24; fmodf and the subtraction are exact), so any partial sum of fewer than 2^28 terms is exact in double and a parallel scan
+// gives the bits of the sequential sum.  Three steps per chunk of 4096 frames: each thread sums its own 16 consecutive terms,
+// thread 0 scans the 256 totals, each thread adds its offset.  (One lane adding all 3198 terms in order took 43 us at the very
+// front of the vocoder, with the whole chip waiting; a plain loop over global memory 0.86 ms.)
 constexpr int CARRY_CHUNK = 4096;
 __global__ void __launch_bounds__(256)
 nsf_carry_kernel(const float *__restrict__ f0, int64_t T, float sr, float upp, float *__restrict__ carry) {
     __shared__ double pre[CARRY_CHUNK];
+    __shared__ double part[257];
     __shared__ double cum_s;
+    constexpr int SEG = CARRY_CHUNK / 256;
     const int64_t b = blockIdx.x;
     const float *f = f0 + b * T;
     float *c = carry + b * T;
@@ -41,25 +45,26 @@ nsf_carry_kernel(const float *__restrict__ f0, int64_t T, float sr, float upp, f
             pre[i] = (double)__fsub_rn(fmodf(__fadd_rn(last, 0.5f), 1.0f), 0.5f);
         }
         __syncthreads();
+        const int lo = threadIdx.x * SEG, hi = lo + SEG < n ? lo + SEG : n;
+        double run = 0.0;
+        for (int i = lo; i < hi; ++i) {
+            run += pre[i];
+            pre[i] = run;
+        }
+        part[threadIdx.x + 1] = run;
+        __syncthreads();
         if (threadIdx.x == 0) {
             double cum = cum_s;
-            int i = 0;
-            for (; i + 8 <= n; i += 8) {
-                double v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = pre[i + j];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    cum += v[j];
-                    pre[i + j] = cum;
-                }
-            }
-            for (; i < n; ++i) {
-                cum += pre[i];
-                pre[i] = cum;
+            part[0] = cum;
+            for (int i = 1; i <= 256; ++i) {
+                cum += part[i];
+                part[i] = cum;
             }
             cum_s = cum;
         }
+        __syncthreads();
+        const double off = part[threadIdx.x];
+        for (int i = lo; i < hi; ++i) pre[i] += off;
         __syncthreads();
         for (int i = threadIdx.x; i < n; i += 256) c[base + i + 1] = fmodf((float)pre[i], 1.0f);
         __syncthreads();
