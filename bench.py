@@ -90,7 +90,7 @@ def parse_args(argv=None):
     ap.add_argument("--inflight", type=int, default=2, help="utterances in flight per GPU, each on its own HIP stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--vocoder-side-streams", type=int, default=None,
-                    help="A/B: side streams the vocoder spreads a stage's ResBlock branches over (0 = every launch on the utterance's stream)")
+                    help="A/B: side streams the vocoder spreads a short stage's ResBlock branches over (default 0 = every launch on the utterance's stream; -1 = one per branch)")
     ap.add_argument("--no-rooflines", action="store_true", help="skip the per-kernel roofline legs (timed region only)")
     ap.add_argument("--cpu-seconds", type=float, default=None,
                     help="clip length of the CPU-baseline sample (default: the config's own clip length, i.e. the same "
@@ -248,7 +248,7 @@ def main():
     vc.load_checkpoint_dict(cpt)
     vc.load_hubert_state_dict(S.make_hubert_state_dict(1))
     vc.vc.load_rmvpe_state_dict(S.make_rmvpe_state_dict(0))
-    vc.branch_streams = args.vocoder_side_streams   # None: convert_batch decides (side streams only with one utterance at a time)
+    vc.branch_streams = args.vocoder_side_streams or 0
     index_dev, bcast = None, {}
     if cfg["index_rows"] > 0:
         big = None

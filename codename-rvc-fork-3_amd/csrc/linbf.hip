@@ -186,6 +186,52 @@ linbf_kernel(const LinBfParams p) {
     }
 
     // ---- epilogue: lane (frame n, features 4 half + 8 rg + 0..3 of each 32-row block) ------------------------------------------
+    if (p.mode == 1) {
+        // planes: a lane's four features of a register group are 8 bytes of a plane row; written as such, a row's 64-byte line is
+        // touched by eight 8-byte stores and the big layers' dirty partial lines leave L2 before they are complete (PMC: 490 MB
+        // written for 157 MB of planes on the feature extractor's first layer).  The two half-waves hold neighbouring feature
+        // quads of the SAME frames, so they swap one quad per register-group pair and each lane stores 16 bytes; the two lanes
+        // of a frame then cover 32 contiguous bytes in one instruction.
+        const int64_t n = n0 + nrow;
+        const bool live = n < p.N;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int mb = m0 + wm * 32 * MI + mi * 32;
+#pragma unroll
+            for (int rp = 0; rp < 2; ++rp) {                // register groups 2 rp (features 16 rp + 0..7), 2 rp + 1 (16 rp + 8..15)
+                lbf_f32x2 v[2][2];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    f32x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = acc[mi][4 * (2 * rp + g) + r];
+                    if (p.bias) o += *reinterpret_cast<const f32x4 *>(p.bias + mb + 4 * half + 8 * (2 * rp + g));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = 0.5f * o[r] * (1.f + erff(o[r] * 0.70710678118654752f));
+                    v[g][0] = lbf_f32x2{o[0], o[1]};
+                    v[g][1] = lbf_f32x2{o[2], o[3]};
+                }
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) {
+                    unsigned w[2][2];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            w[g][h] = __builtin_bit_cast(unsigned, __builtin_convertvector(v[g][h], lbf_bf16x2));
+                            v[g][h] = v[g][h] - lbf_f32x2{__uint_as_float(w[g][h] << 16), __uint_as_float(w[g][h] & 0xffff0000u)};
+                        }
+                    // half 0 keeps group 2 rp and receives the partner's quad of it; half 1 keeps group 2 rp + 1
+                    const unsigned s0 = half ? w[0][0] : w[1][0], s1 = half ? w[0][1] : w[1][1];
+                    const unsigned r0 = (unsigned)__shfl_xor((int)s0, 32, 64), r1 = (unsigned)__shfl_xor((int)s1, 32, 64);
+                    const lbf_u32x4 out = half ? lbf_u32x4{r0, r1, w[1][0], w[1][1]} : lbf_u32x4{w[0][0], w[0][1], r0, r1};
+                    const int m = mb + 16 * rp + 8 * half;
+                    if (live) *reinterpret_cast<lbf_u32x4 *>(reinterpret_cast<unsigned char *>(p.ys) + (((int64_t)sp * p.n_pad + n) * p.M + m) * 2) = out;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int64_t n = n0 + nrow;
@@ -206,22 +252,10 @@ linbf_kernel(const LinBfParams p) {
                 *reinterpret_cast<f32x4 *>(p.y + n * p.M + m) = o;
                 continue;
             }
-            // GELU (erf form, what torch.nn.functional.gelu computes), then the exact three-way split of the four values
+            // mode 3: GELU (erf form, what torch.nn.functional.gelu computes) -> fp32
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = 0.5f * o[r] * (1.f + erff(o[r] * 0.70710678118654752f));
-            if (p.mode == 3) {
-                *reinterpret_cast<f32x4 *>(p.y + n * p.M + m) = o;
-                continue;
-            }
-            lbf_f32x2 v0 = {o[0], o[1]}, v1 = {o[2], o[3]};
-#pragma unroll
-            for (int sp = 0; sp < 3; ++sp) {
-                const unsigned w0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, lbf_bf16x2));
-                const unsigned w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, lbf_bf16x2));
-                *reinterpret_cast<lbf_u32x2 *>(reinterpret_cast<unsigned char *>(p.ys) + (((int64_t)sp * p.n_pad + n) * p.M + m) * 2) = lbf_u32x2{w0, w1};
-                v0 = v0 - lbf_f32x2{__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u)};
-                v1 = v1 - lbf_f32x2{__uint_as_float(w1 << 16), __uint_as_float(w1 & 0xffff0000u)};
-            }
+            *reinterpret_cast<f32x4 *>(p.y + n * p.M + m) = o;
         }
     }
 }

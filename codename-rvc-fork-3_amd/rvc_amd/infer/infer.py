@@ -46,7 +46,7 @@ class VoiceConverter:
         self.use_f0 = None
         self.loaded_model = None
         self.dec_weight_dtype = "f32"   # "bf16": the vocoder's conv weights are stored as bf16 in HBM (BASELINE cfg 4)
-        self.branch_streams = None      # None: convert_batch decides (side streams only with one utterance at a time); an int pins Decoder.set_branch_parallel
+        self.branch_streams = 0         # Decoder.set_branch_parallel for convert_batch: 0 = every vocoder launch on the utterance's stream, -1 = one side stream per ResBlock branch
 
     # ---- embedder (infer.py:64-74; file layout rvc/lib/utils.py:96-146) ----
     def load_hubert(self, embedder_model: str, embedder_model_custom: str = None):
@@ -220,9 +220,10 @@ class VoiceConverter:
                 errors.append(error)
 
         self.net_g.dec.set_concurrency_hint(n_workers)   # per decoder handle: other converters in the process are unaffected
-        # one utterance at a time: nothing else fills the CUs a short vocoder stage leaves idle, so its ResBlock branches run side
-        # by side (-0.3 ms of 32.9 per 30 s utterance; with two in flight it measures level or worse: profiles/r05_branch_streams.txt)
-        self.net_g.dec.set_branch_parallel((-1 if n_workers == 1 else 0) if self.branch_streams is None else self.branch_streams)
+        # ResBlock branches of the vocoder's short stages on side streams: opt-in (self.branch_streams = -1).  It shortens ONE
+        # forward at a time (-0.3 ms of 32.9 per 30 s utterance) and is level or worse with two in flight; off by default also because
+        # side-by-side launches make a kernel's traced duration contain the time it shares the chip (profiles/r05_branch_streams.txt)
+        self.net_g.dec.set_branch_parallel(self.branch_streams or 0)
         threads = [threading.Thread(target=work, args=(t,)) for t in range(n_workers)]
         try:
             for t in threads:

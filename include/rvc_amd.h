@@ -277,7 +277,8 @@ int rvc_decoder_set_concurrency_hint(rvc_decoder *dec, int utterances_in_flight)
  * streams owned by the handle, each branch's last launch adding into the running sum after its predecessor's; the caller's
  * stream waits for the last one, so the call is ordered on `stream` exactly as before and results are bit-identical.
  * Default 0 (every launch on the caller's stream): one forward on an idle device gets 5 % (30 s) to 27 % (3 s) shorter, a
- * pipeline that already keeps two utterances in flight does not (profiles/r05_branch_streams.txt).
+ * pipeline that already keeps two utterances in flight does not, and traced kernel durations then contain the time the branches
+ * share the chip (profiles/r05_branch_streams.txt).
  * Changes the workspace size (every stream owns two ping-pong buffers): query rvc_decoder_workspace_bytes afterwards. */
 int rvc_decoder_set_branch_parallel(rvc_decoder *dec, int side_streams);
 

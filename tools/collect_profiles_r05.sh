@@ -7,6 +7,7 @@ O=$R/gpurun_out/r05p; P=$R/gpurun_out/r05p/profiles; mkdir -p $O $P
 python3 $R/bench.py --config 2 --steps 8 --warmup 2 > $O/bench_cfg2.json 2> $O/bench_cfg2.err
 for c in 1 4 5; do python3 $R/bench.py --config $c --steps 8 --warmup 2 --cpu-seconds 3 > $O/bench_cfg$c.json 2> $O/bench_cfg$c.err; done
 python3 $R/bench.py --config 2 --steps 8 --warmup 2 --inflight 1 --no-cpu-baseline > $O/bench_cfg2_inflight1.json 2>/dev/null
+(cd $R && timeout 300 python3 tools/ab_branch.py 2>&1 | grep -v amdgpu.ids) > $O/ab_branch.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o b -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
 cp /tmp/pb/b_kernel_stats.csv $O/bench_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb1 -o b -- python3 $R/bench.py --steps 5 --warmup 2 --inflight 1 --no-cpu-baseline > $O/bench_under_rocprof_inflight1.log 2>&1
@@ -27,6 +28,10 @@ python3 $R/tools/summarize_pmc.py /tmp/pf/f_counter_collection.csv /tmp/pw/w_cou
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/rf -o f -- python3 $R/tools/pmc_rbf.py > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/rw -o w -- python3 $R/tools/pmc_rbf.py > /dev/null 2>&1
 python3 $R/tools/summarize_pmc_rbf.py /tmp/rf/f_counter_collection.csv /tmp/rw/w_counter_collection.csv $P/pmc_resblock_bf.json > $O/pmc_resblock_bf.txt 2>&1
+# ... of HuBERT's feature extractor on time-major frames (K13, K12 with a row stride)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/hf -o f -- python3 $R/tools/pmc_hubert_front.py > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/hw -o w -- python3 $R/tools/pmc_hubert_front.py > /dev/null 2>&1
+python3 $R/tools/summarize_pmc_front.py /tmp/hf/f_counter_collection.csv /tmp/hw/w_counter_collection.csv > $O/pmc_hubert_front.txt 2>&1
 # SQ counters of the roofline kernel (derived pipe-busy figure next to the raw ones)
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pc -o c -- python3 $R/tools/pmc_conv.py > /dev/null 2>&1
 python3 - > $O/sq_winobf2.txt <<'PY'
