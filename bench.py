@@ -428,12 +428,27 @@ def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev, utterance):
 
     # ---- dominant kernel symbol: the 11-tap ResBlock convs of stages 0-2 ----
     run_mix, mix_flops, mix_launches, mix_alg_bytes, mix_executed = roofline_mix(torch, _native, dev, T, rates, cfg["weights"])
+    # the vocoder of this config on synthetic inputs: timed below, and run (untimed) in front of every roofline batch
+    z = torch.randn(1, 192, T, device=dev)
+    f0 = torch.full((1, T), 220.0, device=dev)
+    gv = torch.randn(1, 256, device=dev)
+    nz = vc.net_g._draw(None, 1, T)
+
+    def dec():
+        return vc.net_g.dec.forward(z, f0, gv, src_randn=nz["src_randn"].contiguous(), src_rand=nz.get("src_rand"),
+                                    adain_randn=nz.get("adain_randn"))
+    dec()
     for _ in range(2):
         run_mix()
-    reps = 5
+    reps = 2
     t_batches = []
-    for _ in range(3):            # MEDIAN of three batches (one batch in ~10 runs 2.5 x the others on a freshly leased box), each behind a device-wide synchronise
+    # MEDIAN of five batches of 2 x 12 launches, each timed DIRECTLY BEHIND one vocoder forward on the same stream: the kernel runs
+    # 4-5 % slower in the state the pipeline leaves the chip in (clock under the preceding launches' load) than in a long run of
+    # nothing but itself, and the pipeline is where rocprofv3 --stats averages it (round 5: 321.0 us traced, 306.5 us from 60
+    # back-to-back isolated launches, 31x us measured this way)
+    for _ in range(5):
         torch.cuda.synchronize()
+        dec()
         e0.record()
         for _ in range(reps):
             run_mix()
@@ -463,20 +478,13 @@ def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev, utterance):
         "algorithmic_vs_fp32_mfma_peak": round(flops_launch / t_launch / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
         "avg_launch_ms": round(t_launch * 1e3, 4), "batch_launch_ms": [round(t * 1e3, 4) for t in t_batches],
         "launches_per_utterance": mix_launches,
-        "timing": "HIP events around the isolated launch mix on the launch stream (nothing else running); rocprofv3 --stats "
-                  "agrees for a sequential run (profiles/); with two utterances in flight a kernel's traced duration also "
-                  "contains the time it shares the chip"}
+        "timing": "HIP events around 2 x 12 launches of the mix on the launch stream, directly behind one (untimed) vocoder forward, median "
+                  "of 5 such batches; rocprofv3 --stats of a sequential run (--inflight 1) averages the same symbol over the pipeline's "
+                  "own launches (profiles/); with two utterances in flight a kernel's traced duration also contains the time it "
+                  "shares the chip"}
     del run_mix
 
     # ---- whole vocoder, timed with events around rvc_decoder_forward ----
-    z = torch.randn(1, 192, T, device=dev)
-    f0 = torch.full((1, T), 220.0, device=dev)
-    gv = torch.randn(1, 256, device=dev)
-    nz = vc.net_g._draw(None, 1, T)
-
-    def dec():
-        return vc.net_g.dec.forward(z, f0, gv, src_randn=nz["src_randn"].contiguous(), src_rand=nz.get("src_rand"),
-                                    adain_randn=nz.get("adain_randn"))
     dec()
     e0.record()
     for _ in range(3):
