@@ -95,6 +95,9 @@ SYMBOLS = {
     "rvc_decoder_set_tap": (c_int, [c_void_p, c_int, c_void_p]),
     "rvc_decoder_set_concurrency_hint": (c_int, [c_void_p, c_int]),
     "rvc_decoder_set_branch_parallel": (c_int, [c_void_p, c_int]),
+    "rvc_posconv_bf16x3_weight_bytes": (c_int, [c_int, c_int, c_int, POINTER(c_size_t)]),
+    "rvc_posconv_bf16x3_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rvc_posconv_gelu_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "rvc_hubert_conv0_workspace_bytes": (c_int, [c_int, POINTER(c_size_t)]),
     "rvc_hubert_conv0_frames_bf16x3": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p,
                                                c_size_t, c_void_p, c_int64, c_void_p]),
@@ -678,6 +681,28 @@ def linear_bf16x3_presplit(xs: torch.Tensor, a_packed: torch.Tensor, bias, n_row
     _check(_lib.rvc_linear_bf16x3_presplit(xs.data_ptr(), a_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
                                            y.data_ptr() if m != 1 else None, y.data_ptr() if m == 1 else None, n_rows, n_pad,
                                            in_features, out_features, m, k_parts, _stream()), "rvc_linear_bf16x3_presplit")
+    return y
+
+
+def posconv_bf16x3_pack_weight(w: torch.Tensor, groups: int, device) -> torch.Tensor:
+    """conv.weight [D, D / groups, taps] (weight norm folded) -> K14's fragment slab in HBM."""
+    w = w.detach().float().cpu().contiguous()
+    d, cg, taps = w.shape
+    need = c_size_t()
+    _check(_lib.rvc_posconv_bf16x3_weight_bytes(d, groups, taps, ctypes.byref(need)), "rvc_posconv_bf16x3_weight_bytes")
+    a = torch.empty(need.value // 2, dtype=torch.int16, device=device)
+    with torch.cuda.device(a.device):
+        _check(_lib.rvc_posconv_bf16x3_pack_weight(w.data_ptr(), d, groups, taps, a.data_ptr(), _stream()), "rvc_posconv_bf16x3_pack_weight")
+    return a
+
+
+def posconv_gelu_bf16x3(x: torch.Tensor, a_packed: torch.Tensor, bias, groups: int, taps: int, padding: int) -> torch.Tensor:
+    """gelu(grouped Conv1d over the frames of x [T, D], output frames 0 .. T - 1) -> [T, D] fp32."""
+    x = _dev_f32(x, "x")
+    t, d = x.shape
+    y = torch.empty_like(x)
+    _check(_lib.rvc_posconv_gelu_bf16x3(x.data_ptr(), a_packed.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                        t, d, groups, taps, padding, _stream()), "rvc_posconv_gelu_bf16x3")
     return y
 
 

@@ -31,6 +31,7 @@ class HubertModelWithFinalProj:
         self.consume_layerdrop_rng = False
         self.native_min_rows = 900      # frames from which the transformer layers run on K12 (linbf.hip); tests set it to 1
         self.frame_convs = True         # feature extractor on time-major frames (K13 + K12) for single clips; tests compare both routes
+        self.native_posconv = True      # positional conv in K14 for single clips; tests compare both routes
         self.frame_convs_min_samples = 400   # (the receptive field of one output frame)
         if state_dict is not None:
             self.load_state_dict(state_dict)
@@ -54,6 +55,7 @@ class HubertModelWithFinalProj:
                 if cw.shape[0] % 128 == 0 and (cw.shape[1] % 16 == 0 or (cw.shape[1] == 1 and cw.shape[2] <= 16)):
                     self._conv_bf[i] = _native.gemm_bf16x3_pack_weight(cw, self.device)
         self._pack_frame_convs()
+        self._pack_posconv()
         self._lin = {}   # K12: fragment slabs of the four projections of every layer (device only)
         self._qkv = {}
         for i in range(self.n_layers):
@@ -85,6 +87,17 @@ class HubertModelWithFinalProj:
             return
         for i in range(1, n):
             self._conv_fr[i] = _native.gemm_bf16x3_pack_weight(ws[i].permute(0, 2, 1).reshape(c, -1).contiguous(), self.device)
+
+    def _pack_posconv(self):
+        """The positional conv (Conv1d(D, D, 128, padding 64, groups 16)) as K14's fragment slab (posconv.hip): 48 or 64 channels per group."""
+        self._posconv = None
+        if self.device.type != "cuda":
+            return
+        from rvc_amd import _native
+        pw = self.w["encoder.pos_conv_embed.conv.weight"]
+        d, cg, taps = pw.shape
+        if d % cg == 0 and cg in (48, 64) and taps <= 128:
+            self._posconv = (_native.posconv_bf16x3_pack_weight(pw, d // cg, self.device), d // cg, taps)
 
     def _features_native(self, wav):
         """conv_layers[0..6] of one clip -> [1, frames, C] fp32, time-major (what feature_projection consumes)."""
@@ -124,6 +137,7 @@ class HubertModelWithFinalProj:
         self._qkv = {i: (a.to(self.device), b.to(self.device), s) for i, (a, b, s) in self._qkv.items()}
         self._conv_bf = {i: a.to(self.device) for i, a in self._conv_bf.items()} if self.device.type == "cuda" else {}
         self._pack_frame_convs()
+        self._pack_posconv()
         self._pack_linears()
         return self
 
@@ -168,12 +182,25 @@ class HubertModelWithFinalProj:
         x = F.layer_norm(x, (x.shape[-1],), w["feature_projection.layer_norm.weight"],
                          w["feature_projection.layer_norm.bias"], 1e-5)
         x = F.linear(x, w["feature_projection.projection.weight"], w["feature_projection.projection.bias"])
-        pos = F.conv1d(x.transpose(1, 2), w["encoder.pos_conv_embed.conv.weight"],
-                       w["encoder.pos_conv_embed.conv.bias"], padding=64, groups=16)
-        x = x + F.gelu(pos[:, :, :-1]).transpose(1, 2)
         d = x.shape[-1]
-        x = F.layer_norm(x, (d,), w["encoder.layer_norm.weight"], w["encoder.layer_norm.bias"], 1e-5)
         b, t, _ = x.shape
+        if x.is_cuda and b == 1 and self._posconv is not None and self.native_posconv:
+            # K14: gelu(grouped conv) over the time-major frames; the add + encoder.layer_norm in K12's fused pass
+            from rvc_amd import _native as N
+            a_pc, groups, taps = self._posconv
+            x2 = x.reshape(t, d).contiguous()
+            pos = N.posconv_gelu_bf16x3(x2, a_pc, w["encoder.pos_conv_embed.conv.bias"], groups, taps, taps // 2)
+            if d in (256, 768, 1024):
+                x, _ = N.bias_residual_layernorm_bf16x3(pos[None], None, x2, w["encoder.layer_norm.weight"], w["encoder.layer_norm.bias"],
+                                                        1e-5, want_planes=False)
+                x = x[None]
+            else:
+                x = F.layer_norm(x + pos[None], (d,), w["encoder.layer_norm.weight"], w["encoder.layer_norm.bias"], 1e-5)
+        else:
+            pos = F.conv1d(x.transpose(1, 2), w["encoder.pos_conv_embed.conv.weight"],
+                           w["encoder.pos_conv_embed.conv.bias"], padding=64, groups=16)
+            x = x + F.gelu(pos[:, :, :-1]).transpose(1, 2)
+            x = F.layer_norm(x, (d,), w["encoder.layer_norm.weight"], w["encoder.layer_norm.bias"], 1e-5)
         h = self.n_heads
         hd = d // h
         # K12 fills the chip from ~900 frames up (18 s of audio; 1599 frames: 1.23-1.37 x hipBLASLt per projection); below that its

@@ -454,6 +454,20 @@ int rvc_conv1d_frames_bf16x3(const void *xs_dev, int64_t n_frames_in, int64_t n_
                              const void *a_dev, const float *bias_dev, float *y_dev, void *ys_dev, int64_t n_frames_out_padded,
                              int out_channels, int mode, void *stream);
 
+/* ---- K14: HuBERT's convolutional position embedding -------------------------------------------------------------------------- *
+ * Replaces `transformers`' HubertPositionalConvEmbedding.forward behind rvc/infer/pipeline.py:450 (weight-normed Conv1d(D, D, 128,
+ * padding = 64, groups = 16) -> HubertSamePadLayer (drop the last frame) -> GELU) for one clip, time-major:
+ *   y_dev[t][o] = gelu(bias[o] + sum_{k, c} W[o][c][k] * x_dev[t + k - padding][group(o) * CG + c]),  t = 0 .. n_frames - 1,
+ * x_dev / y_dev [n_frames][d] fp32 (the caller adds the residual and applies encoder.layer_norm, e.g. with
+ * rvc_bias_residual_layernorm_bf16x3 and n_parts = 1).  bf16 matrix cores, fp32 operands split exactly into three bf16
+ * (csrc/posconv.hip): a block keeps its 128 + taps - 1 frames of one group's channels in LDS for the whole K loop, the weights
+ * stream through by LDS-DMA.  d / groups = 48 or 64, taps <= 128.  a_dev: rvc_posconv_bf16x3_weight_bytes() bytes filled by
+ * rvc_posconv_bf16x3_pack_weight from the host tensor conv.weight [d][d / groups][taps] (weight norm folded).
+ * One 8-wave workgroup per CU, whole LDS. */
+int rvc_posconv_bf16x3_weight_bytes(int d, int groups, int taps, size_t *bytes);
+int rvc_posconv_bf16x3_pack_weight(const float *w_host, int d, int groups, int taps, void *a_dev, void *stream);
+int rvc_posconv_gelu_bf16x3(const float *x_dev, const void *a_dev, const float *bias_dev, float *y_dev, int64_t n_frames, int d,
+                            int groups, int taps, int padding, void *stream);
 
 #ifdef __cplusplus
 }

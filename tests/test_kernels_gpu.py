@@ -264,6 +264,35 @@ def test_conv1d_frames_bf16x3_matches_float64(native, dev, frames_in, c, taps, s
     assert torch.equal(y2[:, :n_out] if mode == "gelu_planes" else y2, y[:, :n_out] if mode == "gelu_planes" else y)
 
 
+@pytest.mark.parametrize("frames,d,groups,taps", [(1499, 768, 16, 128), (49, 768, 16, 128), (1, 768, 16, 128), (300, 1024, 16, 128), (257, 96, 2, 5)])
+def test_posconv_gelu_bf16x3_matches_float64(native, dev, frames, d, groups, taps):
+    """K14 (posconv.hip): HuBERT's positional conv embedding -- Conv1d(D, D, 128, padding 64, groups 16) -> drop the last frame -> GELU
+    (transformers' HubertPositionalConvEmbedding behind pipeline.py:450) over time-major frames.  Against float64 F.conv1d; the
+    error level of torch's fp32 conv.  The 30 s clip, the golden clip's 49 frames, one frame, HuBERT-large's 64 channels per group,
+    a 5-tap toy with two groups."""
+    g = torch.Generator().manual_seed(frames + d)
+    cg = d // groups
+    x = torch.randn(frames, d, generator=g)
+    w = torch.randn(d, cg, taps, generator=g) * (cg * taps) ** -0.5
+    b = torch.randn(d, generator=g)
+    pad = taps // 2
+    ref = F.gelu(F.conv1d(x.t().double()[None], w.double(), b.double(), padding=pad, groups=groups)[0, :, :frames]).t()
+    xd = x.to(dev)
+    lib = F.gelu(F.conv1d(xd.t()[None], w.to(dev), b.to(dev), padding=pad, groups=groups)[0, :, :frames]).t().cpu()
+    a = native.posconv_bf16x3_pack_weight(w, groups, dev)
+    got = native.posconv_gelu_bf16x3(xd, a, b.to(dev), groups, taps, pad)
+    again = native.posconv_gelu_bf16x3(xd, a, b.to(dev), groups, taps, pad)
+    assert torch.equal(got, again)
+    got = got.cpu()
+    rel = lambda t, r: ((t.double() - r).pow(2).mean().sqrt() / r.pow(2).mean().sqrt()).item()
+    err = (got.double() - ref).abs().max().item()
+    print(f"positional conv [{frames} x {d}] groups {groups} taps {taps}: max abs err {err:.2e}, rel rms {rel(got, ref):.2e} (torch fp32 {rel(lib, ref):.2e})")
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item())
+    # one fp32 accumulator chain over K = taps x 48 = 6144 products (sqrt(K) 2^-24 = 4.7e-6 is the random-walk level; the library's
+    # GEMM splits K and lands at 5e-7)
+    assert rel(got, ref) <= max(2.0 * rel(lib, ref), 1.2e-6)
+
+
 @pytest.mark.parametrize("n_samples", [480000, 16000, 410, 47999])
 def test_hubert_conv0_frames_matches_float64(native, dev, n_samples):
     """K13 (hubert_front.hip): Conv1d(1, 512, 10, stride 5, no bias) -> GroupNorm(512, 512) -> GELU (transformers'
