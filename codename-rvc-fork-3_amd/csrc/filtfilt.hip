@@ -14,6 +14,11 @@
 // absolute on +-0.3 signals, below the float32 rounding (6e-8 relative) the audio undergoes right after
 // (pipeline.py:445).  An explicit state-transition scan (A^M) was tried and rejected: the companion matrix is so
 // non-normal (|A^256| ~ 4e7) that the scan is unstable in float64.
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
 #include "common.h"
 
 // SciPy's C loop is built without FMA; HIP's __dmul_rn/__dadd_rn are plain operators that clang would contract
@@ -78,7 +83,7 @@ constexpr int FF_TS = FF_SB + 1;       // tile row stride in doubles (conflict-f
 
 __global__ void __launch_bounds__(64)
 ff_chunk_kernel(const double *__restrict__ x, int64_t n, const double *yf_in, int backward, FiltCoef c, int chunk,
-                int warm, int64_t n_chunks, double *yf_out, double *__restrict__ out) {
+                int warm, int64_t n_chunks, double *yf_out, double *__restrict__ out, const double *__restrict__ zstate) {
     __shared__ double tin[64 * FF_TS];
     __shared__ double tout[64 * FF_TS];
     const int lane = threadIdx.x, u = lane & 31, hrow = lane >> 5;
@@ -89,7 +94,11 @@ ff_chunk_kernel(const double *__restrict__ x, int64_t n, const double *yf_in, in
     const int64_t w0 = i0 - warm;                     // first (virtual) index it runs from; steps with i < 0 are skipped
     const int n_steps = warm + chunk;                 // multiple of FF_SB
     double z[FF_ORD];
-    if (w0 <= 0) {  // exact start: zi * first input sample (scipy.signal.filtfilt)
+    if (zstate) {   // (warm == 0) the state in front of the chunk's first sample, from ff_state_kernel
+        const int64_t chc = ch < n_chunks ? ch : n_chunks - 1;
+#pragma unroll
+        for (int k = 0; k < FF_ORD; ++k) z[k] = zstate[chc * FF_ORD + k];
+    } else if (w0 <= 0) {  // exact start: zi * first input sample (scipy.signal.filtfilt)
         const double x0 = ff_input(x, n, yf_in, 0, backward);
 #pragma unroll
         for (int k = 0; k < FF_ORD; ++k) z[k] = c.zi[k] * x0;
@@ -134,11 +143,13 @@ ff_chunk_kernel(const double *__restrict__ x, int64_t n, const double *yf_in, in
     const int n_sb = n_steps / FF_SB;
     const int out_sb0 = warm / FF_SB;                 // first step-block that produces outputs
     for (int sb = 0; sb < n_sb; ++sb) {
-        __syncthreads();                              // previous tile fully consumed (single wave: a cheap fence)
+        // (lds_barrier, not __syncthreads: the latter also waits for every outstanding global access -- i.e. for the acknowledgement of
+        // the previous step-block's 32 output stores, ~7 000 cycles per step-block, as long as the recurrence itself)
+        lds_barrier();                                // previous tile fully consumed (single wave: a cheap fence)
 #pragma unroll
         for (int k = 0; k < 32; ++k) tin[(2 * k + hrow) * FF_TS + u] = r[k];
         if (sb + 1 < n_sb) fetch(sb + 1);
-        __syncthreads();
+        lds_barrier();
         const int64_t ib = w0 + (int64_t)sb * FF_SB;
         const bool emit = sb >= out_sb0;              // uniform
         if (block_lo(sb) >= 0 && block_hi(sb) < ne) {
@@ -188,13 +199,16 @@ ff_chunk_kernel(const double *__restrict__ x, int64_t n, const double *yf_in, in
             }
         }
         if (sb >= out_sb0) {                          // uniform: the last chunk / FF_SB step-blocks carry outputs
-            __syncthreads();
+            lds_barrier();
+            double yv[32];                            // read unconditionally: an LDS read inside the bounds check below is waited for
+#pragma unroll                                        // before the branch closes -- 32 serial round trips per step-block, as long as the recurrence
+            for (int k = 0; k < 32; ++k) yv[k] = tout[(2 * k + hrow) * FF_TS + u];
 #pragma unroll
             for (int k = 0; k < 32; ++k) {
                 const int64_t row_ch = ch0 + 2 * k + hrow;
                 const int64_t i = row_ch * chunk - warm + (int64_t)sb * FF_SB + u;   // index of tile element (row, u)
                 if (row_ch < n_chunks && i >= 0 && i < ne) {
-                    const double y = tout[(2 * k + hrow) * FF_TS + u];
+                    const double y = yv[k];
                     if (!backward) {
                         yf_out[i] = y;
                     } else {
@@ -207,6 +221,80 @@ ff_chunk_kernel(const double *__restrict__ x, int64_t n, const double *yf_in, in
     }
 }
 
+// double-double helpers (error-free transformations; explicit fma, the file is compiled with contraction off)
+struct dd { double hi, lo; };
+__device__ __forceinline__ dd dd_two_sum(double a, double b) {
+    const double s = a + b, bb = s - a;
+    return dd{s, (a - (s - bb)) + (b - bb)};
+}
+__device__ __forceinline__ dd dd_add(dd a, dd b) {
+    dd s = dd_two_sum(a.hi, b.hi);
+    const double lo = s.lo + (a.lo + b.lo);
+    const double hi = s.hi + lo;
+    return dd{hi, lo - (hi - s.hi)};
+}
+__device__ __forceinline__ dd dd_mul_d(double ghi, double glo, double x) {   // (ghi + glo) * x
+    const double p = ghi * x, e = __builtin_fma(ghi, x, -p);
+    return dd{p, e + glo * x};
+}
+
+// z(i0) for chunk `ch` (i0 = ch * chunk): one wave per chunk, lane j0 takes terms j0, j0 + 64, ...; four waves = four consecutive
+// chunks per block, so the 160 KiB table is fetched into a CU's L1 once for four dot products (one wave per block: 328 MB of L2
+// reads per pass, 102 us)
+// tab: [4][FF_ORD][W]: G hi, G lo, S hi, S lo  (S[i] = A^i zi, i < W)
+constexpr int FF_SW = 4;   // waves (chunks) per block
+__global__ void __launch_bounds__(64 * FF_SW)
+ff_state_kernel(const double *__restrict__ x, int64_t n, const double *__restrict__ yf_in, int backward, FiltCoef c, int chunk, int W,
+                int64_t n_chunks, const double *__restrict__ tab, double *__restrict__ zstate) {
+    const int64_t ch = (int64_t)blockIdx.x * FF_SW + (threadIdx.x >> 6);
+    if (ch >= n_chunks) return;
+    const int64_t i0 = ch * chunk;
+    const int lane = threadIdx.x & 63;
+    const double x0 = ff_input(x, n, yf_in, 0, backward);
+    if (ch == 0) {
+        if (lane < FF_ORD) zstate[lane] = c.zi[lane] * x0;      // scipy.signal.filtfilt's start, as the chunk kernel computes it
+        return;
+    }
+    const int nterm = (int)(i0 < W ? i0 : W);
+    dd acc[FF_ORD];
+#pragma unroll
+    for (int k = 0; k < FF_ORD; ++k) acc[k] = dd{0.0, 0.0};
+    for (int j0 = lane; j0 < nterm; j0 += 128) {                  // two terms per trip: both terms' loads are requested before either is used
+        const int j1 = j0 + 64;
+        const bool two = j1 < nterm;
+        const int j1c = two ? j1 : j0;
+        const double xa = ff_input(x, n, yf_in, i0 - 1 - j0, backward);
+        double xb = ff_input(x, n, yf_in, i0 - 1 - j1c, backward);
+        double ga[2][FF_ORD], gb[2][FF_ORD];
+#pragma unroll
+        for (int k = 0; k < FF_ORD; ++k) {
+            ga[0][k] = tab[(0 * FF_ORD + k) * W + j0]; ga[1][k] = tab[(1 * FF_ORD + k) * W + j0];
+            gb[0][k] = tab[(0 * FF_ORD + k) * W + j1c]; gb[1][k] = tab[(1 * FF_ORD + k) * W + j1c];
+        }
+        xb = two ? xb : 0.0;
+#pragma unroll
+        for (int k = 0; k < FF_ORD; ++k) {
+            acc[k] = dd_add(acc[k], dd_mul_d(ga[0][k], ga[1][k], xa));
+            acc[k] = dd_add(acc[k], dd_mul_d(gb[0][k], gb[1][k], xb));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < FF_ORD; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const dd o = dd{__shfl_xor(acc[k].hi, off, 64), __shfl_xor(acc[k].lo, off, 64)};
+            acc[k] = dd_add(acc[k], o);
+        }
+    }
+    if (lane < FF_ORD) {
+        dd v = acc[0];
+#pragma unroll
+        for (int k = 1; k < FF_ORD; ++k) if (lane == k) v = acc[k];
+        if (i0 < W) v = dd_add(v, dd_mul_d(tab[(2 * FF_ORD + lane) * W + i0], tab[(3 * FF_ORD + lane) * W + i0], x0));   // the exact start's own response
+        zstate[ch * FF_ORD + lane] = v.hi + v.lo;
+    }
+}
+
 }  // namespace rvc
 
 using namespace rvc;
@@ -215,9 +303,60 @@ constexpr int FF_CHUNK = 512;
 constexpr int FF_WARM = 4096;
 static_assert(FF_CHUNK % 32 == 0 && FF_WARM % 32 == 0, "chunk and warm-up are whole step-blocks");
 
+// the state impulse responses of one coefficient set, tabulated on the host in long double, split into double-double, kept in HBM
+namespace {
+struct FfTable {
+    double key[17];
+    int device = -1;
+    double *dev = nullptr;
+};
+std::mutex g_ff_mu;
+std::vector<FfTable> g_ff_tables;
+
+int ff_table_for(const double *coef_host, const double **out) {
+    int device = 0;
+    RVC_HIP(hipGetDevice(&device));
+    std::lock_guard<std::mutex> g(g_ff_mu);
+    for (const FfTable &t : g_ff_tables)
+        if (t.device == device && memcmp(t.key, coef_host, sizeof(t.key)) == 0) { *out = t.dev; return 0; }
+    const int W = FF_WARM;
+    std::vector<double> tab((size_t)4 * FF_ORD * W);
+    const double *b = coef_host, *a = coef_host + 6, *zi = coef_host + 12;
+    long double gv[FF_ORD], sv[FF_ORD];
+    for (int i = 0; i < FF_ORD; ++i) {
+        gv[i] = (long double)b[i + 1] - (long double)a[i + 1] * (long double)b[0];   // z' = A z + B x with y = z0 + b0 x
+        sv[i] = (long double)zi[i];
+    }
+    auto put = [&](int which, int k, int j, long double v) {
+        const double hi = (double)v;
+        tab[((size_t)(2 * which) * FF_ORD + k) * W + j] = hi;
+        tab[((size_t)(2 * which + 1) * FF_ORD + k) * W + j] = (double)(v - (long double)hi);
+    };
+    auto step = [&](long double *v) {      // v <- A v: v'_i = v_{i+1} - a_{i+1} v_0, v'_4 = -a_5 v_0
+        const long double v0 = v[0];
+        for (int i = 0; i < FF_ORD - 1; ++i) v[i] = v[i + 1] - (long double)a[i + 1] * v0;
+        v[FF_ORD - 1] = -(long double)a[FF_ORD] * v0;
+    };
+    for (int j = 0; j < W; ++j) {
+        for (int k = 0; k < FF_ORD; ++k) { put(0, k, j, gv[k]); put(1, k, j, sv[k]); }
+        step(gv);
+        step(sv);
+    }
+    FfTable t;
+    memcpy(t.key, coef_host, sizeof(t.key));
+    t.device = device;
+    RVC_HIP(hipMalloc((void **)&t.dev, tab.size() * sizeof(double)));
+    RVC_HIP(hipMemcpy(t.dev, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    g_ff_tables.push_back(t);
+    *out = t.dev;
+    return 0;
+}
+}  // namespace
+
 extern "C" int rvc_filtfilt_workspace_bytes(int64_t n, size_t *bytes) {
     if (!bytes || n <= FF_PAD) return fail("rvc_filtfilt_workspace_bytes: bad argument");
-    *bytes = align_up((size_t)(n + 2 * FF_PAD) * 8, 256) * 2;
+    const int64_t ne = n + 2 * FF_PAD;
+    *bytes = align_up((size_t)ne * 8, 256) * 2 + align_up((size_t)ceil_div(ne, FF_CHUNK) * FF_ORD * 8, 256);
     return 0;
 }
 
@@ -234,13 +373,17 @@ extern "C" int rvc_filtfilt_order5(const double *x_dev, int64_t n, const double 
     memcpy(c.a, coef_host + 6, sizeof(c.a));
     memcpy(c.zi, coef_host + 12, sizeof(c.zi));
     if (c.a[0] != 1.0) return fail("rvc_filtfilt_order5: a[0] must be 1");
+    const double *tab = nullptr;
+    if (ff_table_for(coef_host, &tab)) return 1;
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t ne = n + 2 * FF_PAD, n_chunks = ceil_div(ne, FF_CHUNK);
     double *yf = (double *)workspace_dev;
+    double *zstate = (double *)((char *)workspace_dev + align_up((size_t)ne * 8, 256) * 2);
     const dim3 grid((unsigned)ceil_div(n_chunks, 64)), block(64);
     for (int backward = 0; backward < 2; ++backward) {
-        hipLaunchKernelGGL(ff_chunk_kernel, grid, block, 0, stream, x_dev, n, yf, backward, c, FF_CHUNK, FF_WARM, n_chunks, yf,
-                           y_dev);
+        hipLaunchKernelGGL(ff_state_kernel, dim3((unsigned)ceil_div(n_chunks, FF_SW)), dim3(64 * FF_SW), 0, stream, x_dev, n, yf, backward, c, FF_CHUNK, FF_WARM, n_chunks, tab, zstate);
+        RVC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(ff_chunk_kernel, grid, block, 0, stream, x_dev, n, yf, backward, c, FF_CHUNK, 0, n_chunks, yf, y_dev, zstate);
         RVC_LAUNCH_CHECK();
     }
     return 0;
