@@ -110,21 +110,73 @@ __device__ __forceinline__ float mrf_rad(float f0, int h, float sr) {
     return q - floorf(q);  // torch remainder for a positive divisor
 }
 
-// pass 1: P1[b][h][i] = double prefix of rad over all samples before frame i (rand_ini added to sample 0)
-__global__ void mrf_prefix1_kernel(MrfSrcParams p) {
-    const int b = blockIdx.x, h = threadIdx.x;
-    if (h >= p.dim) return;
-    double cum = 0.0;
-    double *P1 = p.p1 + ((int64_t)b * p.dim + h) * p.T;
-    for (int64_t i = 0; i < p.T; ++i) {
-        P1[i] = cum;
-        const float rho = mrf_rad(p.f0[b * p.T + i], h, p.sr);
+// pass 1: P1[b][h][i] = double prefix of rad over all samples before frame i (rand_ini added to sample 0).
+// pass 3 (below): P2, the same with the wrap shifts.  Both prefixes are added strictly in frame order, in double, like the
+// reference's CPU cumsum -- but only ADDED by the one lane per harmonic: the per-frame terms (a division, a floor, exact products) are
+// computed by the whole block into LDS first and the prefixes leave through LDS too, so the serial chain is an LDS read and one
+// double add per frame (round 5; with the load, the division and the store inside the chain the two passes took 0.35 + 0.46 ms of
+// one wave at the front of the MRF vocoder, the whole chip waiting).
+constexpr int MRF_CH = 384;              // frames per LDS chunk
+constexpr int MRF_CS = MRF_CH + 1;       // row stride in doubles (the harmonics' rows on different banks)
+
+template <int PASS>
+__device__ __forceinline__ double mrf_prefix_term(const MrfSrcParams &p, int b, int h, int64_t i) {
+    const float rho = mrf_rad(p.f0[b * p.T + i], h, p.sr);
+    if constexpr (PASS == 1) {
         if (i == 0) {
             const float r0 = __fadd_rn(rho, h == 0 ? 0.f : p.rand_ini[b * p.dim + h]);
-            cum += (double)r0 + (double)(p.upp - 1) * (double)rho;
-        } else {
-            cum += (double)p.upp * (double)rho;
+            return (double)r0 + (double)(p.upp - 1) * (double)rho;
         }
+        return (double)p.upp * (double)rho;
+    } else {
+        const float rho_m1 = __fadd_rn(rho, -1.0f);
+        const int w = p.wraps[((int64_t)b * p.dim + h) * p.T + i];
+        if (i == 0) {
+            const float r0 = __fadd_rn(rho, h == 0 ? 0.f : p.rand_ini[b * p.dim + h]);
+            return (double)r0 + (double)(p.upp - 1 - w) * (double)rho + (double)w * (double)rho_m1;
+        }
+        return (double)(p.upp - w) * (double)rho + (double)w * (double)rho_m1;
+    }
+}
+
+template <int PASS>
+__global__ void __launch_bounds__(256) mrf_prefix_kernel(MrfSrcParams p) {
+    __shared__ double term[MRF_MAX_DIM * MRF_CS];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    double *const P = (PASS == 1 ? p.p1 : p.p2) + (int64_t)b * p.dim * p.T;
+    double cum = 0.0;                                     // thread h < dim: the running sum of harmonic h
+    for (int64_t base = 0; base < p.T; base += MRF_CH) {
+        const int n = (int)(p.T - base < MRF_CH ? p.T - base : MRF_CH);
+        for (int idx = tid; idx < p.dim * n; idx += 256) {
+            const int h = idx / n, i = idx - h * n;
+            term[h * MRF_CS + i] = mrf_prefix_term<PASS>(p, b, h, base + i);
+        }
+        __syncthreads();
+        if (tid < p.dim) {
+            double *row = term + tid * MRF_CS;
+            int i = 0;
+            for (; i + 8 <= n; i += 8) {
+                double v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = row[i + j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    row[i + j] = cum;                     // the prefix BEFORE frame i + j
+                    cum += v[j];
+                }
+            }
+            for (; i < n; ++i) {
+                const double v = row[i];
+                row[i] = cum;
+                cum += v;
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < p.dim * n; idx += 256) {
+            const int h = idx / n, i = idx - h * n;
+            P[(int64_t)h * p.T + base + i] = term[h * MRF_CS + i];
+        }
+        __syncthreads();
     }
 }
 
@@ -159,26 +211,7 @@ __global__ void __launch_bounds__(64) mrf_wraps_kernel(MrfSrcParams p) {
     if (threadIdx.x == 0) p.wraps[((int64_t)b * p.dim + h) * p.T + i] = cnt;
 }
 
-// pass 3: P2[b][h][i] = double prefix of (rad + shift) over all samples before frame i
-__global__ void mrf_prefix2_kernel(MrfSrcParams p) {
-    const int b = blockIdx.x, h = threadIdx.x;
-    if (h >= p.dim) return;
-    double cum = 0.0;
-    double *P2 = p.p2 + ((int64_t)b * p.dim + h) * p.T;
-    const int *W = p.wraps + ((int64_t)b * p.dim + h) * p.T;
-    for (int64_t i = 0; i < p.T; ++i) {
-        P2[i] = cum;
-        const float rho = mrf_rad(p.f0[b * p.T + i], h, p.sr);
-        const float rho_m1 = __fadd_rn(rho, -1.0f);
-        const int w = W[i];
-        if (i == 0) {
-            const float r0 = __fadd_rn(rho, h == 0 ? 0.f : p.rand_ini[b * p.dim + h]);
-            cum += (double)r0 + (double)(p.upp - 1 - w) * (double)rho + (double)w * (double)rho_m1;
-        } else {
-            cum += (double)(p.upp - w) * (double)rho + (double)w * (double)rho_m1;
-        }
-    }
-}
+// pass 3: P2[b][h][i] = double prefix of (rad + shift) over all samples before frame i: mrf_prefix_kernel<3> above
 
 // pass 4: one block per (frame, b): in-frame prefix of the wrap flags, sines, noise, Linear(dim -> 1), tanh
 __global__ void __launch_bounds__(256) mrf_source_kernel(MrfSrcParams p) {
@@ -798,11 +831,11 @@ extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const flo
         sp.T = T; sp.upp = d->upp; sp.dim = d->dim; sp.sr = sr;
         for (int h = 0; h < MRF_MAX_DIM; ++h) sp.lin_w[h] = d->lin_w[h];
         sp.lin_b = d->lin_b;
-        hipLaunchKernelGGL(mrf_prefix1_kernel, dim3(batch), dim3(64), 0, stream, sp);
+        hipLaunchKernelGGL(mrf_prefix_kernel<1>, dim3(batch), dim3(256), 0, stream, sp);
         RVC_LAUNCH_CHECK();
         hipLaunchKernelGGL(mrf_wraps_kernel, dim3((unsigned)T, d->dim, batch), dim3(64), 0, stream, sp);
         RVC_LAUNCH_CHECK();
-        hipLaunchKernelGGL(mrf_prefix2_kernel, dim3(batch), dim3(64), 0, stream, sp);
+        hipLaunchKernelGGL(mrf_prefix_kernel<3>, dim3(batch), dim3(256), 0, stream, sp);
         RVC_LAUNCH_CHECK();
         hipLaunchKernelGGL(mrf_source_kernel, dim3((unsigned)T, batch), dim3(256), 0, stream, sp);
         RVC_LAUNCH_CHECK();
