@@ -82,8 +82,8 @@ CONFIGS = {
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed utterances per GPU (default 8; config 3: 512 / N)")
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None, help="timed utterances per GPU (default 20; config 3: 512 / N)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--seconds", type=float, default=None, help="override the clip length of the config")
     ap.add_argument("--index-rows", type=int, default=None, help="override the index size of the config")
@@ -101,7 +101,7 @@ def parse_args(argv=None):
                          "without any kernel (no throughput is measured; the line says so)")
     args = ap.parse_args(argv)
     if args.steps is None:
-        args.steps = max(1, CONFIGS[args.config].get("batch", 8 * max(1, args.gpus)) // max(1, args.gpus))
+        args.steps = max(1, CONFIGS[args.config].get("batch", 20 * max(1, args.gpus)) // max(1, args.gpus))
     return args
 
 

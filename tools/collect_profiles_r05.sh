@@ -4,13 +4,13 @@
 # the roofline kernel, of K3f and of the kNN search.  The PMC summaries are written INTO profiles/ (bench.py reads the JSONs).
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 O=$R/gpurun_out/r05p; P=$R/gpurun_out/r05p/profiles; mkdir -p $O $P
-python3 $R/bench.py --config 2 --steps 8 --warmup 2 > $O/bench_cfg2.json 2> $O/bench_cfg2.err
-for c in 1 4 5; do python3 $R/bench.py --config $c --steps 8 --warmup 2 --cpu-seconds 3 > $O/bench_cfg$c.json 2> $O/bench_cfg$c.err; done
-python3 $R/bench.py --config 2 --steps 8 --warmup 2 --inflight 1 --no-cpu-baseline > $O/bench_cfg2_inflight1.json 2>/dev/null
+python3 $R/bench.py --config 2 --steps 20 --warmup 5 > $O/bench_cfg2.json 2> $O/bench_cfg2.err
+for c in 1 4 5; do python3 $R/bench.py --config $c --steps 20 --warmup 5 --cpu-seconds 3 > $O/bench_cfg$c.json 2> $O/bench_cfg$c.err; done
+python3 $R/bench.py --config 2 --steps 20 --warmup 5 --inflight 1 --no-cpu-baseline > $O/bench_cfg2_inflight1.json 2>/dev/null
 (cd $R && timeout 300 python3 tools/ab_branch.py 2>&1 | grep -v amdgpu.ids) > $O/ab_branch.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o b -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o b -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
 cp /tmp/pb/b_kernel_stats.csv $O/bench_kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb1 -o b -- python3 $R/bench.py --steps 5 --warmup 2 --inflight 1 --no-cpu-baseline > $O/bench_under_rocprof_inflight1.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb1 -o b -- python3 $R/bench.py --steps 10 --warmup 3 --inflight 1 --no-cpu-baseline > $O/bench_under_rocprof_inflight1.log 2>&1
 cp /tmp/pb1/b_kernel_stats.csv $O/bench_kernel_stats_inflight1.csv
 rocprofv3 --kernel-trace --output-format csv -d /tmp/pp -o t -- python3 $R/tools/profile_pipeline.py > $O/profile_pipeline.log 2>&1
 python3 $R/tools/summarize_trace.py /tmp/pp/t_kernel_trace.csv 0 all lastgap > $O/pipeline_kernels.txt
