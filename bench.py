@@ -440,13 +440,13 @@ def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev, utterance):
     dec()
     for _ in range(2):
         run_mix()
-    reps = 2
+    reps = 1
     t_batches = []
-    # MEDIAN of five batches of 2 x 12 launches, each timed DIRECTLY BEHIND one vocoder forward on the same stream: the kernel runs
+    # MEDIAN of nine batches of the 12 launches, each timed DIRECTLY BEHIND one vocoder forward on the same stream: the kernel runs
     # 4-5 % slower in the state the pipeline leaves the chip in (clock under the preceding launches' load) than in a long run of
     # nothing but itself, and the pipeline is where rocprofv3 --stats averages it (round 5: 321.0 us traced, 306.5 us from 60
-    # back-to-back isolated launches, 31x us measured this way)
-    for _ in range(5):
+    # back-to-back isolated launches, 311-314 us measured this way)
+    for _ in range(9):
         torch.cuda.synchronize()
         dec()
         e0.record()
@@ -478,8 +478,8 @@ def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev, utterance):
         "algorithmic_vs_fp32_mfma_peak": round(flops_launch / t_launch / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
         "avg_launch_ms": round(t_launch * 1e3, 4), "batch_launch_ms": [round(t * 1e3, 4) for t in t_batches],
         "launches_per_utterance": mix_launches,
-        "timing": "HIP events around 2 x 12 launches of the mix on the launch stream, directly behind one (untimed) vocoder forward, median "
-                  "of 5 such batches; rocprofv3 --stats of a sequential run (--inflight 1) averages the same symbol over the pipeline's "
+        "timing": "HIP events around the 12 launches of the mix on the launch stream, directly behind one (untimed) vocoder forward, median "
+                  "of 9 such batches; rocprofv3 --stats of a sequential run (--inflight 1) averages the same symbol over the pipeline's "
                   "own launches (profiles/); with two utterances in flight a kernel's traced duration also contains the time it "
                   "shares the chip"}
     del run_mix
