@@ -51,6 +51,9 @@ static inline constexpr int knob(const char *, int dflt) { return dflt; }
 // stand-alone, bare bf16 matrix loops do NOT do it, cause still not isolated), so co-residence of the two kernel families is
 // excluded by construction instead of by the sizes their LDS layouts happen to have.
 constexpr int LDS_WHOLE_CU = 163840;
+// ... and this is how a launcher obtains it: once per kernel (registry in error.cpp), then `hipLaunchKernelGGL(k, grid, block, LDS_WHOLE_CU, ...)`.
+// Returns non-zero and sets the error when the attribute cannot be set.
+int reserve_whole_cu(const void *kernel, const char *what);
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -1,6 +1,9 @@
 // Thread-local last-error string behind the C ABI (include/rvc_amd.h: rvc_last_error).
 #include <stdarg.h>
 
+#include <mutex>
+#include <unordered_set>
+
 #include "common.h"
 
 namespace rvc {
@@ -20,6 +23,18 @@ int fail(const char *fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return 1;
+}
+
+// common.h: LDS_WHOLE_CU.  One hipFuncSetAttribute per kernel and process.
+int reserve_whole_cu(const void *kernel, const char *what) {
+    static std::mutex mu;
+    static std::unordered_set<const void *> done;
+    std::lock_guard<std::mutex> g(mu);
+    if (done.count(kernel)) return 0;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
+    if (e != hipSuccess) return fail("%s: cannot reserve %d bytes of LDS: %s", what, LDS_WHOLE_CU, hipGetErrorString(e));
+    done.insert(kernel);
+    return 0;
 }
 
 }  // namespace rvc

@@ -336,10 +336,7 @@ __global__ void __launch_bounds__(256) ln_reduce_kernel(const float *__restrict_
 
 template <int MI>
 static int linbf_launch(LinBfParams p, int parts, hipStream_t stream) {
-    static std::once_flag once;
-    static hipError_t err = hipSuccess;
-    std::call_once(once, [] { err = hipFuncSetAttribute((const void *)linbf_kernel<MI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU); });
-    if (err != hipSuccess) return fail("linear bf16x3 (pre-split): cannot reserve %d bytes of LDS: %s", LDS_WHOLE_CU, hipGetErrorString(err));
+    if (reserve_whole_cu((const void *)linbf_kernel<MI>, "linear bf16x3 (pre-split)")) return 1;
     p.n_col_blocks = (int)ceil_div(p.N, LBF_BN);
     const int n_m = p.M / LbfGeom<MI>::BM;
     dim3 grid((unsigned)(ceil_div((int64_t)p.n_col_blocks * n_m, 8) * 8), (unsigned)parts, 1);

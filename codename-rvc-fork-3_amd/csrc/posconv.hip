@@ -101,9 +101,9 @@ posconv_kernel(const PosConvParams p) {
             }
         }
     }
-    f32x16 acc;
+    f32x16 acc2[2];                            // two accumulator chains (a matrix instruction then never waits for its predecessor), summed at the end
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc2[0][r] = acc2[1][r] = 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
 
@@ -125,13 +125,14 @@ posconv_kernel(const PosConvParams p) {
             }
             constexpr int ia[6] = {2, 0, 1, 1, 0, 0}, ib[6] = {0, 2, 1, 0, 1, 0};   // small terms first
 #pragma unroll
-            for (int i = 0; i < 6; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ia[i]], fb[ib[i]], acc, 0, 0, 0);
+            for (int i = 0; i < 6; ++i) acc2[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ia[i]], fb[ib[i]], acc2[i & 1], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // tap k + 1 has landed
         lds_barrier();                                            // ... for every wave; tap k's buffer is free
     }
 
     // ---- epilogue: lane (frame t, channels 4 half + 8 rg + 0..3 of the row tile) -------------------------------------------------
+    const f32x16 acc = acc2[0] + acc2[1];
     const int64_t t = t0 + ct * 32 + l31;
     if (t >= p.T) return;
 #pragma unroll
@@ -208,10 +209,7 @@ extern "C" int rvc_posconv_bf16x3_pack_weight(const float *w_host, int d, int gr
 
 template <int CG>
 static int posconv_launch(const PosConvParams &p, hipStream_t stream) {
-    static std::once_flag once;
-    static hipError_t err = hipSuccess;
-    std::call_once(once, [] { err = hipFuncSetAttribute((const void *)posconv_kernel<CG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU); });
-    if (err != hipSuccess) return fail("posconv: cannot reserve %d bytes of LDS: %s", LDS_WHOLE_CU, hipGetErrorString(err));
+    if (reserve_whole_cu((const void *)posconv_kernel<CG>, "posconv")) return 1;
     dim3 grid((unsigned)ceil_div(p.T, PC_BN), (unsigned)p.groups, 1);
     hipLaunchKernelGGL(posconv_kernel<CG>, grid, dim3(PC_NTH), LDS_WHOLE_CU, stream, p);   // owns its CU (common.h)
     RVC_LAUNCH_CHECK();

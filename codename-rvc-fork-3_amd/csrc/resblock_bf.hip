@@ -541,12 +541,7 @@ static int rbf_cu_count() {
 template <int KW, int C, int DBG = 0>
 static int rbf_launch(RbfParams p, int batch, hipStream_t stream) {
     using GM = RbfGeom<KW, C>;
-    static std::once_flag once;
-    static hipError_t err = hipSuccess;
-    std::call_once(once, [] {
-        err = hipFuncSetAttribute((const void *)resblock_bf_kernel<KW, C, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
-    });
-    if (err != hipSuccess) return fail("resblock_bf: cannot reserve %d bytes of LDS: %s", LDS_WHOLE_CU, hipGetErrorString(err));
+    if (reserve_whole_cu((const void *)resblock_bf_kernel<KW, C, DBG>, "resblock_bf")) return 1;
     p.tiles_per_row = (int)ceil_div(p.L, GM::BN);
     p.n_tiles = p.tiles_per_row * batch;
     p.per_xcd = (int)ceil_div(p.n_tiles, 8);

@@ -233,7 +233,11 @@ typedef struct rvc_decoder_config {
     int n_res_dilations;      /* 3 */
     int weight_storage;       /* 0: fp32.  1: the ResBlock / MRF-layer conv weights (98 % of the vocoder's weight bytes) are kept
                                  in HBM as bf16 and widened to fp32 inside the conv kernel (BASELINE cfg 4: "bf16 weights ...
-                                 alt ResBlock kernel path"); the arithmetic stays fp32.  NSF / MRF only. */
+                                 alt ResBlock kernel path"); the arithmetic stays fp32.  NSF / MRF only.
+                                 This is a NUMERICS mode (bf16-VALUED taps), not a footprint reduction: the layers that run on
+                                 the bf16 matrix cores keep fragment slabs of those taps (three bf16 per transformed tap: 126 B
+                                 per (c_out, c_in) pair at 11 taps against 44 B of fp32 taps), so the handle holds MORE weight
+                                 bytes than with fp32 storage. */
 } rvc_decoder_config;
 
 int rvc_decoder_create(const rvc_decoder_config *cfg, rvc_decoder **out);
