@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional as F
 
 WINDOW = 10
+FRAMES_PATH = True     # the unmasked GPU encoder keeps its activations time-major (tests compare it with the channel-major graph)
 
 
 def channel_layer_norm(x, gamma, beta, eps=1e-5):
@@ -34,6 +35,14 @@ def prepare_attention_weights(w: Dict[str, torch.Tensor], n_layers: int) -> None
         w[p + ".o.weight"] = w[p + ".conv_o.weight"][:, :, 0].contiguous()
         w[p + ".ek"] = w[p + ".emb_rel_k"][0].contiguous()
         w[p + ".ev"] = w[p + ".emb_rel_v"][0].contiguous()
+        # the FFN's "same"-padded convs as GEMMs over time-major frames: the window [x[t-1], x[t], x[t+1]] of a frame is k * C
+        # contiguous values of the zero-padded [T + k - 1, C] tensor, W2d[o][j * C + c] = conv.weight[o][c][j]
+        f = f"enc_p.encoder.ffn_layers.{i}"
+        for n in ("conv_1", "conv_2"):
+            cw = w[f + f".{n}.weight"]
+            w[f + f".{n}.w2d"] = cw.permute(0, 2, 1).reshape(cw.shape[0], -1).contiguous()
+    if "enc_p.proj.weight" in w:
+        w["enc_p.proj.w2d"] = w["enc_p.proj.weight"][:, :, 0].contiguous()
 
 
 def _rel_attention_hip(x, w: Dict[str, torch.Tensor], p: str, n_heads: int):
@@ -81,6 +90,38 @@ def rel_attention(x, w: Dict[str, torch.Tensor], p: str, n_heads: int, attn_mask
     return F.conv1d(out, w[p + ".conv_o.weight"], w[p + ".conv_o.bias"])
 
 
+def _same_conv_frames(x, w2d, bias, k: int):
+    """nn.Conv1d(C, O, k, padding = (k - 1) // 2) over TIME-MAJOR frames x [B, T, C] as one GEMM: frame t's window is the k * C
+    contiguous values starting at row t of the zero-padded tensor (an overlapping-row view; the GEMM reads a compact copy of it)."""
+    b, t, c = x.shape
+    pad = (k - 1) // 2
+    xp = F.pad(x, (0, 0, pad, k - 1 - pad))
+    win = xp.as_strided((b, t, k * c), (xp.stride(0), c, 1))
+    return F.linear(win, w2d, bias)
+
+
+def _text_encoder_frames(w: Dict[str, torch.Tensor], x, n_layers: int, n_heads: int, kernel_size: int, out_channels: int):
+    """The unmasked encoder (every frame valid) with the activations kept time-major, [B, T, C]: the attention kernel and the
+    projections are time-major already, LayerNorm over channels is then the plain last-dim one, and the FFN's k-tap convs are GEMMs
+    over overlapping rows -- no transposes, no im2col (rvc/lib/algorithm/attentions.py: Encoder.forward, FFN.forward).  Per layer
+    8 library launches + the attention instead of ~20."""
+    from rvc_amd import _native
+    d = x.shape[-1]
+    scale = 1.0 / math.sqrt(d // n_heads)
+    for i in range(n_layers):
+        p = f"enc_p.encoder.attn_layers.{i}"
+        qkv = F.linear(x, w[p + ".qkv.weight"], w[p + ".qkv.bias"])
+        a = _native.attention_qkv(qkv, n_heads, scale, w[p + ".ek"], w[p + ".ev"])
+        y = F.linear(a, w[p + ".o.weight"], w[p + ".conv_o.bias"])
+        x = F.layer_norm(x + y, (d,), w[f"enc_p.encoder.norm_layers_1.{i}.gamma"], w[f"enc_p.encoder.norm_layers_1.{i}.beta"], 1e-5)
+        f = f"enc_p.encoder.ffn_layers.{i}"
+        y = torch.relu_(_same_conv_frames(x, w[f + ".conv_1.w2d"], w[f + ".conv_1.bias"], kernel_size))
+        y = _same_conv_frames(y, w[f + ".conv_2.w2d"], w[f + ".conv_2.bias"], kernel_size)
+        x = F.layer_norm(x + y, (d,), w[f"enc_p.encoder.norm_layers_2.{i}.gamma"], w[f"enc_p.encoder.norm_layers_2.{i}.beta"], 1e-5)
+    stats = F.linear(x, w["enc_p.proj.w2d"], w["enc_p.proj.bias"]).transpose(1, 2)    # [B, 2 * out, T]: the flow is channel-major
+    return torch.split(stats, out_channels, dim=1)
+
+
 def text_encoder(w: Dict[str, torch.Tensor], phone, pitch, lengths, *, hidden=192, out_channels=192, n_heads=2,
                  n_layers=6, kernel_size=3, lengths_host=None):
     """``lengths_host``: the same lengths as Python ints when the caller has them (saves a device->host read)."""
@@ -88,10 +129,14 @@ def text_encoder(w: Dict[str, torch.Tensor], phone, pitch, lengths, *, hidden=19
     if pitch is not None:
         x = x + F.embedding(pitch, w["enc_p.emb_pitch.weight"])
     x = F.leaky_relu(x * math.sqrt(hidden), 0.1)
-    x = x.transpose(1, -1)
-    t = x.size(2)
+    t = x.size(1)
     x_mask = (torch.arange(t, device=x.device)[None, :] < lengths[:, None]).unsqueeze(1).to(x.dtype)
     full = all(int(n) == t for n in lengths_host) if lengths_host is not None else bool((lengths == t).all())
+    if (full and x.is_cuda and FRAMES_PATH and "enc_p.proj.w2d" in w and (hidden // n_heads) in (64, 96)
+            and w["enc_p.encoder.attn_layers.0.emb_rel_k"].shape[0] == 1):
+        m, logs = _text_encoder_frames(w, x, n_layers, n_heads, kernel_size, out_channels)
+        return m, logs, x_mask
+    x = x.transpose(1, -1)
     attn_mask = None if full else x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
     pad = (kernel_size - 1) // 2
     if full:   # every frame valid: the mask is all ones and multiplying by it is the identity (saves ~30 passes)
