@@ -1000,7 +1000,8 @@ def test_bias_relu_add_bit_exact(native, dev, shape):
 
 
 # ---- K6 filtfilt -------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n", [4000, 480_000, 19, 257])
+# 476 / 477: one chunk exactly / a second chunk of one sample; 4572 / 5000: the first chunk whose state sum is truncated at 4096 terms
+@pytest.mark.parametrize("n", [4000, 480_000, 19, 257, 476, 477, 4572, 5000, 100_003])
 def test_filtfilt_matches_scipy(native, dev, n):
     from scipy import signal
     from rvc_amd.lib import synthetic as S
