@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """ResBlock branches of a vocoder stage on side streams against every launch on one stream: same box, alternating, bit-identity of
-the waveform checked.  VOC=HiFi-GAN|MRF HiFi-GAN, T frames (default 3198 = BASELINE cfg 2)."""
+the waveform checked.  Four decoders: NSF 48 k at T = 3198 (BASELINE cfg 2), NSF 40 k at 1000, MRF 48 k at 3198, NSF 48 k at 301."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "codename-rvc-fork-3_amd")]
