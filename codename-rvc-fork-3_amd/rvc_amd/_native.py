@@ -145,7 +145,7 @@ for _name, (_res, _args) in SYMBOLS.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 if _lib.rvc_abi_version() != ABI_VERSION:
     raise ImportError(f"librvc_amd.so ABI {_lib.rvc_abi_version()} != {ABI_VERSION}: rebuild it")
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RVC_AMD_ABI_VERSION 2
+#define RVC_AMD_ABI_VERSION 3   /* 3: round-5 additions (K3f, K12-K14, branch streams); no existing signature changed */
 
 /* ---- library ------------------------------------------------------------------------------------ */
 
