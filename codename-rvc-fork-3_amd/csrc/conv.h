@@ -62,14 +62,16 @@ int launch_resblock_layer(const float *x, const float *w1, const float *b1, cons
 
 // fused ResBlock PAIR in direct form on the bf16 matrix cores, fp32 operands as exact bf16x3 splits (resblock_bf.hip): the 32- and
 // 64-channel stages; same semantics as launch_resblock_layer with the pair's taps packed as matrix-instruction fragments
-bool resblock_bf_enabled();   // ablation build: RVC_RBF=0 puts the stages back on the unfused kernels
+// tap_splits: 3 = fp32 taps as exact bf16 triples (six products per multiply-add), 1 = bf16-VALUED taps (three products)
+bool resblock_bf_enabled();   // rvc_resblock_bf16x3_set_enabled(0) (ablation build: RVC_RBF=0) puts NEW handles' stages back on the unfused kernels
+void resblock_bf_set_enabled(bool on);
 bool resblock_bf_supported(int c, int k, int dil);
-bool resblock_bf_preferred(int c, int k);   // the shapes where it beats the two launches it replaces (measured)
+bool resblock_bf_preferred(int c, int k, int tap_splits = 3);   // the shapes where it beats the two launches it replaces (measured)
 bool resblock_bf_fits(int c, int64_t L);
-size_t resblock_bf_weight_bytes(int c, int k);
-void resblock_bf_pack_host(const float *w1, const float *w2, int c, int k, std::vector<uint16_t> *out);   // w: [c][c][k]
+size_t resblock_bf_weight_bytes(int c, int k, int tap_splits = 3);
+void resblock_bf_pack_host(const float *w1, const float *w2, int c, int k, std::vector<uint16_t> *out, int tap_splits = 3);   // w: [c][c][k]
 int launch_resblock_bf(const float *x, const void *u, const float *b1, const float *b2, const float *accin, float *y, int batch, int c,
-                       int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream);
+                       int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream, int tap_splits = 3);
 
 // fp32 -> bf16, round to nearest even (what torch's .bfloat16() does); NaN stays NaN
 static inline uint16_t bf16_rne(float f) {

@@ -65,6 +65,7 @@ struct Stage {
     DevBuf nc_w;                  // [1][nc_rows][c_out]
     std::vector<ConvW> c1, c2;    // [n_res_kernels * n_res_dilations]
     std::vector<DevBuf16> pair;   // 32- / 64-channel stages: (c1, c2) of each entry as one slab of bf16x3 matrix-instruction fragments (resblock_bf.hip)
+    int pair_splits = 3;          // ... with this many terms per tap: 1 when the handle stores bf16 weights (the taps are bf16-valued)
 };
 
 // One forward call's side streams: the ResBlock branches of a stage (resblocks[i * nk + m], m = 0..nk-1: hifigan_nsf.py:195-203 sums

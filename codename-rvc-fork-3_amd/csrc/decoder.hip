@@ -649,18 +649,13 @@ extern "C" int rvc_decoder_finalize(rvc_decoder *d) {
                 const bool b16 = c.weight_storage == 1 && (k == 3 || k == 7 || k == 11);
                 if (build_conv(d, p1, s.c_out, s.c_out, k, true, &s.c1[m * c.n_res_dilations + j], b16)) return 1;
                 if (build_conv(d, p2, s.c_out, s.c_out, k, true, &s.c2[m * c.n_res_dilations + j], b16)) return 1;
-                if (resblock_bf_enabled() && resblock_bf_supported(s.c_out, k, 1) && resblock_bf_preferred(s.c_out, k)) {   // the fused pair on the bf16 matrix cores (K3f)
+                const int nts = b16 ? 1 : 3;   // bf16 weight storage: the taps ARE their first split -- one-term fragments, three products per multiply-add
+                if (resblock_bf_enabled() && resblock_bf_supported(s.c_out, k, 1) && resblock_bf_preferred(s.c_out, k, nts)) {   // the fused pair on the bf16 matrix cores (K3f)
                     const HostTensor *w1, *w2;
                     if (need(d, p1 + ".weight", &w1, {s.c_out, s.c_out, k}) || need(d, p2 + ".weight", &w2, {s.c_out, s.c_out, k})) return 1;
-                    std::vector<float> v1(w1->data), v2(w2->data);
-                    if (b16)   // bf16 weight storage: fragments of the bf16-VALUED taps (their second and third splits are zero)
-                        for (std::vector<float> *v : {&v1, &v2})
-                            for (float &f : *v) {
-                                const uint32_t bits = (uint32_t)bf16_rne(f) << 16;
-                                memcpy(&f, &bits, 4);
-                            }
                     std::vector<uint16_t> frags;
-                    resblock_bf_pack_host(v1.data(), v2.data(), s.c_out, k, &frags);
+                    resblock_bf_pack_host(w1->data.data(), w2->data.data(), s.c_out, k, &frags, nts);   // (nts = 1 rounds to bf16: what build_conv(b16) stores)
+                    s.pair_splits = nts;
                     if (s.pair[m * c.n_res_dilations + j].upload(frags)) return 1;
                 }
             }
@@ -938,7 +933,7 @@ extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const flo
                     const float scale = (last && final_branch) ? 1.f / (float)nk : 1.f;
                     if (last && before_last()) return 1;
                     if (launch_resblock_bf(xin, s.pair[m * nd + j].p, s.c1[m * nd + j].b.p, s.c2[m * nd + j].b.p, acc_in, yout, batch,
-                                           s.c_out, len, k, c.res_dilations[j], 0.1f, scale, stream))
+                                           s.c_out, len, k, c.res_dilations[j], 0.1f, scale, stream, s.pair_splits))
                         return 1;
                     xin = yout;
                 }

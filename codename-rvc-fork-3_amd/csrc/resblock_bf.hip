@@ -29,6 +29,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -90,7 +91,10 @@ __device__ __forceinline__ void rb_split3_np(float a, float b, unsigned w[3]) {
     }
 }
 
-template <int KW, int C>
+// NTS = terms of the TAP split: 3 for fp32 taps (six products per multiply-add), 1 for bf16-VALUED taps (BASELINE cfg 4's weight
+// storage: w = w_0 exactly, so the three products w_0 x_0 + w_0 x_1 + w_0 x_2 are the whole result -- half the matrix instructions
+// and a third of the tap-fragment bytes per group; activations and the intermediate keep their three-way split)
+template <int KW, int C, int NTS = 3>
 struct RbfGeom {
     static constexpr int KS = C / 16, RB = C / 32, CG = 4 / RB;
     static constexpr int N1 = CG * 64;                       // conv1 columns per block
@@ -103,7 +107,8 @@ struct RbfGeom {
     static constexpr int RC32 = (XROWS + 31) / 32;           // staged rows in 32-row chunks: a half-wave = one chunk of one channel quad
     static constexpr int NIT = (C / 8) * RC32 / 4;           // (32-row chunk, channel quad pair) items per stager wave
     static constexpr int NG = KW * KS;                       // (tap, k step) groups per conv
-    static constexpr int GROUP_BYTES = 3 * 1024;             // three splits of one 32 x 16 tap fragment
+    static constexpr int GROUP_BYTES = NTS * 1024;           // the splits of one 32 x 16 tap fragment
+    static_assert(NTS == 1 || NTS == 3, "tap split: one term (bf16-valued taps) or three (fp32 taps)");
     static constexpr int CONV_BYTES = NG * RB * GROUP_BYTES;
     static constexpr int R_BYTES = C * N1 * 4 + 16;          // the io buffer (+ 4 floats that take the writes of rows outside the block's own columns): residual (raw rows of the block's own columns) in, outputs out
     static constexpr int LDS_BYTES = X_BYTES + T_BYTES + R_BYTES;
@@ -125,12 +130,14 @@ __device__ __forceinline__ void rb_split3(rb_f32x2 v, unsigned w[3]) {
 
 // DBG (ablation build only): 128 = wave 0 and stager wave 4 write s_memtime stamps to the buffer passed as `accin` (which is then NOT
 // added): [block][compute | stager][64], eight per tile -- tools/stamp_resblock_bf.py turns them into a per-phase breakdown
-template <int KW, int C, int DBG = 0>
+template <int KW, int C, int DBG = 0, int NTS = 3>
 __global__ void __launch_bounds__(RBF_NTH) __attribute__((amdgpu_waves_per_eu(2, 2)))
 resblock_bf_kernel(const RbfParams p) {
-    using GM = RbfGeom<KW, C>;
+    using GM = RbfGeom<KW, C, NTS>;
     constexpr int KS = GM::KS, RB = GM::RB, N1 = GM::N1, H2 = GM::H2, BN = GM::BN, ROWB = GM::ROWB, NIT = GM::NIT;
-    constexpr int NG = GM::NG, PA = 4;   // (a ring of six: no change, measured)
+    // tap-fragment ring: four groups with three-term taps (a ring of six: no change, measured); a one-term group is half as long
+    // (six matrix instructions), so its ring is twice as deep to keep the same distance in cycles between request and use
+    constexpr int NG = GM::NG, PA = NTS == 1 ? 8 : 4;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
     unsigned char *const xs = rb_smem;
@@ -341,14 +348,14 @@ resblock_bf_kernel(const RbfParams p) {
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, 2 * GM::CONV_BYTES, RBF_RSRC_FLAGS);
     const float slope = p.slope;
 
-    rb_bf16x8 fa[PA][3];
+    rb_bf16x8 fa[PA][NTS];
     rb_bf16x8 fb[2][2][3];
     f32x16 acc[2];
     // group g = tap * KS + ks of conv `cv`: the three splits of this wave's row block
     auto load_a = [&](int slot_a, int cv, int g) __attribute__((always_inline)) {
         const int soff = cv * GM::CONV_BYTES + (g * RB + rb) * GM::GROUP_BYTES;
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
+        for (int s = 0; s < NTS; ++s)
             fa[slot_a][s] = __builtin_bit_cast(rb_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(urs, 16 * lane + s * 1024, soff, 0));
     };
     // one window fragment of group g: (column tile cb, split s)
@@ -365,7 +372,9 @@ resblock_bf_kernel(const RbfParams p) {
         for (int g = 0; g < PA - 1; ++g)
             if (g < NG) load_a(g, cv, g);
     };
-    constexpr int ia6[6] = {0, 1, 0, 2, 1, 0}, ib6[6] = {2, 1, 1, 0, 0, 0};   // (tap split, window split): smallest products first
+    // (tap split, window split): smallest products first; one-term taps: w_0 x_2, w_0 x_1, w_0 x_0
+    constexpr int NPR = NTS == 1 ? 3 : 6;
+    constexpr int ia6[6] = {0, NTS == 1 ? 0 : 1, 0, 2, 1, 0}, ib6[6] = {2, 1, NTS == 1 ? 0 : 1, 0, 0, 0};
     auto conv_loop = [&](int cv, const unsigned char *src, int tapstep) __attribute__((always_inline)) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
@@ -375,17 +384,18 @@ resblock_bf_kernel(const RbfParams p) {
         for (int k = 0; k < 6; ++k) load_b1(0, src, tapstep, 0, k & 1, 2 - (k >> 1));
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            // twelve matrix instructions; behind instruction k, pinned: one of the NEXT group's six window fragments (split 2 first:
-            // the order the products consume them), then the three tap fragments of the group three ahead
+            // twelve (one-term taps: six) matrix instructions; behind instruction k, pinned: one of the NEXT group's six window
+            // fragments (split 2 first: the order the products consume them), then the tap fragments of the group PA - 1 ahead
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+            for (int i = 0; i < NPR; ++i)
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) {
                     const int k = 2 * i + cb;
                     acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g % PA][ia6[i]], fb[g & 1][cb][ib6[i]], acc[cb], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (k < 6 && g + 1 < NG) load_b1((g + 1) & 1, src, tapstep, g + 1, k & 1, 2 - (k >> 1));
-                    if (k >= 6 && k < 9 && g + PA - 1 < NG) load_a1((g + PA - 1) % PA, cv, g + PA - 1, k - 6);
+                    if (NTS == 3 && k >= 6 && k < 9 && g + PA - 1 < NG) load_a1((g + PA - 1) % PA, cv, g + PA - 1, k - 6);
+                    if (NTS == 1 && k == 3 && g + PA - 1 < NG) load_a1((g + PA - 1) % PA, cv, g + PA - 1, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
         }
@@ -477,10 +487,18 @@ resblock_bf_kernel(const RbfParams p) {
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
 
+// Runtime switch of the PRODUCT build (rvc_resblock_bf16x3_set_enabled): handles created while it is off keep their narrow stages on
+// the unfused kernels (launch_resblock_layer / winobf / wino).  The ablation build's RVC_RBF=0 sets the initial value.
+static std::atomic<int> g_rbf_on{-1};
 bool resblock_bf_enabled() {
-    static const int on = knob("RVC_RBF", 1);
-    return on != 0;
+    int v = g_rbf_on.load(std::memory_order_relaxed);
+    if (v < 0) {
+        v = knob("RVC_RBF", 1) != 0;
+        g_rbf_on.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
 }
+void resblock_bf_set_enabled(bool on) { g_rbf_on.store(on ? 1 : 0, std::memory_order_relaxed); }
 
 bool resblock_bf_supported(int c, int k, int dil) {
     return ((c == 32 || c == 64) && (k == 3 || k == 7 || k == 11) || (c == 128 && (k == 3 || k == 7))) && dil >= 1 && dil <= 5;
@@ -490,23 +508,29 @@ bool resblock_bf_supported(int c, int k, int dil) {
 // replaces): C = 32: 155-164 / 238-243 / 332-338 at 3 / 7 / 11 taps against 250-272 / 322-341 / 406-434; C = 64: 222-224 / 418-430
 // against 300-317 / 453-482 at 3 / 7 taps.  C = 64 with 11 taps stays on winobf.hip's Winograd form (637-641 against 554-566: the
 // direct form executes 2.1 x its matrix work there and only 116 of a block's 128 columns are outputs).
-bool resblock_bf_preferred(int c, int k) {
+// One-term taps (tap_splits = 1, bf16-valued weights): three products per multiply-add instead of six -- every supported shape
+// (profiles/r06_rbf1_shapes.txt).
+bool resblock_bf_preferred(int c, int k, int tap_splits) {
 #ifdef RVC_ABLATE
     static const int all = knob("RVC_RBF_ALL", 0);
     if (all) return true;
+    static const int one = knob("RVC_RBF_ONE", 1);       // 0: bf16-valued taps as three-term fragments (round 5's cfg 4)
+    if (tap_splits == 1 && !one) tap_splits = 3;
 #endif
+    if (tap_splits == 1) return true;
     return c == 32 || (c == 64 && k != 11) || (c == 128 && k == 3);
 }
 
 bool resblock_bf_fits(int c, int64_t L) { return (int64_t)c * L * 4 < ((int64_t)1 << 31); }
 
-size_t resblock_bf_weight_bytes(int c, int k) { return (size_t)2 * k * (c / 16) * (c / 32) * 3 * 1024; }
+size_t resblock_bf_weight_bytes(int c, int k, int tap_splits) { return (size_t)2 * k * (c / 16) * (c / 32) * tap_splits * 1024; }
 
 // w1, w2: [c][c][k] (PyTorch Conv1d layout) -> [conv][tap][k step][row block][split][lane][8 bf16]: lane l of a fragment holds
-// output channel 32 rb + (l & 31), input channels 16 ks + 8 (l >> 5) .. + 7
-void resblock_bf_pack_host(const float *w1, const float *w2, int c, int k, std::vector<uint16_t> *out) {
+// output channel 32 rb + (l & 31), input channels 16 ks + 8 (l >> 5) .. + 7.  tap_splits = 1: the taps ROUNDED to bf16 (round to
+// nearest even: what `weight_storage = 1` stores), one fragment per group.
+void resblock_bf_pack_host(const float *w1, const float *w2, int c, int k, std::vector<uint16_t> *out, int tap_splits) {
     const int KS = c / 16, RB = c / 32;
-    out->assign(resblock_bf_weight_bytes(c, k) / 2, 0);
+    out->assign(resblock_bf_weight_bytes(c, k, tap_splits) / 2, 0);
     for (int cv = 0; cv < 2; ++cv) {
         const float *w = cv ? w2 : w1;
         for (int tap = 0; tap < k; ++tap)
@@ -517,13 +541,13 @@ void resblock_bf_pack_host(const float *w1, const float *w2, int c, int k, std::
                             const int co = 32 * rb + (lane & 31), ci = 16 * ks + 8 * (lane >> 5) + e;
                             float r = w[((size_t)co * c + ci) * k + tap];
                             const size_t group = (((size_t)cv * k + tap) * KS + ks) * RB + rb;
-                            for (int s = 0; s < 3; ++s) {
+                            for (int s = 0; s < tap_splits; ++s) {
                                 const uint16_t h = bf16_rne(r);
                                 const uint32_t bits = (uint32_t)h << 16;
                                 float f;
                                 memcpy(&f, &bits, 4);
                                 r -= f;                      // exact in fp32
-                                (*out)[(group * 3 + s) * 512 + lane * 8 + e] = h;
+                                (*out)[(group * tap_splits + s) * 512 + lane * 8 + e] = h;
                             }
                         }
     }
@@ -538,24 +562,26 @@ static int rbf_cu_count() {
     return n;
 }
 
-template <int KW, int C, int DBG = 0>
+template <int KW, int C, int DBG = 0, int NTS = 3>
 static int rbf_launch(RbfParams p, int batch, hipStream_t stream) {
-    using GM = RbfGeom<KW, C>;
-    if (reserve_whole_cu((const void *)resblock_bf_kernel<KW, C, DBG>, "resblock_bf")) return 1;
+    using GM = RbfGeom<KW, C, NTS>;
+    if (reserve_whole_cu((const void *)resblock_bf_kernel<KW, C, DBG, NTS>, "resblock_bf")) return 1;
     p.tiles_per_row = (int)ceil_div(p.L, GM::BN);
     p.n_tiles = p.tiles_per_row * batch;
     p.per_xcd = (int)ceil_div(p.n_tiles, 8);
     const int cus = rbf_cu_count() / 8 * 8;
     const int slots = (int)std::min<int64_t>(cus / 8, p.per_xcd);           // blocks per XCD
-    hipLaunchKernelGGL((resblock_bf_kernel<KW, C, DBG>), dim3((unsigned)(slots * 8)), dim3(RBF_NTH), LDS_WHOLE_CU, stream, p);   // owns its CU (common.h)
+    hipLaunchKernelGGL((resblock_bf_kernel<KW, C, DBG, NTS>), dim3((unsigned)(slots * 8)), dim3(RBF_NTH), LDS_WHOLE_CU, stream, p);   // owns its CU (common.h)
     RVC_LAUNCH_CHECK();
     return 0;
 }
 
-// x, y: [batch][c][L] (must NOT alias: blocks read their neighbours' columns); u: resblock_bf_pack_host's slab on the device
+// x, y: [batch][c][L] (must NOT alias: blocks read their neighbours' columns); u: resblock_bf_pack_host's slab on the device, packed
+// with the same tap_splits
 int launch_resblock_bf(const float *x, const void *u, const float *b1, const float *b2, const float *accin, float *y, int batch, int c,
-                       int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream) {
+                       int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream, int tap_splits) {
     if (!resblock_bf_supported(c, k, dil)) return fail("resblock_bf: unsupported shape (%d channels, %d taps, dilation %d)", c, k, dil);
+    if (tap_splits != 1 && tap_splits != 3) return fail("resblock_bf: tap split of %d terms (1 or 3)", tap_splits);
     if (x == y) return fail("resblock_bf: in-place operation is not supported");
     if (!(slope >= 0.f && slope <= 1.f)) return fail("resblock_bf: leaky slope %g outside [0, 1]", (double)slope);
     if (!resblock_bf_fits(c, L)) return fail("resblock_bf: a %d x %lld slab exceeds the 2 GiB buffer addressing", c, (long long)L);
@@ -565,11 +591,15 @@ int launch_resblock_bf(const float *x, const void *u, const float *b1, const flo
     p.x = x; p.u = u; p.b1 = b1; p.b2 = b2; p.accin = accin; p.y = y; p.L = L; p.dil = dil; p.slope = slope; p.out_scale = out_scale;
 #ifdef RVC_ABLATE
     static const int dbg = knob("RVC_RBF_DBG", 0);
-#define RVC_RBF_DBG_CASE(KW, CC) if (dbg == 128 && k == KW && c == CC) return rbf_launch<KW, CC, 128>(p, batch, stream)
+#define RVC_RBF_DBG_CASE(KW, CC) if (dbg == 128 && k == KW && c == CC && tap_splits == 3) return rbf_launch<KW, CC, 128>(p, batch, stream)
     RVC_RBF_DBG_CASE(3, 32); RVC_RBF_DBG_CASE(7, 32); RVC_RBF_DBG_CASE(11, 32); RVC_RBF_DBG_CASE(7, 64);
 #undef RVC_RBF_DBG_CASE
+#define RVC_RBF_DBG_CASE(KW, CC) if (dbg == 128 && k == KW && c == CC && tap_splits == 1) return rbf_launch<KW, CC, 128, 1>(p, batch, stream)
+    RVC_RBF_DBG_CASE(11, 32); RVC_RBF_DBG_CASE(7, 64); RVC_RBF_DBG_CASE(11, 64); RVC_RBF_DBG_CASE(7, 128);
+#undef RVC_RBF_DBG_CASE
 #endif
-#define RVC_RBF_CASE(KW, CC) if (k == KW && c == CC) return rbf_launch<KW, CC>(p, batch, stream)
+#define RVC_RBF_CASE(KW, CC)                                                                     \
+    if (k == KW && c == CC) return tap_splits == 1 ? rbf_launch<KW, CC, 0, 1>(p, batch, stream) : rbf_launch<KW, CC, 0, 3>(p, batch, stream)
     RVC_RBF_CASE(3, 32); RVC_RBF_CASE(7, 32); RVC_RBF_CASE(11, 32);
     RVC_RBF_CASE(3, 64); RVC_RBF_CASE(7, 64); RVC_RBF_CASE(11, 64);
     RVC_RBF_CASE(3, 128); RVC_RBF_CASE(7, 128);
@@ -581,23 +611,28 @@ int launch_resblock_bf(const float *x, const void *u, const float *b1, const flo
 
 using namespace rvc;
 
-extern "C" int rvc_resblock_bf16x3_weight_bytes(int c, int k, size_t *bytes) {
-    if (!bytes) return fail("rvc_resblock_bf16x3_weight_bytes: null pointer");
-    if (!resblock_bf_supported(c, k, 1)) return fail("rvc_resblock_bf16x3_weight_bytes: c must be 32 or 64 with k 3, 7 or 11, or 128 with k 3 or 7");
-    *bytes = resblock_bf_weight_bytes(c, k);
+static int rbf_weight_bytes_abi(const char *fn, int c, int k, int tap_splits, size_t *bytes) {
+    if (!bytes) return fail("%s: null pointer", fn);
+    if (!resblock_bf_supported(c, k, 1)) return fail("%s: c must be 32 or 64 with k 3, 7 or 11, or 128 with k 3 or 7", fn);
+    *bytes = resblock_bf_weight_bytes(c, k, tap_splits);
+    return 0;
+}
+static int rbf_pack_abi(const char *fn, const float *w1_host, const float *w2_host, int c, int k, int tap_splits, void *u_dev, void *stream) {
+    if (!w1_host || !w2_host || !u_dev) return fail("%s: null pointer", fn);
+    size_t bytes = 0;
+    if (rbf_weight_bytes_abi(fn, c, k, tap_splits, &bytes)) return 1;
+    std::vector<uint16_t> u;
+    resblock_bf_pack_host(w1_host, w2_host, c, k, &u, tap_splits);
+    hipError_t e = hipMemcpyAsync(u_dev, u.data(), bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return fail("%s: %s", fn, hipGetErrorString(e));
     return 0;
 }
 
+extern "C" int rvc_resblock_bf16x3_weight_bytes(int c, int k, size_t *bytes) { return rbf_weight_bytes_abi("rvc_resblock_bf16x3_weight_bytes", c, k, 3, bytes); }
+
 extern "C" int rvc_resblock_bf16x3_pack_weight(const float *w1_host, const float *w2_host, int c, int k, void *u_dev, void *stream) {
-    if (!w1_host || !w2_host || !u_dev) return fail("rvc_resblock_bf16x3_pack_weight: null pointer");
-    size_t bytes = 0;
-    if (rvc_resblock_bf16x3_weight_bytes(c, k, &bytes)) return 1;
-    std::vector<uint16_t> u;
-    resblock_bf_pack_host(w1_host, w2_host, c, k, &u);
-    hipError_t e = hipMemcpyAsync(u_dev, u.data(), bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
-    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
-    if (e != hipSuccess) return fail("rvc_resblock_bf16x3_pack_weight: %s", hipGetErrorString(e));
-    return 0;
+    return rbf_pack_abi("rvc_resblock_bf16x3_pack_weight", w1_host, w2_host, c, k, 3, u_dev, stream);
 }
 
 extern "C" int rvc_resblock_bf16x3_forward(const float *x_dev, const void *u_dev, const float *b1_dev, const float *b2_dev,
@@ -605,5 +640,25 @@ extern "C" int rvc_resblock_bf16x3_forward(const float *x_dev, const void *u_dev
                                            float slope, float out_scale, void *stream) {
     if (!x_dev || !u_dev || !y_dev) return fail("rvc_resblock_bf16x3_forward: null pointer");
     return launch_resblock_bf(x_dev, u_dev, b1_dev, b2_dev, acc_dev, y_dev, batch, c, length, k, dilation, slope, out_scale,
-                              (hipStream_t)stream);
+                              (hipStream_t)stream, 3);
+}
+
+// ... with bf16-VALUED taps (BASELINE cfg 4's weight storage): one-term tap split, three products per multiply-add
+extern "C" int rvc_resblock_bf16w_weight_bytes(int c, int k, size_t *bytes) { return rbf_weight_bytes_abi("rvc_resblock_bf16w_weight_bytes", c, k, 1, bytes); }
+
+extern "C" int rvc_resblock_bf16w_pack_weight(const float *w1_host, const float *w2_host, int c, int k, void *u_dev, void *stream) {
+    return rbf_pack_abi("rvc_resblock_bf16w_pack_weight", w1_host, w2_host, c, k, 1, u_dev, stream);
+}
+
+extern "C" int rvc_resblock_bf16w_forward(const float *x_dev, const void *u_dev, const float *b1_dev, const float *b2_dev,
+                                          const float *acc_dev, float *y_dev, int batch, int c, int64_t length, int k, int dilation,
+                                          float slope, float out_scale, void *stream) {
+    if (!x_dev || !u_dev || !y_dev) return fail("rvc_resblock_bf16w_forward: null pointer");
+    return launch_resblock_bf(x_dev, u_dev, b1_dev, b2_dev, acc_dev, y_dev, batch, c, length, k, dilation, slope, out_scale,
+                              (hipStream_t)stream, 1);
+}
+
+extern "C" int rvc_resblock_bf16x3_set_enabled(int enabled) {
+    resblock_bf_set_enabled(enabled != 0);
+    return 0;
 }

@@ -117,6 +117,11 @@ SYMBOLS = {
     "rvc_resblock_bf16x3_pack_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "rvc_resblock_bf16x3_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int,
                                             c_int, c_float, c_float, c_void_p]),
+    "rvc_resblock_bf16w_weight_bytes": (c_int, [c_int, c_int, POINTER(c_size_t)]),
+    "rvc_resblock_bf16w_pack_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "rvc_resblock_bf16w_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int,
+                                           c_int, c_float, c_float, c_void_p]),
+    "rvc_resblock_bf16x3_set_enabled": (c_int, [c_int]),
     "rvc_gemm_bf16x3_weight_bytes": (c_int, [c_int, c_int, POINTER(c_size_t)]),
     "rvc_gemm_bf16x3_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rvc_linear_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
@@ -145,7 +150,7 @@ for _name, (_res, _args) in SYMBOLS.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 if _lib.rvc_abi_version() != ABI_VERSION:
     raise ImportError(f"librvc_amd.so ABI {_lib.rvc_abi_version()} != {ABI_VERSION}: rebuild it")
 
@@ -592,32 +597,40 @@ def conv1d_winobf_forward(x, u_packed, bias, c_out, k, dilation=1, slope_in=1.0,
 
 
 # ---- K3f: fused ResBlock pair (dilated conv -> conv + residual) on the bf16 matrix cores -------------------------
-def resblock_bf16x3_pack_weight(w1: torch.Tensor, w2: torch.Tensor, device) -> torch.Tensor:
-    """The two nn.Conv1d weights [c, c, k] of one ResBlock dilation -> fragment slab on the device."""
+def resblock_bf16x3_pack_weight(w1: torch.Tensor, w2: torch.Tensor, device, bf16_taps: bool = False) -> torch.Tensor:
+    """The two nn.Conv1d weights [c, c, k] of one ResBlock dilation -> fragment slab on the device.  bf16_taps: the taps rounded to
+    bf16 (BASELINE cfg 4's weight storage), one fragment per group instead of three -- for resblock_bf16x3_forward(bf16_taps=True)."""
     w1 = w1.detach().float().cpu().contiguous()
     w2 = w2.detach().float().cpu().contiguous()
     c, c_in, k = w1.shape
     if c != c_in or w2.shape != w1.shape:
         raise NativeError(f"resblock pair: square convs of one shape expected, got {tuple(w1.shape)} and {tuple(w2.shape)}")
+    stem = "rvc_resblock_bf16w" if bf16_taps else "rvc_resblock_bf16x3"
     n = c_size_t()
-    _check(_lib.rvc_resblock_bf16x3_weight_bytes(c, k, ctypes.byref(n)), "rvc_resblock_bf16x3_weight_bytes")
+    _check(getattr(_lib, stem + "_weight_bytes")(c, k, ctypes.byref(n)), stem + "_weight_bytes")
     u = torch.empty(n.value // 2, dtype=torch.int16, device=device)
-    _check(_lib.rvc_resblock_bf16x3_pack_weight(w1.data_ptr(), w2.data_ptr(), c, k, u.data_ptr(), _stream()), "rvc_resblock_bf16x3_pack_weight")
+    _check(getattr(_lib, stem + "_pack_weight")(w1.data_ptr(), w2.data_ptr(), c, k, u.data_ptr(), _stream()), stem + "_pack_weight")
     return u
 
 
-def resblock_bf16x3_forward(x, u_packed, b1, b2, k, dilation=1, slope=0.1, acc=None, out_scale=1.0, out=None):
-    """y = out_scale * (conv2(leaky(conv1_d(leaky(x)) + b1)) + b2 + x [+ acc]) for x [B, C, L] in HBM (residuals.py:75-86)."""
+def resblock_bf16x3_forward(x, u_packed, b1, b2, k, dilation=1, slope=0.1, acc=None, out_scale=1.0, out=None, bf16_taps: bool = False):
+    """y = out_scale * (conv2(leaky(conv1_d(leaky(x)) + b1)) + b2 + x [+ acc]) for x [B, C, L] in HBM (residuals.py:75-86).
+    bf16_taps: u_packed holds one-term fragments of bf16-valued taps (three products per multiply-add; hifigan_mrf.py:13-83 at cfg 4)."""
     x = _dev_f32(x, "x")
     b, c, length = x.shape
     y = out if out is not None else torch.empty_like(x)
     if y.data_ptr() == x.data_ptr():
         raise NativeError("resblock pair: x and y must not alias")
-    _check(_lib.rvc_resblock_bf16x3_forward(x.data_ptr(), u_packed.data_ptr(), b1.data_ptr() if b1 is not None else None,
-                                            b2.data_ptr() if b2 is not None else None, acc.data_ptr() if acc is not None else None,
-                                            y.data_ptr(), b, c, length, k, dilation, float(slope), float(out_scale), _stream()),
-           "rvc_resblock_bf16x3_forward")
+    name = "rvc_resblock_bf16w_forward" if bf16_taps else "rvc_resblock_bf16x3_forward"
+    _check(getattr(_lib, name)(x.data_ptr(), u_packed.data_ptr(), b1.data_ptr() if b1 is not None else None,
+                               b2.data_ptr() if b2 is not None else None, acc.data_ptr() if acc is not None else None,
+                               y.data_ptr(), b, c, length, k, dilation, float(slope), float(out_scale), _stream()), name)
     return y
+
+
+def resblock_bf16x3_set_enabled(enabled: bool) -> None:
+    """Process-wide: decoder handles finalized while this is off keep their narrow ResBlock stages on the unfused kernels."""
+    _check(_lib.rvc_resblock_bf16x3_set_enabled(1 if enabled else 0), "rvc_resblock_bf16x3_set_enabled")
 
 
 # ---- K11: fp32 GEMM / strided conv1d as exact bf16x3 splits on the bf16 matrix cores ----------------------------

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RVC_AMD_ABI_VERSION 3   /* 3: round-5 additions (K3f, K12-K14, branch streams); no existing signature changed */
+#define RVC_AMD_ABI_VERSION 4   /* 3: round-5 additions (K3f, K12-K14, branch streams); 4: round-6 additions (K3f with one-term taps, its runtime switch); no existing signature changed */
 
 /* ---- library ------------------------------------------------------------------------------------ */
 
@@ -389,6 +389,22 @@ int rvc_resblock_bf16x3_pack_weight(const float *w1_host, const float *w2_host, 
 int rvc_resblock_bf16x3_forward(const float *x_dev, const void *u_dev, const float *b1_dev, const float *b2_dev,
                                 const float *acc_dev, float *y_dev, int batch, int c, int64_t length, int k, int dilation,
                                 float slope, float out_scale, void *stream);
+/* The same pair with bf16-VALUED taps -- the weights of a handle created with weight_storage = 1 (BASELINE cfg 4: "MRF-HiFi-GAN,
+ * bf16 weights, alt ResBlock kernel path"; MRFLayer.forward, rvc/lib/algorithm/generators/hifigan_mrf.py:13-83, is the body above).
+ * A bf16-valued tap IS the first term of its split (w = w_0 exactly), so w x = w_0 x_0 + w_0 x_1 + w_0 x_2 is the whole product:
+ * THREE matrix products per multiply-add instead of six, one 1 KiB tap fragment per (tap, 16 input channels, 32 output channels)
+ * instead of three; activations and the intermediate keep their exact three-way split, so the result is the fp32 result of the
+ * pair on the rounded taps to the same ~2^-23 as the six-product form.  pack_weight ROUNDS the fp32 taps it is given to bf16
+ * (round to nearest even, what weight_storage = 1 and torch's .bfloat16() do).  Shapes and rules as above. */
+int rvc_resblock_bf16w_weight_bytes(int c, int k, size_t *bytes);
+int rvc_resblock_bf16w_pack_weight(const float *w1_host, const float *w2_host, int c, int k, void *u_dev, void *stream);
+int rvc_resblock_bf16w_forward(const float *x_dev, const void *u_dev, const float *b1_dev, const float *b2_dev,
+                               const float *acc_dev, float *y_dev, int batch, int c, int64_t length, int k, int dilation,
+                               float slope, float out_scale, void *stream);
+/* Process-wide runtime switch for K3f inside rvc_decoder_finalize (default 1): decoder handles finalized while it is 0 keep the
+ * (conv, conv) pairs of their narrow stages on the unfused kernels (csrc/resblock.hip, winobf.hip, wino.hip) -- the fall-back an
+ * operator reaches for without rebuilding the library.  The entry points above are not affected. */
+int rvc_resblock_bf16x3_set_enabled(int enabled);
 
 /* ---- K11: fp32 GEMM / strided conv1d on the bf16 matrix cores with fp32-exact operands ------------------------------------ *
  * Replaces the fp32 library GEMMs behind `transformers`' HubertModel at rvc/infer/pipeline.py:450: the attention / FFN

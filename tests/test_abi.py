@@ -26,7 +26,7 @@ def test_header_and_library_agree():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/rvc_amd.h but not exported"
     assert sorted(_native.SYMBOLS) == declared, "ctypes table and header drifted apart"
-    assert lib.rvc_abi_version() == _native.ABI_VERSION == 3
+    assert lib.rvc_abi_version() == _native.ABI_VERSION == 4
 
 
 def test_errors_are_reported_not_swallowed():

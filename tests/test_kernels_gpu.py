@@ -185,6 +185,51 @@ def test_resblock_pair_bf16x3_matches_float64(native, dev, c, k, dil, length, ba
     assert torch.equal(again, plain)                      # bit-reproducible
 
 
+@pytest.mark.parametrize("c,k,dil,length,batch", [
+    (32, 3, 1, 4096, 1), (32, 3, 5, 1000, 2), (32, 7, 3, 749, 2), (32, 7, 5, 16384, 1), (32, 11, 1, 2051, 1), (32, 11, 5, 513, 2),
+    (32, 11, 5, 31, 1), (32, 3, 1, 5, 1), (64, 3, 5, 777, 2), (64, 7, 1, 5003, 1), (64, 11, 1, 2051, 1), (64, 11, 5, 9999, 2),
+    (64, 11, 3, 117, 1), (128, 3, 3, 1237, 2), (128, 7, 1, 2051, 1), (128, 7, 5, 777, 1), (128, 7, 3, 50, 1),
+    (32, 11, 5, 1535040, 1), (64, 11, 3, 767520, 1), (64, 7, 1, 767520, 1), (128, 7, 5, 383760, 1), (128, 3, 1, 383760, 1),   # the cfg-4 stage shapes
+])
+def test_resblock_pair_bf16_taps_matches_float64(native, dev, c, k, dil, length, batch):
+    """K3f with ONE-TERM taps (rvc_resblock_bf16w_*): BASELINE cfg 4's "alt ResBlock kernel path" -- the MRF layer
+    (hifigan_mrf.py:13-83 = residuals.py:75-86) with bf16-stored weights.  A bf16-valued tap is the first term of its own split, so
+    three products per multiply-add (w x_0 + w x_1 + w x_2) are exact to the same 2^-23 as the six of the fp32-tap form.  Reference:
+    the pair in float64 on the bf16-ROUNDED taps (the cfg-4 oracle runs fp32 math on the same rounded weights); the result
+    must also be what the three-term kernel gives on fragments of those rounded taps (its second and third fragments are zero) to
+    fp32 summation-order noise, and be bit-reproducible."""
+    g = torch.Generator().manual_seed(c * 1000 + k * 10 + dil + 7)
+    x = torch.randn(batch, c, length, generator=g)
+    w1 = (torch.randn(c, c, k, generator=g) / (c * k) ** 0.5)
+    w2 = (torch.randn(c, c, k, generator=g) / (c * k) ** 0.5)
+    w1r, w2r = w1.bfloat16().float(), w2.bfloat16().float()
+    b1, b2 = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    acc = torch.randn(batch, c, length, generator=g)
+
+    def pair64(xx, bb1, bb2):
+        t = conv1d_f64(F.leaky_relu(xx.double(), 0.1), w1r, bb1, padding=(k - 1) // 2 * dil, dilation=dil)
+        return conv1d_f64(F.leaky_relu(t, 0.1), w2r, bb2, padding=(k - 1) // 2) + xx.double()
+
+    u1 = native.resblock_bf16x3_pack_weight(w1, w2, dev, bf16_taps=True)       # unrounded in: the pack rounds (RNE)
+    assert u1.numel() * 3 == native.resblock_bf16x3_pack_weight(w1r, w2r, dev).numel()
+    xd = x.to(dev)
+    ref = (pair64(x, b1.double(), b2.double()) + acc.double()) / 3
+    got = native.resblock_bf16x3_forward(xd, u1, b1.to(dev), b2.to(dev), k, dil, 0.1, acc=acc.to(dev), out_scale=1 / 3, bf16_taps=True).cpu()
+    err = (got.double() - ref).abs().max().item()
+    assert err <= 6e-5, err
+    ref2 = pair64(x, None, None)
+    plain = native.resblock_bf16x3_forward(xd, u1, None, None, k, dil, 0.1, bf16_taps=True).cpu()
+    assert (plain.double() - ref2).abs().max().item() <= 6e-5
+    u3 = native.resblock_bf16x3_pack_weight(w1r, w2r, dev)
+    three = native.resblock_bf16x3_forward(xd, u3, None, None, k, dil, 0.1).cpu()
+    rel = lambda t: ((t.double() - ref2).pow(2).mean().sqrt() / ref2.pow(2).mean().sqrt()).item()
+    r1, r3 = rel(plain), rel(three)
+    print(f"C {c} k {k} d {dil} L {length} B {batch}: relative RMS error vs float64 on the rounded taps: one-term {r1:.2e}, three-term {r3:.2e}")
+    assert r1 <= 1.5 * r3 + 1e-8
+    again = native.resblock_bf16x3_forward(xd, u1, None, None, k, dil, 0.1, bf16_taps=True).cpu()
+    assert torch.equal(again, plain)                      # bit-reproducible
+
+
 @pytest.mark.parametrize("n_rows,k,m,mode,k_parts", [
     (1599, 768, 2304, "f32", 1), (1599, 768, 768, "parts", 3), (1599, 768, 3072, "gelu_planes", 1),
     (1599, 3072, 768, "parts", 3), (149, 768, 768, "parts", 6), (1, 768, 2304, "f32", 1), (300, 256, 256, "parts", 2),
