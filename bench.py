@@ -25,7 +25,10 @@ through the C ABI (rvc_index_broadcast) and verified by a device-side checksum; 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      the dominant kernel symbol (the 11-tap ResBlock convs of vocoder stages 0-2: Winograd F(4,4) on the bf16 matrix
                 cores with fp32 operands split exactly into three bf16), timed live with HIP events on the launch stream
-  roofline_knn  the L2 top-8 search at this config's (queries x rows), HBM bytes per pass as SURVEY §8d defines them
+  roofline_knn  the L2 top-8 search at this config's (queries x rows): the fp16-screened regime, `frac` = its fp16 MFMA fraction
+                (what bounds it); physical HBM bytes and SURVEY §8d's formula figure ride along as hbm_frac_physical / frac_8d
+  roofline_knn_stream  the same search for ONE 32-query tile (knn_direct_kernel: one pass over the fp32 rows) -- the HBM-bound
+                regime, `frac` = N x 3072 B / time / 8 TB/s, `traffic` from profiles/pmc_knn_stream_<N>.json
   host_io       the same K steps with host NumPy in / host float32 out (PCIe inclusive) at the same `inflight`
   cpu_baseline  the oracle (CPU restatement of the reference, oracle/rvc_oracle.py) on the host cores, on the config's own
                 utterance and index: warm-up + median of 3 (rank 0, N = 1 only; --cpu-seconds bounds the sample)
@@ -523,6 +526,21 @@ def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev, utterance):
         ktraffic, ksrc = pmc_traffic(f"knn_{n_rows}", "bytes_per_search") if F_ == 1599 else (None, None)
         res["roofline_knn"] = _native.knn_roofline_report(n_rows, F_, 768, t_knn, PEAK_HBM_GBS, PEAK_FP32_MFMA_TFLOPS,
                                                           PEAK_F16_MFMA_TFLOPS, traffic=ktraffic, traffic_source=ksrc)
+        # ---- the STREAMING regime of the same search: one query tile (32 queries: a 0.64 s clip, or one segment's tail) against the
+        # resident index -- knn_direct_kernel makes ONE pass over the fp32 rows and is bound by HBM; this is the regime in which
+        # north_star's ">= 60 % HBM roofline on the kNN kernel" is a physical statement (pipeline.py:497-507 with a short feats tensor)
+        qs = q[:32].contiguous()
+        idx.search_device(qs)
+        reps = 50 if n_rows <= 200_000 else 8
+        e0.record()
+        for _ in range(reps):
+            idx.search_device(qs)
+        e1.record()
+        torch.cuda.synchronize()
+        t_s = e0.elapsed_time(e1) / reps * 1e-3
+        straffic, ssrc = pmc_traffic(f"knn_stream_{n_rows}", "bytes_per_search")
+        res["roofline_knn_stream"] = _native.knn_roofline_report(n_rows, 32, 768, t_s, PEAK_HBM_GBS, PEAK_FP32_MFMA_TFLOPS,
+                                                                 PEAK_F16_MFMA_TFLOPS, traffic=straffic, traffic_source=ssrc)
     return res
 
 

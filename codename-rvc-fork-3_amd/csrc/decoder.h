@@ -89,6 +89,7 @@ struct RefineStage {
     ConvW input_conv;                  // k7, (ch_in + down_c) -> ch_out
     DevBuf adain1[4], adain2[4];       // per branch [ch_out]
     std::vector<ConvW> c1, c2;         // [n_res_kernels * n_res_dilations]
+    std::vector<DevBuf16> pair;        // narrow stages: (c1, c2) of each entry as one slab of bf16x3 fragments (resblock_bf.hip)
 };
 
 }  // namespace rvc

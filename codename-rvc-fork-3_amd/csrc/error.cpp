@@ -25,15 +25,18 @@ int fail(const char *fmt, ...) {
     return 1;
 }
 
-// common.h: LDS_WHOLE_CU.  One hipFuncSetAttribute per kernel and process.
+// common.h: LDS_WHOLE_CU.  One hipFuncSetAttribute per (device, kernel) and process: the attribute belongs to the CURRENT device's
+// function object, so a process that drives several devices (a thread per device) needs it on each.
 int reserve_whole_cu(const void *kernel, const char *what) {
     static std::mutex mu;
-    static std::unordered_set<const void *> done;
+    static std::unordered_set<const void *> done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
     std::lock_guard<std::mutex> g(mu);
-    if (done.count(kernel)) return 0;
+    if (dev < 64 && done[dev].count(kernel)) return 0;
     const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
-    if (e != hipSuccess) return fail("%s: cannot reserve %d bytes of LDS: %s", what, LDS_WHOLE_CU, hipGetErrorString(e));
-    done.insert(kernel);
+    if (e != hipSuccess) return fail("%s: cannot reserve %d bytes of LDS on device %d: %s", what, LDS_WHOLE_CU, dev, hipGetErrorString(e));
+    if (dev < 64) done[dev].insert(kernel);   // (beyond 64 devices: set it every time -- it is cheap)
     return 0;
 }
 

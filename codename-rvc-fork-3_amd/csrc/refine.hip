@@ -268,6 +268,7 @@ int refine_finalize(rvc_decoder *d) {
         const int nb = c.n_res_kernels * c.n_res_dilations;
         s.c1 = std::vector<ConvW>(nb);
         s.c2 = std::vector<ConvW>(nb);
+        s.pair = std::vector<DevBuf16>(nb);
         for (int m = 0; m < c.n_res_kernels; ++m) {
             const std::string bm = ub + ".blocks." + std::to_string(m);
             if (upload_vec(d, bm + ".0.weight", {s.ch_out}, &s.adain1[m])) return 1;
@@ -276,6 +277,19 @@ int refine_finalize(rvc_decoder *d) {
                 const int k = c.res_kernel_sizes[m];
                 if (build_conv(d, bm + ".1.convs1." + std::to_string(j), s.ch_out, s.ch_out, k, true, &s.c1[m * c.n_res_dilations + j])) return 1;
                 if (build_conv(d, bm + ".1.convs2." + std::to_string(j), s.ch_out, s.ch_out, k, true, &s.c2[m * c.n_res_dilations + j])) return 1;
+                // the narrow stages' (conv, conv) pairs as ONE launch on the bf16 matrix cores (resblock_bf.hip, K3f): the ResBlock body
+                // is the NSF vocoder's (refinegan.py:59-85 = residuals.py:75-86) with slope 0.2.  Since round 6 this takes the layers
+                // that ran wino.hip's fp32 Winograd kernel (64 channels x 3 taps, the 32-channel stage) -- the kernel that returns wrong
+                // words next to a co-resident bf16-matrix workgroup (profiles/r05_mfma_cohabitation.txt) is off every default path.
+                if (resblock_bf_enabled() && resblock_bf_supported(s.ch_out, k, 1) && resblock_bf_preferred(s.ch_out, k, 3)) {
+                    const HostTensor *w1, *w2;
+                    if (need(d, bm + ".1.convs1." + std::to_string(j) + ".weight", &w1, {s.ch_out, s.ch_out, k}) ||
+                        need(d, bm + ".1.convs2." + std::to_string(j) + ".weight", &w2, {s.ch_out, s.ch_out, k}))
+                        return 1;
+                    std::vector<uint16_t> frags;
+                    resblock_bf_pack_host(w1->data.data(), w2->data.data(), s.ch_out, k, &frags, 3);
+                    if (s.pair[m * c.n_res_dilations + j].upload(frags)) return 1;
+                }
             }
         }
         ch = s.ch_out;
@@ -410,7 +424,15 @@ int refine_forward(rvc_decoder *d, const float *z_dev, const float *f0_dev, cons
             RVC_LAUNCH_CHECK();
             nz += (size_t)batch * bs;
             const float *xin = A;
-            const bool fused = resblock_layer_supported(s.ch_out, k) && nd == 3;
+            const bool pairs = s.pair[m * nd].p && resblock_bf_fits(s.ch_out, lo) && nd % 2 == 1;
+            for (int j = 0; pairs && j < nd; ++j) {   // A -> Y -> T1 -> Y ... (no in-place: blocks read neighbours' columns; an odd count ends in Y)
+                float *yout = (j % 2 == 1) ? T1 : Y;
+                if (launch_resblock_bf(xin, s.pair[m * nd + j].p, s.c1[m * nd + j].b.p, s.c2[m * nd + j].b.p, nullptr, yout, batch, s.ch_out, lo,
+                                       k, c.res_dilations[j], slope, 1.f, stream, 3))
+                    return 1;
+                xin = yout;
+            }
+            const bool fused = !pairs && resblock_layer_supported(s.ch_out, k) && nd == 3;
             for (int j = 0; fused && j < nd; ++j) {   // A -> Y -> T1 -> Y (no in-place: blocks read neighbours' columns)
                 float *yout = (j == 1) ? T1 : Y;
                 if (launch_resblock_layer(xin, s.c1[m * nd + j].w.p, s.c1[m * nd + j].b.p, s.c2[m * nd + j].w.p, s.c2[m * nd + j].b.p,
@@ -418,7 +440,7 @@ int refine_forward(rvc_decoder *d, const float *z_dev, const float *f0_dev, cons
                     return 1;
                 xin = yout;
             }
-            for (int j = 0; !fused && j < nd; ++j) {
+            for (int j = 0; !fused && !pairs && j < nd; ++j) {
                 const int dil = c.res_dilations[j];
                 ConvParams p;
                 p.x1 = xin; p.c1 = s.ch_out; p.slope1 = slope; p.x1_bstride = bs; p.l_in = lo;

@@ -261,8 +261,8 @@ def knn_roofline_report(n_rows: int, n_queries: int, dim: int, seconds: float, p
     """SURVEY §8d's kNN roofline for one rvc_knn_search of (n_queries x n_rows) that took `seconds` (all launches of the
     search: query conversion, sample pass, bound, main pass, exact re-scoring).  §8d prices a pass over the index at
     n_rows * dim * 4 B (the fp32 rows the reference's algorithm reads) times ceil(Q / Qt) passes; the screened regime
-    (Qt = 256) streams an fp16 copy, so the bytes it really moves per pass are half of that: `frac` is the physical figure
-    (bytes the passes read / time / HBM peak), `frac_8d` the formula's."""
+    (Qt = 256) streams an fp16 copy, so the bytes it really moves per pass are half of that.  Since round 6 `frac` is the fraction of
+    whatever BOUNDS the regime (see below); `hbm_frac_physical` and `frac_8d` carry the two HBM readings in every regime."""
     screened = n_queries > 64 and n_rows >= 16384 and dim % 256 == 0
     stream = n_queries <= 64
     q_tile = 256 if screened else (32 if stream else 128)
@@ -270,23 +270,36 @@ def knn_roofline_report(n_rows: int, n_queries: int, dim: int, seconds: float, p
     bytes_8d = passes * n_rows * dim * 4.0
     bytes_moved = passes * n_rows * dim * (2.0 if screened else 4.0) + (8.0 * n_queries * dim * 4 if screened else 0.0)
     flops = 2.0 * n_queries * n_rows * dim
-    return {"kernel": ("knn_screen_kernel<false> (sample) + knn_select_kernel + knn_screen_kernel<true> (main, fp16 MFMA) + "
-                       "knn_finalize_kernel (exact fp32 re-scoring)" if screened else
-                       ("knn_direct_kernel" if stream else "knn_partial_kernel") + " + knn_finalize_kernel"),
-            "regime": "fp16-screened, exact re-scoring" if screened else ("fp32 streaming" if stream else "fp32 GEMM"),
-            "shape": f"{n_queries} queries x {n_rows} rows x {dim}", "bound": "hbm", "query_tile": q_tile, "passes": passes,
-            "bytes_per_pass_8d": n_rows * dim * 4,
-            # `achieved` / `frac` are PHYSICAL: the bytes this regime's passes read (fp16 copy when screened) over the search
-            # time.  SURVEY 8d's formula figure (fp32 rows x passes, bytes the screened kernel does not read) stays as *_8d.
-            "achieved": round(bytes_moved / seconds / 1e9, 1), "peak": peak_hbm_gbs,
-            "unit": "GB/s", "frac": round(bytes_moved / seconds / 1e9 / peak_hbm_gbs, 4),
-            "bytes_moved_per_search": bytes_moved,
-            "achieved_8d": round(bytes_8d / seconds / 1e9, 1), "frac_8d": round(bytes_8d / seconds / 1e9 / peak_hbm_gbs, 4),
-            "traffic": traffic, "traffic_source": traffic_source,   # measured HBM bytes per search (the caller's: profiles/pmc_knn_*.json)
-            "mfma_tflops": round(flops / seconds / 1e12, 2),
-            "mfma_frac": round(flops / seconds / 1e12 / (peak_f16_tflops if screened else peak_f32_tflops), 4),
-            "mfma_peak_used": "fp16 dense 2500 TF" if screened else "fp32 157.3 TF",
-            "avg_search_ms": round(seconds * 1e3, 4)}
+    mfma_peak = peak_f16_tflops if screened else peak_f32_tflops
+    hbm_gbs = bytes_moved / seconds / 1e9
+    mfma_tf = flops / seconds / 1e12
+    # What bounds each regime decides which fraction is `frac`: the streaming regime (<= 64 queries, ONE pass over the fp32 rows) is
+    # HBM-bound -- bytes / time / 8 TB/s; the screened regime (a 256 x 256 GEMM tile per block on the fp16 matrix cores, the index
+    # mostly served from L2 / MALL) is bound by the matrix pipe's operand ingest -- its `frac` is the fp16 MFMA fraction, and the
+    # HBM figures (physical bytes, and SURVEY 8d's formula on fp32 rows the kernel never reads) are footnotes.
+    bound = "hbm" if stream else "mfma"
+    out = {"kernel": ("knn_screen_kernel<false> (sample) + knn_select_kernel + knn_screen_kernel<true> (main, fp16 MFMA) + "
+                      "knn_finalize_kernel (exact fp32 re-scoring)" if screened else
+                      ("knn_direct_kernel" if stream else "knn_partial_kernel") + " + knn_finalize_kernel"),
+           "regime": "fp16-screened, exact re-scoring" if screened else ("fp32 streaming" if stream else "fp32 GEMM"),
+           "shape": f"{n_queries} queries x {n_rows} rows x {dim}", "bound": bound, "query_tile": q_tile, "passes": passes,
+           "bytes_per_pass_8d": n_rows * dim * 4}
+    if bound == "hbm":
+        out.update({"achieved": round(hbm_gbs, 1), "peak": peak_hbm_gbs, "unit": "GB/s", "frac": round(hbm_gbs / peak_hbm_gbs, 4),
+                    "frac_is": "physical: bytes the pass reads (n_rows x dim x 4) / search time / HBM peak"})
+    else:
+        out.update({"achieved": round(mfma_tf, 2), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(mfma_tf / mfma_peak, 4),
+                    "frac_is": "2 x queries x rows x dim / search time / the dense " + ("fp16" if screened else "fp32") + " MFMA peak "
+                               "(round 5 and earlier printed an HBM fraction here: now hbm_frac_physical / frac_8d)"})
+    out.update({"bytes_moved_per_search": bytes_moved,
+                "hbm_gbs_physical": round(hbm_gbs, 1), "hbm_frac_physical": round(hbm_gbs / peak_hbm_gbs, 4),
+                "achieved_8d": round(bytes_8d / seconds / 1e9, 1), "frac_8d": round(bytes_8d / seconds / 1e9 / peak_hbm_gbs, 4),
+                "frac_8d_is": "SURVEY 8d's formula (passes x n_rows x dim x 4 B / t / 8 TB/s): fp32 bytes the screened kernel never reads -- a footnote",
+                "traffic": traffic, "traffic_source": traffic_source,   # measured HBM bytes per search (the caller's: profiles/pmc_knn_*.json)
+                "mfma_tflops": round(mfma_tf, 2), "mfma_frac": round(mfma_tf / mfma_peak, 4),
+                "mfma_peak_used": "fp16 dense 2500 TF" if screened else "fp32 157.3 TF",
+                "avg_search_ms": round(seconds * 1e3, 4)})
+    return out
 
 
 # ---- K4 ------------------------------------------------------------------------------------------

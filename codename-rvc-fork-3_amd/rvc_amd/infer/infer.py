@@ -192,7 +192,10 @@ class VoiceConverter:
                         if i >= len(audios):
                             break
                         a = audios[i]
-                        if torch.is_tensor(a) or kwargs.get("split_audio") or kwargs.get("noise_seed") is not None:
+                        # (a host array longer than x_max is filtered on the host BEFORE its upload -- Pipeline.pipeline's long-input
+                        # branch -- so it takes the plain host path: no device -> host copy of the input, one synchronise at its end)
+                        long_host = not torch.is_tensor(a) and len(a) + self.vc.window > self.vc.t_max
+                        if torch.is_tensor(a) or long_host or kwargs.get("split_audio") or kwargs.get("noise_seed") is not None:
                             results[i] = self.convert_array(a, **kwargs)
                             continue
                         slot = slots[k & 1]

@@ -377,29 +377,45 @@ class Pipeline:
         big_npy = index.vectors if index is not None else None
         # high-pass, split points and padding stay float64 but run in HBM (the reference does them in NumPy/SciPy)
         as_tensor = torch.is_tensor(audio)
-        if as_tensor:
-            audio = audio.to(device=self.device, dtype=torch.float64)
-        else:
+        n_in = int(audio.shape[0])
+        long_input = n_in + self.window > self.t_max
+        if long_input:
+            # Long inputs are cut at arg-min positions of a 160-tap box sum of the filtered signal (below); this direct-form
+            # high-pass amplifies 1-ulp differences to ~2e-8, enough to move such an arg-min, so the split integers are only
+            # reproducible with SciPy's exact SEQUENTIAL recurrence -- 2 x n dependent float64 steps of three operations each, which
+            # one GPU lane walks at ~75-96 ns a step (45-140 ms per 45 s clip; measured, csrc/filtfilt.hip) against ~9 ms for
+            # SciPy's C loop: that one filter runs on the host.  The reference's boundary hands over a HOST array (pipeline.py:509),
+            # so the filter runs on it BEFORE the upload: no device -> host copy, no stream synchronisation.  Only the HBM-resident
+            # entry (a device tensor in: bench.py's `value`) pays a copy each way.
+            host = audio.detach().to(dtype=torch.float64).cpu().numpy() if as_tensor else np.ascontiguousarray(audio, dtype=np.float64)
+            filtered = np.ascontiguousarray(signal.filtfilt(bh, ah, host))
             with torch.cuda.device(self.device):
-                audio = _pinned.upload(np.ascontiguousarray(audio, dtype=np.float64), self.device)
-        if audio.shape[0] + self.window > self.t_max:
-            # long inputs are cut at arg-min positions of a 160-tap box sum of the filtered signal (below); this
-            # direct-form high-pass amplifies 1-ulp differences to ~2e-8, enough to move such an arg-min, so the split
-            # integers are only reproducible with SciPy's exact sequential recurrence: run that one on the host
-            audio = torch.from_numpy(np.ascontiguousarray(signal.filtfilt(bh, ah, audio.cpu().numpy()))).to(self.device)
+                audio = _pinned.upload(filtered, self.device)
         else:
+            if as_tensor:
+                audio = audio.to(device=self.device, dtype=torch.float64)
+            else:
+                with torch.cuda.device(self.device):
+                    audio = _pinned.upload(np.ascontiguousarray(audio, dtype=np.float64), self.device)
             audio = _native.filtfilt_order5(audio, bh, ah)                  # pipeline.py:562, in HBM
         n_audio = audio.shape[0]
         opt_ts = []
-        if n_audio + self.window > self.t_max:                               # pipeline.py:563-577
+        if long_input:                                                       # pipeline.py:563-577
             pad = F.pad(audio.view(1, 1, -1), (self.window // 2, self.window // 2), mode="reflect").view(-1)
             audio_sum = torch.zeros_like(audio)
             for i in range(self.window):                                     # same 160 sequential float64 adds
                 audio_sum += pad[i: i + n_audio]
-            for t in range(self.t_center, n_audio, self.t_center):
-                seg = audio_sum[t - self.t_query: t + self.t_query].abs()
-                first_min = int(torch.nonzero(seg == seg.min())[0, 0])
-                opt_ts.append(t - self.t_query + first_min)
+            # every split window at once, ONE device -> host read for all the integers: row r = |audio_sum| on
+            # [t_r - t_query, t_r + t_query) (a window that runs past the end is shorter in the reference: masked with +inf here),
+            # split = the FIRST position of the row's minimum (np.where(...)[0][0], pipeline.py:571-576)
+            ts = torch.arange(self.t_center, n_audio, self.t_center, device=self.device)
+            if ts.numel():
+                pos = ts[:, None] - self.t_query + torch.arange(2 * self.t_query, device=self.device)[None, :]
+                inside = pos < n_audio
+                seg = torch.where(inside, audio_sum[pos.clamp(max=n_audio - 1)].abs(), torch.full((), float("inf"), dtype=audio_sum.dtype, device=self.device))
+                is_min = seg == seg.min(dim=1, keepdim=True).values
+                first = torch.where(is_min, torch.arange(2 * self.t_query, device=self.device)[None, :], 2 * self.t_query).min(dim=1).values
+                opt_ts = (ts - self.t_query + first).tolist()
         s = 0
         audio_opt = []
         t = None

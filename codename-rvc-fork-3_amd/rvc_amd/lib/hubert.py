@@ -99,6 +99,14 @@ class HubertModelWithFinalProj:
         if d % cg == 0 and cg in (48, 64) and taps <= 128:
             self._posconv = (_native.posconv_bf16x3_pack_weight(pw, d // cg, self.device), d // cg, taps)
 
+    def _frame_convs_max_samples(self) -> int:
+        """The longest clip the time-major route takes: K12 addresses an operand through one buffer descriptor (< 2 GiB), and the
+        largest operand is layer 0's output, 3 planes x frames padded to 128 x C x 2 B (512 channels: ~218 s of audio).  Longer
+        unsegmented clips fall through to the channel-major route below (Pipeline never sends more than x_max = 41 s at once)."""
+        c = self.w["feature_extractor.conv_layers.0.conv.weight"].shape[0]
+        frames = ((1 << 31) - (1 << 20)) // (6 * c) // 128 * 128 - 128
+        return frames * CONV_STRIDES[0]
+
     def _features_native(self, wav):
         """conv_layers[0..6] of one clip -> [1, frames, C] fp32, time-major (what feature_projection consumes)."""
         from rvc_amd import _native as N
@@ -153,7 +161,8 @@ class HubertModelWithFinalProj:
     @torch.no_grad()
     def __call__(self, wav: torch.Tensor):
         w = self.w
-        if wav.is_cuda and wav.shape[0] == 1 and self._conv_fr and self.frame_convs and wav.shape[1] >= self.frame_convs_min_samples:
+        if wav.is_cuda and wav.shape[0] == 1 and self._conv_fr and self.frame_convs and \
+                self.frame_convs_min_samples <= wav.shape[1] <= self._frame_convs_max_samples():
             return self._encode(self._features_native(wav))
         x = wav[:, None, :]
         for i, s in enumerate(CONV_STRIDES):
@@ -196,10 +205,13 @@ class HubertModelWithFinalProj:
                 x = x[None]
             else:
                 x = F.layer_norm(x + pos[None], (d,), w["encoder.layer_norm.weight"], w["encoder.layer_norm.bias"], 1e-5)
-        else:
-            pos = F.conv1d(x.transpose(1, 2), w["encoder.pos_conv_embed.conv.weight"],
-                           w["encoder.pos_conv_embed.conv.bias"], padding=64, groups=16)
-            x = x + F.gelu(pos[:, :, :-1]).transpose(1, 2)
+        else:   # padding / groups from the weight's own shape, like the native route (HubertPositionalConvEmbedding: padding = taps // 2,
+            pw = w["encoder.pos_conv_embed.conv.weight"]   # one frame dropped when taps is even -- HubertSamePadLayer)
+            taps = pw.shape[2]
+            pos = F.conv1d(x.transpose(1, 2), pw, w["encoder.pos_conv_embed.conv.bias"], padding=taps // 2, groups=d // pw.shape[1])
+            if taps % 2 == 0:
+                pos = pos[:, :, :-1]
+            x = x + F.gelu(pos).transpose(1, 2)
             x = F.layer_norm(x, (d,), w["encoder.layer_norm.weight"], w["encoder.layer_norm.bias"], 1e-5)
         h = self.n_heads
         hd = d // h

@@ -219,5 +219,16 @@ class Farm:
         return Result(d)
 
     def close(self):
+        """Stop the farm NOW: jobs that are already running (30-45 s oracle pipelines on 32 threads each) are terminated, not
+        waited for -- an early-exit session (-x, Ctrl-C, a failed GPU leg) must not keep the host busy, write into the deleted
+        directory or hang in the executor's join at interpreter exit."""
+        procs = list(getattr(self.pool, "_processes", {}).values())   # (no public handle on the workers of a ProcessPoolExecutor)
         self.pool.shutdown(wait=False, cancel_futures=True)
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            p.join(timeout=5)
+            if p.is_alive():
+                p.kill()
         shutil.rmtree(self.dir, ignore_errors=True)

@@ -26,6 +26,34 @@ def rms(x):
     return float(np.sqrt(np.mean(x * x)))
 
 
+# ---- tie-aware f0 comparison (flat-salience synthetic RMVPE): shared by test_fullsize_gpu.py and test_pipeline_gpu.py --------
+SAL_TIE = 2.5e-4   # salience near-tie bound: ~4x the largest GPU-vs-CPU salience difference measured (6e-5, tools/diag_rmvpe.py)
+F0_NOISE = 2e-5    # relative f0 difference that identical arg-max bins produce (measured ~1e-6: the 9-bin weighted mean
+                   # moves with the salience's 1e-5-level differences)
+
+
+def f0_tie_report(f0_p, sal_p, f0_o, sal_o):
+    """Frames where the product's RMVPE contour differs from the oracle's by more than fp noise, each CERTIFIED as a
+    near-tie of the salience arg-max (RMVPE.py:459-512 picks the arg-max bin, then averages +-4 bins around it): the bin
+    the product chose must be within SAL_TIE of the oracle's maximum IN THE ORACLE'S OWN salience, and the two saliences
+    must agree to SAL_TIE everywhere on that frame.  The synthetic (random-weight) RMVPE has a flat, noise-like
+    salience -- median top-2 gap 2e-3, minimum ~1e-6 over 3200 frames -- so two fp32 evaluations of the same network
+    legitimately pick different bins on a frame now and then.  Returns the differing frame indices (all certified)."""
+    n = min(len(f0_p), len(f0_o))
+    f0_p, f0_o, sal_p, sal_o = f0_p[:n], f0_o[:n], sal_p[:n], sal_o[:n]
+    assert np.abs(sal_p - sal_o).max() <= SAL_TIE, np.abs(sal_p - sal_o).max()
+    differ = np.nonzero(np.abs(f0_p - f0_o) > F0_NOISE * np.maximum(f0_o, 1.0))[0]
+    for t in differ:
+        bp, bo = int(sal_p[t].argmax()), int(sal_o[t].argmax())
+        if bp == bo:          # same bin, so the voicing decision differs: max salience within SAL_TIE of the 0.03 threshold
+            assert abs(sal_o[t].max() - 0.03) <= SAL_TIE, (t, f0_p[t], f0_o[t], sal_o[t].max())
+            continue
+        assert sal_o[t, bo] - sal_o[t, bp] <= SAL_TIE, \
+            f"frame {t}: product bin {bp} vs oracle bin {bo} is not a salience near-tie ({sal_o[t, bo] - sal_o[t, bp]:.2e})"
+    return differ
+
+
+
 @pytest.fixture(scope="session")
 def golden():
     return load_golden

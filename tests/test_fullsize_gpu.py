@@ -47,30 +47,7 @@ def _converter(S, sr, voc, hubert, config=None):
     return vc
 
 
-SAL_TIE = 2.5e-4   # salience near-tie bound: ~4x the largest GPU-vs-CPU salience difference measured (6e-5, tools/diag_rmvpe.py)
-F0_NOISE = 2e-5    # relative f0 difference that identical arg-max bins produce (measured ~1e-6: the 9-bin weighted mean
-                   # moves with the salience's 1e-5-level differences)
-
-
-def _f0_tie_report(f0_p, sal_p, f0_o, sal_o):
-    """Frames where the product's RMVPE contour differs from the oracle's by more than fp noise, each CERTIFIED as a
-    near-tie of the salience arg-max (RMVPE.py:459-512 picks the arg-max bin, then averages +-4 bins around it): the bin
-    the product chose must be within SAL_TIE of the oracle's maximum IN THE ORACLE'S OWN salience, and the two saliences
-    must agree to SAL_TIE everywhere on that frame.  The synthetic (random-weight) RMVPE has a flat, noise-like
-    salience -- median top-2 gap 2e-3, minimum ~1e-6 over 3200 frames -- so two fp32 evaluations of the same network
-    legitimately pick different bins on a frame now and then.  Returns the differing frame indices (all certified)."""
-    n = min(len(f0_p), len(f0_o))
-    f0_p, f0_o, sal_p, sal_o = f0_p[:n], f0_o[:n], sal_p[:n], sal_o[:n]
-    assert np.abs(sal_p - sal_o).max() <= SAL_TIE, np.abs(sal_p - sal_o).max()
-    differ = np.nonzero(np.abs(f0_p - f0_o) > F0_NOISE * np.maximum(f0_o, 1.0))[0]
-    for t in differ:
-        bp, bo = int(sal_p[t].argmax()), int(sal_o[t].argmax())
-        if bp == bo:          # same bin, so the voicing decision differs: max salience within SAL_TIE of the 0.03 threshold
-            assert abs(sal_o[t].max() - 0.03) <= SAL_TIE, (t, f0_p[t], f0_o[t], sal_o[t].max())
-            continue
-        assert sal_o[t, bo] - sal_o[t, bp] <= SAL_TIE, \
-            f"frame {t}: product bin {bp} vs oracle bin {bo} is not a salience near-tie ({sal_o[t, bo] - sal_o[t, bp]:.2e})"
-    return differ
+from conftest import SAL_TIE, F0_NOISE, f0_tie_report as _f0_tie_report  # noqa: E402  (shared with test_pipeline_gpu.py)
 
 
 def _run_pair(farm, key, vc, hubert, audio, rate, seed):
@@ -329,12 +306,17 @@ def test_decoder_T3198_stage_by_stage_vs_oracle(S, oracle_farm, case):
     assert err <= 5e-5, err
 
 
-def test_convert_batch_full_length_inflight2_equals_sequential(S, hubert, monkeypatch):
-    """The benchmarked MODE at the benchmarked LENGTH: four 30 s utterances through convert_batch with two in flight (cfg 2:
-    48 k NSF vocoder, 100 k index, index_rate 0.75) against the same four converted one at a time.  The synthesizer's random
-    draws are zeroed so that both runs are deterministic; every kernel of one utterance (vocoder included) then runs next to
-    the other utterance's HuBERT / retrieval / vocoder kernels for the whole 30 s, which the 3-6 s clips of
-    test_convert_batch_inflight_equals_sequential do not give.  Gate 1e-5: the library GEMMs are not bit-stable run to run."""
+@pytest.mark.parametrize("cfg", [2, 4, 5])
+def test_convert_batch_full_length_inflight2_equals_sequential(S, hubert, monkeypatch, cfg):
+    """The benchmarked MODE at the benchmarked LENGTH, for every vocoder bench.py runs that way: four 30 s utterances through
+    convert_batch with two in flight against the same four converted one at a time -- cfg 2 (48 k NSF vocoder), cfg 4 (MRF vocoder,
+    bf16 weight storage: K3f with one-term taps next to K3y) and cfg 5 (RefineGAN, whose narrow layers still run wino_conv_kernel,
+    the kernel that profiles/r05_mfma_cohabitation.txt shows returning wrong words next to a co-resident bf16-matrix workgroup: here
+    it runs for 30 s beside the OTHER utterance's bf16 kernels, kept apart only by their whole-CU LDS request), 100 k index,
+    index_rate 0.75.  The synthesizer's random draws are zeroed (RefineGAN: its 24 AdaIN noise tensors too) so that both runs are
+    deterministic; every kernel of one utterance then runs next to the other utterance's HuBERT / retrieval / vocoder kernels for
+    the whole 30 s, which the 3-6 s clips of test_convert_batch_inflight_equals_sequential do not give.  Gate 1e-5: the library
+    GEMMs are not bit-stable run to run."""
     from rvc_amd.infer.infer import VoiceConverter
     from rvc_amd.lib.algorithm.synthesizers import Synthesizer
     real_draw = Synthesizer._draw
@@ -344,7 +326,10 @@ def test_convert_batch_full_length_inflight2_equals_sequential(S, hubert, monkey
 
     monkeypatch.setattr(Synthesizer, "_draw", zero_draw)
     vc = VoiceConverter(device=DEV)
-    vc.load_checkpoint_dict(S.make_synth_checkpoint(48000, "HiFi-GAN", seed=0, smooth_pitch=True))
+    voc = {2: "HiFi-GAN", 4: "MRF HiFi-GAN", 5: "RefineGAN"}[cfg]
+    if cfg == 4:
+        vc.dec_weight_dtype = "bf16"
+    vc.load_checkpoint_dict(S.make_synth_checkpoint(48000, voc, seed=0, smooth_pitch=True))
     vc.hubert_model = hubert
     vc.vc.load_rmvpe_state_dict(S.make_rmvpe_state_dict(0, peaked=True))
     vc.vc.set_index(S.synth_index(100_000, seed=0))
@@ -359,7 +344,8 @@ def test_convert_batch_full_length_inflight2_equals_sequential(S, hubert, monkey
             assert a.shape == b_.shape == (1_439_040,)
             assert bool(torch.isfinite(b_).all())
             worst = max(worst, rms((a - b_).cpu().numpy()))
-    print(f"4 x 30 s, two in flight vs one at a time (zero noise): worst waveform rms difference {worst:.3e} (signal rms {rms(seq[0].cpu().numpy()):.3f})")
+    print(f"cfg {cfg} ({voc}): 4 x 30 s, two in flight vs one at a time (zero noise): worst waveform rms difference {worst:.3e} (signal rms {rms(seq[0].cpu().numpy()):.3f})")
+    assert rms(seq[0].cpu().numpy()) > 0.02
     assert worst <= 1e-5, worst
 
 

@@ -4,12 +4,15 @@ Run on the MI355X box: python -m pytest tests -m gpu.  Tolerances are stated at 
 integer outputs (neighbour ids) are exact up to documented near-ties; waveforms are gated at the
 north_star's 1e-3 RMS with the observed error asserted far below it.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import load_golden, rms
+from conftest import REPO, load_golden, rms
 
 pytestmark = pytest.mark.gpu
 
@@ -189,7 +192,7 @@ def test_resblock_pair_bf16x3_matches_float64(native, dev, c, k, dil, length, ba
     (32, 3, 1, 4096, 1), (32, 3, 5, 1000, 2), (32, 7, 3, 749, 2), (32, 7, 5, 16384, 1), (32, 11, 1, 2051, 1), (32, 11, 5, 513, 2),
     (32, 11, 5, 31, 1), (32, 3, 1, 5, 1), (64, 3, 5, 777, 2), (64, 7, 1, 5003, 1), (64, 11, 1, 2051, 1), (64, 11, 5, 9999, 2),
     (64, 11, 3, 117, 1), (128, 3, 3, 1237, 2), (128, 7, 1, 2051, 1), (128, 7, 5, 777, 1), (128, 7, 3, 50, 1),
-    (32, 11, 5, 1535040, 1), (64, 11, 3, 767520, 1), (64, 7, 1, 767520, 1), (128, 7, 5, 383760, 1), (128, 3, 1, 383760, 1),   # the cfg-4 stage shapes
+    (32, 11, 5, 1535040, 1), (64, 11, 3, 767520, 1), (128, 7, 5, 383760, 1),   # the cfg-4 stage shapes
 ])
 def test_resblock_pair_bf16_taps_matches_float64(native, dev, c, k, dil, length, batch):
     """K3f with ONE-TERM taps (rvc_resblock_bf16w_*): BASELINE cfg 4's "alt ResBlock kernel path" -- the MRF layer
@@ -228,6 +231,47 @@ def test_resblock_pair_bf16_taps_matches_float64(native, dev, c, k, dil, length,
     assert r1 <= 1.5 * r3 + 1e-8
     again = native.resblock_bf16x3_forward(xd, u1, None, None, k, dil, 0.1, bf16_taps=True).cpu()
     assert torch.equal(again, plain)                      # bit-reproducible
+
+
+@pytest.mark.parametrize("c,form", [(32, "three"), (64, "three"), (128, "three"), (32, "one"), (64, "one"), (128, "one")])
+def test_resblock_pair_fresh_buffers_right_after_load(c, form):
+    """ADVICE round 5 (resblock_bf.hip:290): K3f is the default path of the narrow stages and carries a race that was removed by
+    reordering the stager prologue without being explained (profiles/r05_rbf_notes.txt item 5: wrong second tiles on the FIRST
+    launches into FRESH output buffers).  tools/stress_rbf.py reproduces that regime in a child process whose first GPU work it is:
+    every benchmarked (taps, dilation) of this channel count, 50 launches each into 50 never-written buffers (25 untouched, 25
+    NaN-poisoned), all bit-equal to the first and the first equal to the fp32 direct-form pair."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "stress_rbf.py"), str(c), form, "50"], capture_output=True, text=True, timeout=900)
+    print(r.stdout[-4000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_resblock_pair_runtime_switch(native, dev):
+    """rvc_resblock_bf16x3_set_enabled(0): the operator's fall-back without a rebuild -- a decoder finalized while the switch is off runs
+    its narrow stages on the unfused kernels (launch_resblock_layer / winobf / wino) and must give the waveform of the default
+    handle to fp32 accumulation noise; handles finalized earlier are not affected; the switch is restored."""
+    from rvc_amd.lib import synthetic as S
+    from rvc_amd.lib.algorithm.weights import fold_weight_norm
+    cpt = S.make_synth_checkpoint(48000, "HiFi-GAN", seed=0)
+    folded = {k[4:]: v for k, v in fold_weight_norm(cpt["weight"]).items() if k.startswith("dec.")}
+    T = 300
+    g = torch.Generator(device=dev).manual_seed(5)
+    args = (torch.randn(1, 192, T, device=dev, generator=g), torch.full((1, T), 220.0, device=dev), torch.randn(1, 256, device=dev, generator=g))
+    kw = dict(src_randn=torch.randn(1, T * 480, 1, device=dev, generator=g), src_rand=torch.zeros(1, 1, device=dev))
+    on = native.Decoder("HiFi-GAN", 48000, folded)
+    ref = on.forward(*args, **kw).clone()
+    native.resblock_bf16x3_set_enabled(False)
+    try:
+        off = native.Decoder("HiFi-GAN", 48000, folded)
+        out_off = off.forward(*args, **kw).clone()
+        assert torch.equal(on.forward(*args, **kw), ref)          # the earlier handle keeps its kernels
+    finally:
+        native.resblock_bf16x3_set_enabled(True)
+    again = native.Decoder("HiFi-GAN", 48000, folded).forward(*args, **kw)
+    assert torch.equal(again, ref)
+    e = rms((out_off - ref).cpu().numpy())
+    print(f"K3f off vs on: waveform rms difference {e:.2e} (signal rms {rms(ref.cpu().numpy()):.3f})")
+    assert 0.0 < e <= 2e-6, e                                      # (exactly 0 would mean the switch changed nothing)
 
 
 @pytest.mark.parametrize("n_rows,k,m,mode,k_parts", [
@@ -748,7 +792,7 @@ def test_decoder_full_synth_golden(native, dev, ref_inputs):
     assert rms(out - g["o"]) <= 5e-5, rms(out - g["o"])
 
 
-@pytest.mark.parametrize("co", ["gemmbf", "winobf2", "knn_screen", "attention_bf", "resblock_bf", "linear_presplit"])
+@pytest.mark.parametrize("co", ["gemmbf", "winobf2", "winobf", "knn_screen", "attention_bf", "resblock_bf", "resblock_bf1", "linear_presplit", "posconv"])
 @pytest.mark.parametrize("k,c", [(11, 128), (3, 64), (7, 32)])
 def test_fp32_winograd_next_to_the_bf16_gemm_is_bit_exact(native, dev, k, c, co):
     """Regression test of profiles/r03_mfma_cohabitation.txt / r04_mfma_cohabitation.txt: while one thread launches a kernel that
@@ -766,10 +810,19 @@ def test_fp32_winograd_next_to_the_bf16_gemm_is_bit_exact(native, dev, k, c, co)
         ub = native.conv1d_winobf_pack_weight(torch.randn(128, 128, 11, generator=g) * 0.03, dev)
         xb = torch.randn(1, 128, 100000, generator=g).to(dev)
         bb = torch.zeros(128, device=dev)
+    if co == "winobf":       # K3x: the 64-row form (c_out % 128 != 0)
+        ub = native.conv1d_winobf_pack_weight(torch.randn(64, 64, 11, generator=g) * 0.03, dev)
+        xb = torch.randn(1, 64, 200000, generator=g).to(dev)
+        bb = torch.zeros(64, device=dev)
+    if co == "posconv":      # K14
+        pw = native.posconv_bf16x3_pack_weight(torch.randn(768, 48, 128, generator=g) * 0.02, 16, dev)
+        pb = torch.zeros(768, device=dev)
+        pxp = torch.randn(1599, 768, generator=g).to(dev)
     if co == "attention_bf":
         qkv = (torch.randn(1, 1599, 3 * 12 * 64, generator=g) * 1.5).to(dev)
-    if co == "resblock_bf":
-        up = native.resblock_bf16x3_pack_weight(torch.randn(32, 32, 7, generator=g) * 0.03, torch.randn(32, 32, 7, generator=g) * 0.03, dev)
+    if co in ("resblock_bf", "resblock_bf1"):
+        up = native.resblock_bf16x3_pack_weight(torch.randn(32, 32, 7, generator=g) * 0.03, torch.randn(32, 32, 7, generator=g) * 0.03, dev,
+                                                bf16_taps=co == "resblock_bf1")
         xp = torch.randn(1, 32, 400000, generator=g).to(dev)
         yp = torch.empty_like(xp)
     if co == "linear_presplit":
@@ -798,8 +851,12 @@ def test_fp32_winograd_next_to_the_bf16_gemm_is_bit_exact(native, dev, k, c, co)
                     native.conv1d_winobf_forward(xb, ub, bb, 128, 11, 1, 0.1)
                 elif co == "attention_bf":
                     native.attention_qkv(qkv, 12, 0.125)
-                elif co == "resblock_bf":
-                    native.resblock_bf16x3_forward(xp, up, None, None, 7, 3, 0.1, out=yp)
+                elif co == "winobf":
+                    native.conv1d_winobf_forward(xb, ub, bb, 64, 11, 1, 0.1)
+                elif co == "posconv":
+                    native.posconv_gelu_bf16x3(pxp, pw, pb, 16, 128, 64)
+                elif co in ("resblock_bf", "resblock_bf1"):
+                    native.resblock_bf16x3_forward(xp, up, None, None, 7, 3, 0.1, out=yp, bf16_taps=co == "resblock_bf1")
                 elif co == "linear_presplit":
                     native.linear_bf16x3_presplit(xl, al, None, 1599, 3072, "gelu_planes")
                 else:

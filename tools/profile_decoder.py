@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Decoder-only run for rocprofv3 (BASELINE cfg-2 shape: T = 3198 frames, NSF 48k)."""
+"""Decoder-only run for rocprofv3 (BASELINE cfg-2 shape: T = 3198 frames, NSF 48k).  usage: profile_decoder.py [vocoder [f32|bf16]]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "codename-rvc-fork-3_amd")]
@@ -10,7 +10,8 @@ from rvc_amd.lib.algorithm.weights import fold_weight_norm
 voc = sys.argv[1] if len(sys.argv) > 1 else "HiFi-GAN"
 cpt = S.make_synth_checkpoint(48000, voc, seed=0)
 folded = {k[4:]: v for k, v in fold_weight_norm(cpt["weight"]).items() if k.startswith("dec.")}
-dec = _native.Decoder(voc, 48000, folded)
+storage = sys.argv[2] if len(sys.argv) > 2 else "f32"       # "bf16": BASELINE cfg 4's weight storage (K3f with one-term taps)
+dec = _native.Decoder(voc, 48000, folded, **({"weight_storage": "bf16"} if storage == "bf16" else {}))
 dev = "cuda:0"
 T = 3198
 dim = 9 if voc.startswith("MRF") else 1
