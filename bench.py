@@ -333,8 +333,9 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": ("f32 activations x bf16-stored vocoder taps (7/11-tap convs, 3-tap ones at >= 128 channels: bf16x3 Winograd fragments of the bf16-valued taps on the bf16 "
-                  "matrix cores, fp32 accumulate; 3-tap and 32-channel layers: fp32 matrix instruction on taps widened from bf16)")
+        "dtype": ("f32 activations x bf16-stored vocoder taps (C <= 64, and C = 128 at 3 / 7 taps: direct-form fused pairs with ONE-TERM taps -- a bf16-valued tap is "
+                  "its own first split, three bf16 products per multiply-add against exact bf16x3 activations; C = 256 and C = 128 at 11 taps: bf16x3 Winograd "
+                  "fragments of the bf16-valued taps; fp32 accumulate everywhere)")
                  if cfg["weights"] == "bf16" else
                  "f32 (vocoder 7/11-tap convs and 3-tap ones at >= 128 channels: fp32 operands as exact bf16x3 splits on the bf16 matrix cores, fp32 accumulate)",
         "data": "synthetic (seeded random-init weights, FM-tone utterances, clustered index)",
@@ -553,11 +554,18 @@ def control_flow_only(torch, D, args, cfg, rank, world):
     assert D.checksums_agree(idx)
     mine = D.shard_indices(args.steps * world, rank, world)
     total, t_max = D.reduce_report(len(mine) * 1000, 1.0 + 0.001 * rank, "cpu")
+    secs = D.gather_seconds(1.0 + 0.001 * rank, "cpu")
     info = D.last_broadcast_info()
     if rank == 0:
         print(json.dumps({"metric": "control-flow-only (no kernels, no throughput)", "value": None, "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ranks": torch.distributed.get_world_size() if world > 1 else 1,
-                          "rccl_ranks": None, "index_broadcast": {"transport": info.get("transport"), "n_ranks": info.get("n_ranks", 1)},
+                          "rccl_ranks": None,
+                          "index_broadcast": {"transport": info.get("transport"), "n_ranks": info.get("n_ranks", 1), "bytes": info.get("bytes"),
+                                              "seconds": info.get("seconds"),
+                                              "gbps": round(info.get("bytes", 0) / max(info.get("seconds") or 0.0, 1e-9) / 1e9, 3) if world > 1 else None},
+                          # the same self-diagnosis fields the measured line carries: per-rank spread of the timed region
+                          "ms_per_step_ranks": {"min": round(min(secs) / args.steps * 1e3, 2), "max": round(max(secs) / args.steps * 1e3, 2),
+                                                "all": [round(t / args.steps * 1e3, 2) for t in secs]},
                           "total_samples": total, "t_max": t_max, "baseline_config": args.config}), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -38,7 +38,8 @@ struct ConvParams {
     float out_scale = 1.f;
     int batch = 1;
     const uint32_t *w_wino16 = nullptr;   // ... stored as bf16 pairs (with w16)
-    const void *w_winobf = nullptr;  // the transformed taps as bf16x3 matrix-instruction fragments (winobf.hip): taken first where it applies
+    const void *w_direct1 = nullptr; // bf16-VALUED taps as one-term direct-form fragments (convbf1.hip, K3d): taken first where it applies
+    const void *w_winobf = nullptr;  // the transformed taps as bf16x3 matrix-instruction fragments (winobf.hip): taken next
     const float *w_wino = nullptr;   // the same taps in wino.hip's layout: launch_conv may take the fast (Winograd) form for
                                      // plain 3 / 7 / 11-tap layers where it is the faster one
     int debug = 0;   // experiments only (RVC_CONV_DEBUG): 1 = skip x loads, 2 = skip y stores, 4 = skip res loads
@@ -72,6 +73,16 @@ size_t resblock_bf_weight_bytes(int c, int k, int tap_splits = 3);
 void resblock_bf_pack_host(const float *w1, const float *w2, int c, int k, std::vector<uint16_t> *out, int tap_splits = 3);   // w: [c][c][k]
 int launch_resblock_bf(const float *x, const void *u, const float *b1, const float *b2, const float *accin, float *y, int batch, int c,
                        int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream, int tap_splits = 3);
+
+// one square conv with bf16-VALUED taps in direct form on the bf16 matrix cores, one-term taps x exact bf16x3 activations (convbf1.hip,
+// K3d): C = 128 / 256; same semantics as launch_winobf2_conv (y must not alias x)
+bool convbf1_supported(int c, int k, int dil);
+bool convbf1_preferred(int c, int k);       // the layers of a bf16-storage handle that take it (measured): the ones K3f cannot hold
+bool convbf1_fits(int c, int64_t L);
+size_t convbf1_weight_bytes(int c, int k);
+void convbf1_pack_host(const float *w, int c, int k, std::vector<uint16_t> *out);   // w: [c][c][k], rounded to bf16 here
+int launch_convbf1(const float *x, const void *u, const float *bias, const float *res, const float *accin, float *y, int batch, int c,
+                   int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream);
 
 // fp32 -> bf16, round to nearest even (what torch's .bfloat16() does); NaN stays NaN
 static inline uint16_t bf16_rne(float f) {

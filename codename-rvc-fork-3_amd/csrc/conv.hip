@@ -464,6 +464,9 @@ int launch_conv(const ConvParams &p_in, hipStream_t stream) {
     const bool plain = !p_in.x2 && p_in.up_stride == 0 && p_in.bias_bstride == 0 &&
         p_in.l_in == p_in.l_out && p_in.n_cols == p_in.l_out && p_in.x1_bstride == (int64_t)p_in.c1 * p_in.l_in &&
         p_in.y_bstride == (int64_t)p_in.m_total * p_in.l_out && p_in.slope1 >= 0.f && p_in.slope1 <= 1.f && p_in.padl == (p_in.kw - 1) / 2 * p_in.dil;
+    if (p_in.w_direct1 && plain && p_in.c1 == p_in.m_total && p_in.x1 != p_in.y && convbf1_supported(p_in.c1, p_in.kw, p_in.dil) && convbf1_fits(p_in.c1, p_in.l_in))
+        return launch_convbf1(p_in.x1, p_in.w_direct1, p_in.bias, p_in.res, p_in.accin, p_in.y, p_in.batch, p_in.c1, p_in.l_out, p_in.kw, p_in.dil,
+                              p_in.slope1, p_in.out_scale, stream);
     if (p_in.w_winobf && plain && wino_enabled() && winobf_enabled() && winobf_supported(p_in.c1, p_in.m_total, p_in.kw, p_in.dil) &&
         winobf_fits(p_in.c1, p_in.m_total, p_in.l_in))
         return launch_winobf_conv(p_in.x1, p_in.w_winobf, p_in.bias, p_in.res, p_in.accin, p_in.y, p_in.batch, p_in.c1, p_in.m_total, p_in.l_out,

@@ -46,6 +46,7 @@ struct ConvW {
     DevBuf wu;                    // square 3 / 7 / 11-tap layers: the taps again in wino.hip's layout
     DevBuf16 wu16;                // ... as bf16 pairs when the handle stores bf16 (two uint16 per word)
     DevBuf16 wx;                  // square 7 / 11-tap layers at >= 64 channels (fp32 storage): transformed taps split in three bf16 (winobf.hip)
+    DevBuf16 wd;                  // bf16 storage, 128 / 256 channels where the fused pair does not apply: one-term direct-form fragments (convbf1.hip)
     int c_in = 0, c_out = 0, k = 0;
 };
 

@@ -455,6 +455,11 @@ int build_conv(const rvc_decoder *d, const std::string &prefix, int c_out, int c
             std::vector<uint16_t> halves(words.size() * 2);
             memcpy(halves.data(), words.data(), words.size() * 4);
             if (out->wu16.upload(halves)) return 1;
+            if (convbf1_supported(c_out, k, 1) && convbf1_preferred(c_out, k)) {   // direct form with one-term taps (K3d): taken before the Winograd form
+                std::vector<uint16_t> frags;
+                convbf1_pack_host(w->data.data(), c_out, k, &frags);
+                if (out->wd.upload(frags)) return 1;
+            }
             if (winobf_enabled() && winobf_supported(c_in, c_out, k, 1)) {   // the bf16-matrix-core form on the bf16-VALUED taps: a transformed
                 std::vector<float> vals((size_t)c_out * c_in * k);           // tap is a sum of four of them and needs its three-way split like any other
                 for (size_t i = 0; i < vals.size(); ++i) {
@@ -962,14 +967,14 @@ extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const flo
                 const int dil = c.res_dilations[j];
                 ConvParams p;
                 p.x1 = xin; p.c1 = s.c_out; p.slope1 = 0.1f; p.x1_bstride = bs; p.l_in = len;
-                p.w = s.c1[m * nd + j].w.p; p.w16 = s.c1[m * nd + j].w16.p; p.bias = s.c1[m * nd + j].b.p; p.w_wino = s.c1[m * nd + j].wu.p; p.w_winobf = s.c1[m * nd + j].wx.p;
+                p.w = s.c1[m * nd + j].w.p; p.w16 = s.c1[m * nd + j].w16.p; p.bias = s.c1[m * nd + j].b.p; p.w_wino = s.c1[m * nd + j].wu.p; p.w_winobf = s.c1[m * nd + j].wx.p; p.w_direct1 = s.c1[m * nd + j].wd.p;
                 p.w_wino16 = reinterpret_cast<const uint32_t *>(s.c1[m * nd + j].wu16.p);
                 p.y = T1; p.y_bstride = bs; p.m_total = s.c_out; p.c_out = s.c_out; p.n_cols = len; p.l_out = len;
                 p.kw = k; p.dil = dil; p.padl = (k - 1) / 2 * dil; p.batch = batch;
                 if (launch_conv(p, stream)) return 1;
                 ConvParams q;
                 q.x1 = T1; q.c1 = s.c_out; q.slope1 = 0.1f; q.x1_bstride = bs; q.l_in = len;
-                q.w = s.c2[m * nd + j].w.p; q.w16 = s.c2[m * nd + j].w16.p; q.bias = s.c2[m * nd + j].b.p; q.w_wino = s.c2[m * nd + j].wu.p; q.w_winobf = s.c2[m * nd + j].wx.p;
+                q.w = s.c2[m * nd + j].w.p; q.w16 = s.c2[m * nd + j].w16.p; q.bias = s.c2[m * nd + j].b.p; q.w_wino = s.c2[m * nd + j].wu.p; q.w_winobf = s.c2[m * nd + j].wx.p; q.w_direct1 = s.c2[m * nd + j].wd.p;
                 q.w_wino16 = reinterpret_cast<const uint32_t *>(s.c2[m * nd + j].wu16.p);
                 q.res = xin;
                 q.y_bstride = bs; q.m_total = s.c_out; q.c_out = s.c_out; q.n_cols = len; q.l_out = len;

@@ -122,6 +122,10 @@ SYMBOLS = {
     "rvc_resblock_bf16w_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int,
                                            c_int, c_float, c_float, c_void_p]),
     "rvc_resblock_bf16x3_set_enabled": (c_int, [c_int]),
+    "rvc_conv1d_bf16w_weight_bytes": (c_int, [c_int, c_int, POINTER(c_size_t)]),
+    "rvc_conv1d_bf16w_pack_weight": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "rvc_conv1d_bf16w_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int,
+                                         c_int, c_float, c_float, c_void_p]),
     "rvc_gemm_bf16x3_weight_bytes": (c_int, [c_int, c_int, POINTER(c_size_t)]),
     "rvc_gemm_bf16x3_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rvc_linear_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
@@ -638,6 +642,34 @@ def resblock_bf16x3_forward(x, u_packed, b1, b2, k, dilation=1, slope=0.1, acc=N
     _check(getattr(_lib, name)(x.data_ptr(), u_packed.data_ptr(), b1.data_ptr() if b1 is not None else None,
                                b2.data_ptr() if b2 is not None else None, acc.data_ptr() if acc is not None else None,
                                y.data_ptr(), b, c, length, k, dilation, float(slope), float(out_scale), _stream()), name)
+    return y
+
+
+# ---- K3d: one square conv with bf16-valued taps, direct form (C = 128 / 256) --------------------------------------
+def conv1d_bf16w_pack_weight(w: torch.Tensor, device) -> torch.Tensor:
+    """nn.Conv1d weight [c, c, k] -> one-term direct-form fragment slab on the device (the taps ROUNDED to bf16)."""
+    w = w.detach().float().cpu().contiguous()
+    c, c_in, k = w.shape
+    if c != c_in:
+        raise NativeError(f"conv1d_bf16w: a square conv expected, got {tuple(w.shape)}")
+    n = c_size_t()
+    _check(_lib.rvc_conv1d_bf16w_weight_bytes(c, k, ctypes.byref(n)), "rvc_conv1d_bf16w_weight_bytes")
+    u = torch.empty(n.value // 2, dtype=torch.int16, device=device)
+    _check(_lib.rvc_conv1d_bf16w_pack_weight(w.data_ptr(), c, k, u.data_ptr(), _stream()), "rvc_conv1d_bf16w_pack_weight")
+    return u
+
+
+def conv1d_bf16w_forward(x, u_packed, bias, k, dilation=1, slope_in=1.0, res=None, acc=None, out_scale=1.0, out=None):
+    """y = out_scale * (conv_d(leaky(x, slope_in)) + bias [+ res] [+ acc]) for x [B, C, L] in HBM, C = 128 / 256 (K3d)."""
+    x = _dev_f32(x, "x")
+    b, c, length = x.shape
+    y = out if out is not None else torch.empty_like(x)
+    if y.data_ptr() == x.data_ptr():
+        raise NativeError("conv1d_bf16w: x and y must not alias")
+    _check(_lib.rvc_conv1d_bf16w_forward(x.data_ptr(), u_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                         res.data_ptr() if res is not None else None, acc.data_ptr() if acc is not None else None,
+                                         y.data_ptr(), b, c, length, k, dilation, float(slope_in), float(out_scale), _stream()),
+           "rvc_conv1d_bf16w_forward")
     return y
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RVC_AMD_ABI_VERSION 4   /* 3: round-5 additions (K3f, K12-K14, branch streams); 4: round-6 additions (K3f with one-term taps, its runtime switch); no existing signature changed */
+#define RVC_AMD_ABI_VERSION 4   /* 3: round-5 additions (K3f, K12-K14, branch streams); 4: round-6 additions (K3f / K3d with one-term taps, K3f's runtime switch); no existing signature changed */
 
 /* ---- library ------------------------------------------------------------------------------------ */
 
@@ -401,6 +401,18 @@ int rvc_resblock_bf16w_pack_weight(const float *w1_host, const float *w2_host, i
 int rvc_resblock_bf16w_forward(const float *x_dev, const void *u_dev, const float *b1_dev, const float *b2_dev,
                                const float *acc_dev, float *y_dev, int batch, int c, int64_t length, int k, int dilation,
                                float slope, float out_scale, void *stream);
+/* ---- K3d: ONE square conv with bf16-VALUED taps, direct form, for the layers the fused pair cannot hold in LDS ------------------ *
+ * Replaces one conv of the same ResBlock / MRFLayer body (rvc/lib/algorithm/residuals.py:75-86, hifigan_mrf.py:13-83) at
+ * C = 256 (K = 3, 7, 11) and C = 128 (K = 11; K = 3 / 7 accepted too) in a decoder handle created with weight_storage = 1:
+ *     y = out_scale * (conv_d(leaky(x, slope)) + bias [+ res] [+ acc])
+ * One-term taps (rounded to bf16 by pack_weight, round to nearest even) against activations split exactly into three bf16: three
+ * matrix products per multiply-add, no Winograd transform; persistent 8-wave workgroups walking (64 columns x all channels) tiles
+ * (csrc/convbf1.hip).  dilation 1..5, C * L * 4 < 2^31; y must not alias x (res and acc may alias y). */
+int rvc_conv1d_bf16w_weight_bytes(int c, int k, size_t *bytes);
+int rvc_conv1d_bf16w_pack_weight(const float *w_host, int c, int k, void *u_dev, void *stream);
+int rvc_conv1d_bf16w_forward(const float *x_dev, const void *u_dev, const float *bias_dev, const float *res_dev,
+                             const float *acc_dev, float *y_dev, int batch, int c, int64_t length, int k, int dilation,
+                             float slope_in, float out_scale, void *stream);
 /* Process-wide runtime switch for K3f inside rvc_decoder_finalize (default 1): decoder handles finalized while it is 0 keep the
  * (conv, conv) pairs of their narrow stages on the unfused kernels (csrc/resblock.hip, winobf.hip, wino.hip) -- the fall-back an
  * operator reaches for without rebuilding the library.  The entry points above are not affected. */

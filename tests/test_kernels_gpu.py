@@ -233,11 +233,55 @@ def test_resblock_pair_bf16_taps_matches_float64(native, dev, c, k, dil, length,
     assert torch.equal(again, plain)                      # bit-reproducible
 
 
-@pytest.mark.parametrize("c,form", [(32, "three"), (64, "three"), (128, "three"), (32, "one"), (64, "one"), (128, "one")])
+@pytest.mark.parametrize("c,k,dil,length,batch", [
+    (128, 11, 1, 4096, 1), (128, 11, 3, 4097, 1), (128, 11, 5, 777, 2), (128, 3, 1, 1000, 1), (128, 7, 5, 31, 1), (128, 11, 5, 63, 1),
+    (256, 3, 1, 2051, 1), (256, 7, 3, 1237, 2), (256, 11, 5, 5003, 1), (256, 11, 1, 64, 1), (256, 7, 1, 65, 1), (256, 11, 3, 9999, 1),
+    (128, 11, 5, 383760, 1), (256, 11, 3, 38376, 1), (256, 7, 5, 38376, 1),   # the cfg-4 stage shapes
+])
+def test_conv1d_bf16_taps_direct_matches_float64(native, dev, c, k, dil, length, batch):
+    """K3d (convbf1.hip, rvc_conv1d_bf16w_*): one square conv of the MRF layer (hifigan_mrf.py:13-83 = residuals.py:75-86) with bf16-stored
+    taps in direct form -- one-term taps x exact bf16x3 activations -- at the channel counts the fused pair cannot hold (C = 256;
+    C = 128 with 11 taps).  Against F.conv1d in float64 on the bf16-ROUNDED taps with the fused activation, bias, residual, running sum
+    and scale; every dilation, lengths shorter than a tile / not a multiple of anything (the element-wise store path), several tiles
+    per block (persistent loop), batch > 1, res aliasing y (how the decoder calls it).  Gate: the bf16x3 Winograd form's (6e-5 at
+    |y| ~ 1); the relative RMS error must not exceed 1.5 x the Winograd form's on fragments of the same rounded taps; bit-reproducible."""
+    g = torch.Generator().manual_seed(c * 1000 + k * 10 + dil + 3)
+    x = torch.randn(batch, c, length, generator=g)
+    w = torch.randn(c, c, k, generator=g) / (c * k) ** 0.5
+    wr = w.bfloat16().float()
+    b = torch.randn(c, generator=g)
+    res = torch.randn(batch, c, length, generator=g)
+    acc = torch.randn(batch, c, length, generator=g)
+    ref = (conv1d_f64(F.leaky_relu(x.double(), 0.1), wr, b, padding=(k - 1) // 2 * dil, dilation=dil) + res.double() + acc.double()) / 3
+    u = native.conv1d_bf16w_pack_weight(w, dev)            # unrounded in: the pack rounds (RNE)
+    xd = x.to(dev)
+    got = native.conv1d_bf16w_forward(xd, u, b.to(dev), k, dil, 0.1, res=res.to(dev), acc=acc.to(dev), out_scale=1 / 3).cpu()
+    err = (got.double() - ref).abs().max().item()
+    assert err <= 6e-5, err
+    ref2 = conv1d_f64(x, wr, None, padding=(k - 1) // 2 * dil, dilation=dil)
+    plain = native.conv1d_bf16w_forward(xd, u, None, k, dil, 1.0).cpu()
+    assert (plain.double() - ref2).abs().max().item() <= 6e-5
+    wino = native.conv1d_winobf_forward(xd, native.conv1d_winobf_pack_weight(wr, dev), None, c, k, dil, 1.0).cpu()
+    rel = lambda t: ((t.double() - ref2).pow(2).mean().sqrt() / ref2.pow(2).mean().sqrt()).item()
+    r1, rw = rel(plain), rel(wino)
+    print(f"C {c} k {k} d {dil} L {length} B {batch}: relative RMS error vs float64 on the rounded taps: direct one-term {r1:.2e}, bf16x3 Winograd {rw:.2e}")
+    assert r1 <= 1.5 * rw + 1e-8
+    # res aliasing y (conv2 of the second and third dilation in the decoder's schedule), twice: bit-reproducible
+    y1 = res.to(dev).clone()
+    native.conv1d_bf16w_forward(xd, u, b.to(dev), k, dil, 0.1, res=y1, out=y1)
+    y2 = res.to(dev).clone()
+    native.conv1d_bf16w_forward(xd, u, b.to(dev), k, dil, 0.1, res=y2, out=y2)
+    assert torch.equal(y1, y2)
+    ref3 = conv1d_f64(F.leaky_relu(x.double(), 0.1), wr, b, padding=(k - 1) // 2 * dil, dilation=dil) + res.double()
+    assert (y1.cpu().double() - ref3).abs().max().item() <= 6e-5
+
+
+@pytest.mark.parametrize("c,form", [(32, "three"), (64, "three"), (128, "three"), (32, "one"), (64, "one"), (128, "one"), (128, "direct"), (256, "direct")])
 def test_resblock_pair_fresh_buffers_right_after_load(c, form):
     """ADVICE round 5 (resblock_bf.hip:290): K3f is the default path of the narrow stages and carries a race that was removed by
     reordering the stager prologue without being explained (profiles/r05_rbf_notes.txt item 5: wrong second tiles on the FIRST
-    launches into FRESH output buffers).  tools/stress_rbf.py reproduces that regime in a child process whose first GPU work it is:
+    launches into FRESH output buffers; K3d, convbf1.hip, shares the stager design and is held to the same test).  tools/stress_rbf.py
+    reproduces that regime in a child process whose first GPU work it is:
     every benchmarked (taps, dilation) of this channel count, 50 launches each into 50 never-written buffers (25 untouched, 25
     NaN-poisoned), all bit-equal to the first and the first equal to the fp32 direct-form pair."""
     import subprocess
@@ -792,7 +836,7 @@ def test_decoder_full_synth_golden(native, dev, ref_inputs):
     assert rms(out - g["o"]) <= 5e-5, rms(out - g["o"])
 
 
-@pytest.mark.parametrize("co", ["gemmbf", "winobf2", "winobf", "knn_screen", "attention_bf", "resblock_bf", "resblock_bf1", "linear_presplit", "posconv"])
+@pytest.mark.parametrize("co", ["gemmbf", "winobf2", "winobf", "knn_screen", "attention_bf", "resblock_bf", "resblock_bf1", "convbf1", "linear_presplit", "posconv"])
 @pytest.mark.parametrize("k,c", [(11, 128), (3, 64), (7, 32)])
 def test_fp32_winograd_next_to_the_bf16_gemm_is_bit_exact(native, dev, k, c, co):
     """Regression test of profiles/r03_mfma_cohabitation.txt / r04_mfma_cohabitation.txt: while one thread launches a kernel that
@@ -814,6 +858,10 @@ def test_fp32_winograd_next_to_the_bf16_gemm_is_bit_exact(native, dev, k, c, co)
         ub = native.conv1d_winobf_pack_weight(torch.randn(64, 64, 11, generator=g) * 0.03, dev)
         xb = torch.randn(1, 64, 200000, generator=g).to(dev)
         bb = torch.zeros(64, device=dev)
+    if co == "convbf1":      # K3d
+        ud = native.conv1d_bf16w_pack_weight(torch.randn(256, 256, 7, generator=g) * 0.03, dev)
+        xd1 = torch.randn(1, 256, 40000, generator=g).to(dev)
+        yd1 = torch.empty_like(xd1)
     if co == "posconv":      # K14
         pw = native.posconv_bf16x3_pack_weight(torch.randn(768, 48, 128, generator=g) * 0.02, 16, dev)
         pb = torch.zeros(768, device=dev)
@@ -853,6 +901,8 @@ def test_fp32_winograd_next_to_the_bf16_gemm_is_bit_exact(native, dev, k, c, co)
                     native.attention_qkv(qkv, 12, 0.125)
                 elif co == "winobf":
                     native.conv1d_winobf_forward(xb, ub, bb, 64, 11, 1, 0.1)
+                elif co == "convbf1":
+                    native.conv1d_bf16w_forward(xd1, ud, None, 7, 3, 0.1, out=yd1)
                 elif co == "posconv":
                     native.posconv_gelu_bf16x3(pxp, pw, pb, 16, 128, 64)
                 elif co in ("resblock_bf", "resblock_bf1"):

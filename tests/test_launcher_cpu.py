@@ -32,6 +32,10 @@ def test_bench_self_launches_n_ranks(world):
     assert line["index_broadcast"]["n_ranks"] == world
     assert line["total_samples"] == 3 * world * 1000                   # every rank converted its i mod N share
     assert abs(line["t_max"] - (1.0 + 0.001 * (world - 1))) < 1e-9     # MAX over ranks
+    # the fields that make a first real N-GPU run self-diagnosing: per-rank spread of the timed region, the broadcast's rate
+    spread = line["ms_per_step_ranks"]
+    assert len(spread["all"]) == world and spread["min"] <= spread["max"] and abs(spread["max"] - line["t_max"] / 3 * 1e3) < 0.01
+    assert line["index_broadcast"]["bytes"] == 256 * 768 * 4 and line["index_broadcast"]["gbps"] is not None
 
 
 def test_bench_refuses_more_gpus_than_visible():

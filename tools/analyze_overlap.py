@@ -6,7 +6,7 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 WHOLE = ("winobf2_conv_kernel", "winobf_conv_kernel", "resblock_bf_kernel", "linbf_kernel", "posconv_kernel", "attention_bf_kernel",
-         "knn_screen_kernel", "conv_mfma_kernel", "gemmbf_kernel", "wino_conv_kernel")
+         "knn_screen_kernel", "conv_mfma_kernel", "gemmbf_kernel", "wino_conv_kernel", "convbf1_kernel")
 # the timed region: from the first nsf_carry after warm-up (3 x 2 utterances) to the last conv_post of the first pass
 posts = [r for r in rows if "conv_post_kernel" in r["Kernel_Name"]]
 t_lo, t_hi = int(posts[6]["End_Timestamp"]), int(posts[6 + 10 - 1]["End_Timestamp"])

@@ -14,7 +14,7 @@ out = {}
 for name in f:
     if "resblock_bf_kernel" not in name: continue
     K, C = (int(v) for v in name.split("<")[1].split(">")[0].split(",")[:2])
-    L = 1535040 if C == 32 else 767520
+    L = {32: 1535040, 64: 767520, 128: 383760}[C]
     tensor = C * L * 4
     fr, wr = st.mean(f[name]), st.mean(w.get(name, [0.0]))
     print(f"{name:44s} launches {len(f[name]):3d}: FETCH_SIZE raw {fr/1e6:7.1f} MB (x2 for 16-byte reads: {2*fr/1e6:7.1f}), WRITE_SIZE {wr/1e6:7.1f} MB; "
