@@ -16,6 +16,7 @@ python3 $R/bench.py --config 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/benc
 python3 $R/bench.py --config 4 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_cfg4_again.json 2>/dev/null
 for c in 1 5; do python3 $R/bench.py --config $c --steps 20 --warmup 5 --cpu-seconds 3 > $O/bench_cfg$c.json 2> $O/bench_cfg$c.err; done
 python3 $R/bench.py --config 2 --steps 20 --warmup 5 --inflight 1 --no-cpu-baseline > $O/bench_cfg2_inflight1.json 2>/dev/null
+python3 $R/bench.py --config 2 --steps 21 --warmup 6 --inflight 3 --no-cpu-baseline --no-rooflines > $O/bench_cfg2_inflight3.json 2>/dev/null
 python3 $R/bench.py --config 2 --seconds 100 --steps 8 --warmup 2 --no-cpu-baseline --no-rooflines > $O/bench_cfg2_100s.json 2> $O/bench_cfg2_100s.err
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o b -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
 cp /tmp/pb/b_kernel_stats.csv $O/bench_kernel_stats.csv
@@ -29,6 +30,7 @@ rocprofv3 --kernel-trace --output-format csv -d /tmp/d1 -o t -- python3 $R/tools
 rocprofv3 --kernel-trace --output-format csv -d /tmp/d2 -o t -- python3 $R/tools/profile_decoder.py RefineGAN >/dev/null 2>&1; python3 $R/tools/summarize_trace.py /tmp/d2/t_kernel_trace.csv > $O/decoder_kernels_refinegan.txt
 rocprofv3 --kernel-trace --output-format csv -d /tmp/d3 -o t -- python3 $R/tools/profile_decoder.py "MRF HiFi-GAN" bf16 >/dev/null 2>&1; python3 $R/tools/summarize_trace.py /tmp/d3/t_kernel_trace.csv > $O/decoder_kernels_mrf_bf16.txt
 BENCH_ONE=1 python3 $R/tools/bench_resblock_bf.py 2>&1 | grep -v amdgpu.ids > $O/rbf1_shapes.txt
+python3 $R/tools/bench_convbf1.py 2>&1 | grep -v amdgpu.ids > $O/convbf1_shapes.txt
 # HBM traffic of the roofline kernel: FETCH_SIZE and WRITE_SIZE in separate passes (they do not fit one)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -o f -- python3 $R/tools/pmc_conv.py > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -o w -- python3 $R/tools/pmc_conv.py > /dev/null 2>&1
@@ -40,6 +42,25 @@ python3 $R/tools/summarize_pmc_rbf.py /tmp/rf/f_counter_collection.csv /tmp/rw/w
 # SQ counters: the roofline kernel, then the one-term pairs (derived pipe-busy figure next to the raw ones)
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pc -o c -- python3 $R/tools/pmc_conv.py > /dev/null 2>&1
 ONE=1 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pc1 -o c -- python3 $R/tools/pmc_rbf.py > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pc2 -o c -- python3 $R/tools/pmc_convbf1.py > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/cf -o f -- python3 $R/tools/pmc_convbf1.py > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/cw -o w -- python3 $R/tools/pmc_convbf1.py > /dev/null 2>&1
+python3 - > $O/pmc_convbf1.txt <<'PY'
+import csv, collections, statistics as st
+def load(path):
+    d = collections.OrderedDict()
+    for r in csv.DictReader(open(path)):
+        d.setdefault((r["Kernel_Name"].split("(")[0].replace("void ", ""), r["Grid_Size"]), []).append(float(r["Counter_Value"]) * 1024.0)
+    return d
+f, w = load("/tmp/cf/f_counter_collection.csv"), load("/tmp/cw/w_counter_collection.csv")
+for (name, grid), v in f.items():
+    if "convbf1_kernel" in name or "copyBuffer" in name:
+        C = 256 if "256>" in name else 128
+        L = 38376 if C == 256 else 383760
+        t = C * L * 4 / 1e6
+        print(f"{name:40s} launches {len(v):3d}: FETCH_SIZE raw {st.mean(v)/1e6:7.1f} MB (x2 for 16-byte / x1.77 for 4-byte reads), WRITE_SIZE {st.mean(w.get((name, grid), [0]))/1e6:7.1f} MB"
+              + (f"; algorithmic: x {t:.1f} + res {t:.1f} read, y {t:.1f} written" if "convbf1" in name else "  (calibration: a tensor copy)"))
+PY
 # the L2 -> CU request path and the LDS of the roofline kernel (verdict item 3: "write the bound down with counters")
 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum --kernel-trace --output-format csv -d /tmp/pt -o c -- python3 $R/tools/pmc_conv.py > $O/pmc_tcp.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pl -o c -- python3 $R/tools/pmc_conv.py > $O/pmc_lds.log 2>&1
@@ -73,6 +94,7 @@ print("==== winobf2_conv_kernel (K3y): SQ pass"); table("/tmp/pc/c_counter_colle
 print("==== winobf2_conv_kernel (K3y): L1 -> L2 requests"); table("/tmp/pt/c_counter_collection.csv", "winobf2_conv_kernel")
 print("==== winobf2_conv_kernel (K3y): LDS / instruction mix"); table("/tmp/pl/c_counter_collection.csv", "winobf2_conv_kernel")
 print("==== resblock_bf_kernel with one-term taps (K3f, cfg 4): SQ pass"); table("/tmp/pc1/c_counter_collection.csv", "resblock_bf_kernel")
+print("==== convbf1_kernel (K3d, cfg 4): SQ pass"); table("/tmp/pc2/c_counter_collection.csv", "convbf1_kernel")
 PY
 # kNN: kernel stats + HBM traffic of one search at 100 k and 2 M rows: the screened regime, then the streaming regime
 (cd $R && bash tools/profile_knn.sh) > $O/knn_profile.log 2>&1
@@ -96,6 +118,6 @@ PY
 done
 python3 -c "
 import json
-for f in ('bench_cfg2_again', 'bench_cfg4_again', 'bench_cfg2_inflight1', 'bench_cfg2_100s'):
+for f in ('bench_cfg2_again', 'bench_cfg4_again', 'bench_cfg2_inflight1', 'bench_cfg2_inflight3', 'bench_cfg2_100s'):
     d=json.loads([l for l in open('$O/'+f+'.json') if l.startswith('{')][-1]); print(f, d['ms_per_step'], 'ms/step; host_io', d['host_io']['ms_per_step'])"
 tail -3 $O/pipeline_kernels.txt
