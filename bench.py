@@ -20,7 +20,7 @@ rvc/train/extract/extract.py:141-152, starts its per-device workers the same way
 that differs from --gpus, or fewer visible GPUs than --gpus, is an error, never a silent 1-GPU run.  Every rank converts
 its own utterances (utterance i -> rank i mod N); the index is built on rank 0 and replicated with ONE RCCL broadcast
 through the C ABI (rvc_index_broadcast) and verified by a device-side checksum; the steady state has no collective
-("scaling": "weak").  On each GPU `--inflight` utterances (default 2) are in flight at a time, each on its own HIP stream.
+("scaling": "weak").  On each GPU `--inflight` utterances (default 3) are in flight at a time, each on its own HIP stream.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      the dominant kernel symbol (the 11-tap ResBlock convs of vocoder stages 0-2: Winograd F(4,4) on the bf16 matrix
@@ -90,7 +90,8 @@ def parse_args(argv=None):
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--seconds", type=float, default=None, help="override the clip length of the config")
     ap.add_argument("--index-rows", type=int, default=None, help="override the index size of the config")
-    ap.add_argument("--inflight", type=int, default=2, help="utterances in flight per GPU, each on its own HIP stream")
+    ap.add_argument("--inflight", type=int, default=3, help="utterances in flight per GPU, each on its own HIP stream (round 6: 3 -- "
+                    "25.1-25.7 ms per cfg-2 utterance against 26.0-26.2 with 2 on the same box, profiles/r06_inflight_sweep.txt; rounds 2-5: 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--vocoder-side-streams", type=int, default=None,
                     help="A/B: side streams the vocoder spreads a short stage's ResBlock branches over (default 0 = every launch on the utterance's stream; -1 = one per branch)")
@@ -126,8 +127,9 @@ def roofline_mix(torch, native, dev, T, rates, weights, k=11):
     wave), i.e. the 11-tap ResBlock convs of vocoder stages 0 and 1 (C = 256, 128; the C = 64 stage runs winobf.hip's 64 x 128
     blocks, the C = 32 stage the fp32 kernels), per stage and for each dilation d: conv1 (dilation d) then conv2 (dilation 1,
     + residual; the last one also + running sum, x 1/3) -- 12 launches, the population rocprofv3 --stats averages over for that
-    symbol.  `weights` = "bf16" (BASELINE cfg 4) rounds the taps to bf16 first, as the decoder handle with bf16 weight storage
-    does: the transformed taps are then fragments of bf16-VALUED taps, the kernel and its arithmetic are the same.
+    symbol.  `weights` = "bf16" (BASELINE cfg 4): the decoder handle with bf16 weight storage runs THESE layers on K3d
+    (rvc::convbf1_kernel<11, C>, convbf1.hip: direct form, one-term taps, three bf16 products per multiply-add) -- the same 12
+    launches are timed on that kernel and `executed` counts its products.
     Returns (callable, algorithmic flops per call, launches per call, algorithmic HBM bytes per call, executed flops)."""
     gen = torch.Generator().manual_seed(1)
     stages, flops, executed, alg_bytes = [], 0.0, 0.0, 0.0
@@ -140,14 +142,20 @@ def roofline_mix(torch, native, dev, T, rates, weights, k=11):
         w1, w2 = torch.randn(C, C, k, generator=gen) * 0.02, torch.randn(C, C, k, generator=gen) * 0.02
         if weights == "bf16":
             w1, w2 = w1.bfloat16().float(), w2.bfloat16().float()
+        pack = native.conv1d_bf16w_pack_weight if weights == "bf16" else native.conv1d_winobf_pack_weight
         st = dict(C=C, x=x, t1=torch.empty_like(x), y=torch.randn(1, C, L, device=dev), acc=torch.randn(1, C, L, device=dev),
-                  w1=native.conv1d_winobf_pack_weight(w1, dev), w2=native.conv1d_winobf_pack_weight(w2, dev), bias=torch.zeros(C, device=dev))
+                  w1=pack(w1, dev), w2=pack(w2, dev), bias=torch.zeros(C, device=dev))
         stages.append(st)
         flops += 6 * 2.0 * C * C * k * L                          # 2 x MACs of the conv as the reference computes it
-        executed += 6 * 2.0 * C * C * points * (L / 4.0) * per_mac
+        # bf16 storage: the same layers run K3d (convbf1.hip) -- direct form, every multiply-add, THREE bf16 products each
+        executed += 6 * 2.0 * C * C * k * L * 3 if weights == "bf16" else 6 * 2.0 * C * C * points * (L / 4.0) * per_mac
         tensor = C * L * 4.0
         alg_bytes += 3 * (2 * tensor) + 2 * (3 * tensor) + 1 * (4 * tensor)   # conv1: r+w; conv2: r+res+w (+acc)
-    fwd = native.conv1d_winobf_forward
+    if weights == "bf16":
+        def fwd(x, u, bias, C, k_, d, slope, **kw):
+            return native.conv1d_bf16w_forward(x, u, bias, k_, d, slope, **kw)
+    else:
+        fwd = native.conv1d_winobf_forward
 
     def run():
         for st in stages:
@@ -278,13 +286,29 @@ def main():
         return vc.convert_batch([pool[(first + j) % len(pool)] for j in range(count)], inflight=inflight, **kw)
 
     run_steps(audios, 0, args.warmup * inflight)   # every stream warms up its own workspaces / side stream
+    # Two one-off stalls that a short timed region must not contain by accident (seen as 10-50 ms in about one fresh process of three:
+    # 28.5 against 26.0 ms per step for the same tree on one box, profiles/r06_bench_cfg2.json vs _again): a device allocation in the
+    # middle of the run -- the host threads of the utterances in flight interleave differently every time, and an interleaving that
+    # needs one more cached block than warm-up left behind sends torch's allocator to hipMalloc -- and a full Python garbage collection.
+    # Warm-up therefore ends with one batch at `inflight + 1` (peak demand above the steady state's: the pool keeps the slack), and the
+    # interpreter's long-lived objects are frozen out of the collector's generations.  Both are reported in the line (`timed_region`).
+    vc.convert_batch([audios[j % len(audios)] for j in range(inflight + 1)], inflight=inflight + 1, **kw)
+    import gc
+    gc.collect()
+    gc.freeze()
     barrier()
     torch.cuda.synchronize()
+    mem0, gc0 = torch.cuda.memory_stats(dev), [g["collections"] for g in gc.get_stats()]
     t0 = time.perf_counter()
     outs = run_steps(audios, args.warmup, args.steps)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    mem1, gc1 = torch.cuda.memory_stats(dev), [g["collections"] for g in gc.get_stats()]
+    timed_region = {"device_allocations": int(mem1.get("num_device_alloc", 0) - mem0.get("num_device_alloc", 0)),
+                    "allocator_retries": int(mem1.get("num_alloc_retries", 0) - mem0.get("num_alloc_retries", 0)),
+                    "reserved_bytes": int(mem1.get("reserved_bytes.all.current", 0)),
+                    "gc_collections": [b - a for a, b in zip(gc0, gc1)]}
     samples = sum(int(o.shape[0]) for o in outs)
     total_samples, t_max = D.reduce_report(samples, elapsed, dev)
     rank_seconds = D.gather_seconds(elapsed, dev)
@@ -333,9 +357,9 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": ("f32 activations x bf16-stored vocoder taps (C <= 64, and C = 128 at 3 / 7 taps: direct-form fused pairs with ONE-TERM taps -- a bf16-valued tap is "
-                  "its own first split, three bf16 products per multiply-add against exact bf16x3 activations; C = 256 and C = 128 at 11 taps: bf16x3 Winograd "
-                  "fragments of the bf16-valued taps; fp32 accumulate everywhere)")
+        "dtype": ("f32 activations x bf16-stored vocoder taps (every ResBlock conv in direct form with ONE-TERM taps -- a bf16-valued tap is its own first split, "
+                  "three bf16 products per multiply-add against exact bf16x3 activations: fused pairs up to 128 channels x 7 taps, single convs at 256 channels "
+                  "and at 128 x 11 taps; fp32 accumulate everywhere)")
                  if cfg["weights"] == "bf16" else
                  "f32 (vocoder 7/11-tap convs and 3-tap ones at >= 128 channels: fp32 operands as exact bf16x3 splits on the bf16 matrix cores, fp32 accumulate)",
         "data": "synthetic (seeded random-init weights, FM-tone utterances, clustered index)",
@@ -357,6 +381,7 @@ def main():
             "rccl_version": bcast.get("rccl_version"), "library": bcast.get("library"),
             "verified": "device checksum (rvc_checksum64) equal on every rank"},
         "host_io": host_io,
+        "timed_region": timed_region,   # hipMalloc calls / Python collections INSIDE the timed region (both should be zero / young generations only)
         # what the host side of each rank looks like: convert_batch drives `inflight` Python threads per rank; at N = 8 the
         # driver's scaling curve can be read against this (host-bound ranks show as equal GPU idle on every rank)
         "host": {"cpus": os.cpu_count(), "affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
@@ -464,17 +489,23 @@ def rooflines(torch, _native, vc, cpt, cfg, dev, n_in, index_dev, utterance):
     cfg2 = T == 3198 and list(rates[:2]) == [12, 10]
     exe_launch = mix_executed / mix_launches
     traffic, traffic_src = pmc_traffic("winobf2_k11") if cfg2 else (None, None)
+    bf16w = cfg["weights"] == "bf16"
+    if bf16w:
+        traffic, traffic_src = None, None      # (the PMC file is K3y's)
     res["roofline"] = {
-        "kernel": "rvc::winobf2_conv_kernel<11,128,0>: ALL 12 launches per utterance of this symbol -- the 11-tap ResBlock convs of vocoder "
+        "kernel": ("rvc::convbf1_kernel<11,256> + <11,128> (K3d: direct form, one-term bf16 taps x exact bf16x3 activations): ALL 12 launches per utterance"
+                   if bf16w else "rvc::winobf2_conv_kernel<11,128,0>: ALL 12 launches per utterance of this symbol")
+                  + " -- the 11-tap ResBlock convs of vocoder "
                   f"stages 0-1 (C=256/128 at {T * rates[0]}/{T * rates[0] * rates[1]} columns) in the decoder's own mix (dilations 1/3/5, "
-                  "residual on every second one); per-launch figures are averages over the 12"
-                  + ("; taps rounded to bf16 first, as the bf16-storage decoder handle holds them" if cfg["weights"] == "bf16" else ""),
+                  "residual on every second one); per-launch figures are averages over the 12",
         "bound": "mfma", "achieved": round(exe_launch / t_launch / 1e12, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": round(exe_launch / t_launch / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
-        "achieved_is": "bf16 matrix flops the kernel EXECUTES / launch time, against the dense bf16 MFMA peak: the pipe's own "
-                       "occupancy.  One fp32 multiply-add of the Winograd F(4,4) form (7 * 3 / (4 * 11) = 0.477 of the conv's "
-                       "multiply-adds) costs six bf16 products (fp32 operands split exactly into three bf16, fp32 accumulate); "
-                       "the SURVEY 8d ALGORITHMIC rate (2 x MACs of the 11-tap conv / time) is algorithmic_tflops, "
+        "achieved_is": "bf16 matrix flops the kernel EXECUTES / launch time, against the dense bf16 MFMA peak: the pipe's own occupancy.  "
+                       + ("Direct form: every multiply-add of the conv, three bf16 products each (a bf16-valued tap is one term; the activations "
+                          "keep their exact three-way split), fp32 accumulate; " if bf16w else
+                          "One fp32 multiply-add of the Winograd F(4,4) form (7 * 3 / (4 * 11) = 0.477 of the conv's "
+                          "multiply-adds) costs six bf16 products (fp32 operands split exactly into three bf16, fp32 accumulate); ")
+                       + "the SURVEY 8d ALGORITHMIC rate (2 x MACs of the 11-tap conv / time) is algorithmic_tflops, "
                        "i.e. algorithmic_vs_fp32_mfma_peak x the 157.3 TF an fp32-matrix-instruction kernel could reach",
         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(mix_alg_bytes / mix_launches),
         "algorithmic_flops_per_launch": flops_launch, "executed_flops_per_launch": exe_launch,

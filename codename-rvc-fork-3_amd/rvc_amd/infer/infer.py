@@ -141,11 +141,12 @@ class VoiceConverter:
         merged = merge_audio(chunks, converted, intervals, 16000, self.tgt_sr)
         return torch.from_numpy(merged).to(audio.device) if torch.is_tensor(audio) else merged
 
-    def convert_batch(self, audios, *, inflight: int = 2, **kwargs):
+    def convert_batch(self, audios, *, inflight: int = 3, **kwargs):
         """Convert a list of 16 kHz utterances with ``inflight`` of them on the GPU at a time, each on its own HIP stream
         (one host thread per stream; the HIP / PyTorch calls release the GIL).  Utterances share no state,
-        and one utterance alone leaves the chip partly idle -- the 8-CU BiGRU, the 600-tile first vocoder stage, ~1500
-        small launches -- so two interleaved utterances finish ~7 % sooner than two in sequence.  Results keep the input
+        and one utterance alone leaves the chip partly idle -- the 8-CU BiGRU, the 1.17-round first vocoder stage, ~1500
+        small launches -- so interleaved utterances finish sooner than in sequence: 30.4 / 26.0 / 25.1-25.7 ms per 30 s
+        utterance at 1 / 2 / 3 in flight (round 6, profiles/r06_inflight_sweep.txt; each one in flight keeps ~2.5 GB of workspaces).  Results keep the input
         order; device tensors in give device tensors out (valid once this returns)."""
         import threading
         audios = list(audios)
@@ -279,10 +280,10 @@ class VoiceConverter:
 
     def convert_audio_batch(self, audio_input_paths: str, audio_output_path: str, **kwargs):
         """infer.py:350-414: every WAV of a folder, skipping existing outputs.  The reference loops sequentially; here the
-        first file loads the models, the rest are converted ``inflight`` (default 2) at a time, each on its own HIP
+        first file loads the models, the rest are converted ``inflight`` (default 3) at a time, each on its own HIP
         stream (see convert_batch)."""
         import threading
-        inflight = max(1, int(kwargs.pop("inflight", 2)))
+        inflight = max(1, int(kwargs.pop("inflight", 3)))
         try:
             start_time = time.time()
             print(f"Converting audio batch '{audio_input_paths}'...")

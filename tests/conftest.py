@@ -54,6 +54,59 @@ def f0_tie_report(f0_p, sal_p, f0_o, sal_o):
 
 
 
+def vs_oracle(vc, hubert, S, cpt, audio, *, seed, sid=0, pitch=0, big=None, index_rate=0.0, protect=0.5, gate=1e-3,
+              volume_envelope=1, f0_autotune=False, f0_autotune_strength=1, oracle_kw=None, label="", version="v2", reference=None):
+    """Product vs oracle (flat-salience synthetic RMVPE) under one seed, TIE-AWARE in f0 like test_fullsize_gpu.py: two correct
+    fp32 evaluations of the random-weight RMVPE can pick different salience bins on a frame now and then (the GPU contour itself
+    moves by ~1e-7 from run to run: DESIGN.md section 2), and one such frame moves the NSF source's phase for the rest of the clip
+    (seen once as 1.1e-2 on the 2 s 40 k sweep case that otherwise agrees to 2.5e-6).  When the plain comparison misses the gate,
+    every frame on which the two raw contours differ must be a CERTIFIED near-tie (f0_tie_report: salience arg-max, or the 0.03
+    voicing threshold; coarse-pitch flips: a .5 rounding boundary) -- and there must be one, or the miss is a real error -- and the
+    oracle is re-run on the product's contour, so that everything downstream is still compared at the gate.
+    `reference`: the REFERENCE's own output for this input (a tests/golden fixture).  The product is then compared with it directly;
+    only on a miss is the oracle evaluated -- it must reproduce the reference's output (2e-5: the pin) -- and the treatment above
+    applied.  Returns (product output, what it was finally compared with, rms error)."""
+    import torch
+    from oracle import rvc_oracle as O
+    okw = dict(sid=sid, pitch=pitch, big_npy=big, index_rate=index_rate, protect=protect, volume_envelope=volume_envelope,
+               f0_autotune=f0_autotune, f0_autotune_strength=f0_autotune_strength, **(oracle_kw or {}))
+    hub_sd, rm_sd = S.make_hubert_state_dict(1), S.make_rmvpe_state_dict(0)
+    taps_o = {}
+
+    def oracle(**extra):
+        torch.manual_seed(seed)
+        return O.pipeline(hub_sd, rm_sd, cpt, np.array(audio, copy=True), **okw, **extra)
+
+    want = oracle(taps=taps_o) if reference is None else np.asarray(reference)
+    vc.vc.debug_taps = {}
+    try:
+        got = vc.vc.pipeline(hubert, vc.net_g, sid, np.array(audio, copy=True), pitch, "rmvpe", "", index_rate, True, 3, volume_envelope, version,
+                             protect, 128, f0_autotune, f0_autotune_strength, None, noise_seed=seed)
+        f0_p = vc.vc.debug_taps["f0_raw"].cpu().numpy()
+        sal_p = vc.vc.debug_taps["salience"].cpu().numpy()
+    finally:
+        vc.vc.debug_taps = None
+    assert got.shape == want.shape and got.dtype == np.float32
+    err = rms(got - want)
+    if err > gate:
+        if reference is not None:
+            pinned = oracle(taps=taps_o)
+            assert rms(pinned - want) <= 2e-5, f"{label}: the oracle does not reproduce the reference's output ({rms(pinned - want):.2e})"
+        f0_o, sal_o = taps_o["f0_raw"], taps_o["salience"]
+        differ = f0_tie_report(f0_p, sal_p, f0_o, sal_o)            # asserts that every differing frame is a certified near-tie
+        n_f = min(len(f0_p), len(f0_o))
+        c_p = O.f0_to_coarse(f0_p[:n_f].astype(np.float64), pitch, f0_autotune, f0_autotune_strength)[0]
+        c_o = O.f0_to_coarse(f0_o[:n_f].astype(np.float64), pitch, f0_autotune, f0_autotune_strength)[0]
+        flips = np.nonzero(c_p != c_o)[0]
+        assert len(differ) + len(flips) > 0, f"{label}: rms err {err:.3e} with identical f0 contours"
+        assert len(differ) + len(flips) <= max(2, n_f // 100), (len(differ), len(flips), n_f)
+        want = oracle(f0_override=f0_p)
+        print(f"{label}: plain rms err {err:.3e} explained by {len(differ)} certified salience near-tie frame(s) / {len(flips)} coarse-pitch "
+              f"flip(s) of {n_f}; the oracle follows the product's contour")
+        err = rms(got - want)
+    return got, want, err
+
+
 @pytest.fixture(scope="session")
 def golden():
     return load_golden

@@ -208,12 +208,16 @@ def test_multi_segment_matches_reference_golden(S, hubert):
     class Tier:
         x_pad, x_query, x_center, x_max, device = 1, int(g["x_query"]), int(g["x_center"]), int(g["x_max"]), DEV
 
+    from conftest import vs_oracle
     vc = _converter(S, 48000, "HiFi-GAN", hubert, config=Tier())
-    vc.vc.set_index(S.synth_index(4096, seed=0))
-    out = vc.vc.pipeline(hubert, vc.net_g, int(g["sid"]), g["audio"].copy(), 0, "rmvpe", "", float(g["index_rate"]), True, 3, 1,
-                         "v2", float(g["protect"]), 128, False, 1, None, noise_seed=int(g["seed"]))
+    big = S.synth_index(4096, seed=0)
+    vc.vc.set_index(big)
+    # (reference mode of the tie-aware comparison: the product against the reference's output; only on a miss the oracle -- which must
+    # then reproduce that output -- and the certified-near-tie treatment)
+    out, _, err = vs_oracle(vc, hubert, S, S.make_synth_checkpoint(48000, "HiFi-GAN", seed=0), g["audio"], seed=int(g["seed"]), sid=int(g["sid"]),
+                            big=big, index_rate=float(g["index_rate"]), protect=float(g["protect"]), reference=g["out"], label="multi-segment",
+                            oracle_kw=dict(x_query=int(g["x_query"]), x_center=int(g["x_center"]), x_max=int(g["x_max"])))
     assert out.dtype == np.float32 and out.shape == g["out"].shape
-    err = rms(out - g["out"])
     print(f"multi-segment (3 segments) vs reference: rms err {err:.3e} (ref rms {rms(g['out']):.3f})")
     assert err <= 1e-3, err
 
@@ -309,7 +313,7 @@ def test_decoder_T3198_stage_by_stage_vs_oracle(S, oracle_farm, case):
 @pytest.mark.parametrize("cfg", [2, 4, 5])
 def test_convert_batch_full_length_inflight2_equals_sequential(S, hubert, monkeypatch, cfg):
     """The benchmarked MODE at the benchmarked LENGTH, for every vocoder bench.py runs that way: four 30 s utterances through
-    convert_batch with two in flight against the same four converted one at a time -- cfg 2 (48 k NSF vocoder), cfg 4 (MRF vocoder,
+    convert_batch with THREE in flight (bench.py's default since round 6; rounds 2-5: two) against the same four converted one at a time -- cfg 2 (48 k NSF vocoder), cfg 4 (MRF vocoder,
     bf16 weight storage: K3f with one-term taps next to K3y) and cfg 5 (RefineGAN, whose narrow layers still run wino_conv_kernel,
     the kernel that profiles/r05_mfma_cohabitation.txt shows returning wrong words next to a co-resident bf16-matrix workgroup: here
     it runs for 30 s beside the OTHER utterance's bf16 kernels, kept apart only by their whole-CU LDS request), 100 k index,
@@ -338,13 +342,13 @@ def test_convert_batch_full_length_inflight2_equals_sequential(S, hubert, monkey
     torch.cuda.synchronize()
     worst = 0.0
     for rep in range(2):
-        par = vc.convert_batch(audios, inflight=2, index_rate=0.75)
+        par = vc.convert_batch(audios, inflight=3, index_rate=0.75)
         torch.cuda.synchronize()
         for a, b_ in zip(seq, par):
             assert a.shape == b_.shape == (1_439_040,)
             assert bool(torch.isfinite(b_).all())
             worst = max(worst, rms((a - b_).cpu().numpy()))
-    print(f"cfg {cfg} ({voc}): 4 x 30 s, two in flight vs one at a time (zero noise): worst waveform rms difference {worst:.3e} (signal rms {rms(seq[0].cpu().numpy()):.3f})")
+    print(f"cfg {cfg} ({voc}): 4 x 30 s, three in flight vs one at a time (zero noise): worst waveform rms difference {worst:.3e} (signal rms {rms(seq[0].cpu().numpy()):.3f})")
     assert rms(seq[0].cpu().numpy()) > 0.02
     assert worst <= 1e-5, worst
 
@@ -353,8 +357,12 @@ def test_convert_array_caller_vs_oracle(S, hubert, sds, tmp_path):
     """a18 (infer.py:262-311): the peak limit to 0.95 and the index-path normalisation ("trained" -> "added", quotes and
     blanks stripped) as VoiceConverter.convert_array applies them, against the oracle fed with the same front end."""
     from oracle import rvc_oracle as O
-    cpt = S.make_synth_checkpoint(48000, "HiFi-GAN", seed=0)
+    # trained-like RMVPE + pitch embedding on both sides (the oracle is evaluated here, no fixture is involved): nothing tie-aware needed
+    cpt = S.make_synth_checkpoint(48000, "HiFi-GAN", seed=0, smooth_pitch=True)
+    rm_peaked = S.make_rmvpe_state_dict(0, peaked=True)
     vc = _converter(S, 48000, "HiFi-GAN", hubert)
+    vc.load_checkpoint_dict(cpt)
+    vc.vc.load_rmvpe_state_dict(rm_peaked)
     big = S.synth_index(3000, seed=4)
     np.save(os.path.join(tmp_path, "added_IVF42_Flat.npy"), big)
     asked = '  "' + os.path.join(tmp_path, "trained_IVF42_Flat.npy") + '" \n'     # what a UI text box hands over
@@ -362,7 +370,7 @@ def test_convert_array_caller_vs_oracle(S, hubert, sds, tmp_path):
     assert np.abs(audio).max() > 1.0
     limited = audio / (np.abs(audio).max() / 0.95)                                # infer.py:262-265
     torch.manual_seed(606)
-    want = O.pipeline(sds[0], sds[1], cpt, limited.copy(), sid=0, pitch=0, big_npy=big, index_rate=0.6, protect=0.5)
+    want = O.pipeline(sds[0], rm_peaked, cpt, limited.copy(), sid=0, pitch=0, big_npy=big, index_rate=0.6, protect=0.5)
     got = vc.convert_array(audio, index_path=asked, index_rate=0.6, protect=0.5, sid=0, noise_seed=606)
     assert got.shape == want.shape
     err = rms(got - want)

@@ -16,7 +16,7 @@ python3 $R/bench.py --config 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/benc
 python3 $R/bench.py --config 4 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_cfg4_again.json 2>/dev/null
 for c in 1 5; do python3 $R/bench.py --config $c --steps 20 --warmup 5 --cpu-seconds 3 > $O/bench_cfg$c.json 2> $O/bench_cfg$c.err; done
 python3 $R/bench.py --config 2 --steps 20 --warmup 5 --inflight 1 --no-cpu-baseline > $O/bench_cfg2_inflight1.json 2>/dev/null
-python3 $R/bench.py --config 2 --steps 21 --warmup 6 --inflight 3 --no-cpu-baseline --no-rooflines > $O/bench_cfg2_inflight3.json 2>/dev/null
+python3 $R/bench.py --config 2 --steps 20 --warmup 5 --inflight 2 --no-cpu-baseline --no-rooflines > $O/bench_cfg2_inflight2.json 2>/dev/null
 python3 $R/bench.py --config 2 --seconds 100 --steps 8 --warmup 2 --no-cpu-baseline --no-rooflines > $O/bench_cfg2_100s.json 2> $O/bench_cfg2_100s.err
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o b -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
 cp /tmp/pb/b_kernel_stats.csv $O/bench_kernel_stats.csv
@@ -118,6 +118,6 @@ PY
 done
 python3 -c "
 import json
-for f in ('bench_cfg2_again', 'bench_cfg4_again', 'bench_cfg2_inflight1', 'bench_cfg2_inflight3', 'bench_cfg2_100s'):
+for f in ('bench_cfg2_again', 'bench_cfg4_again', 'bench_cfg2_inflight1', 'bench_cfg2_inflight2', 'bench_cfg2_100s'):
     d=json.loads([l for l in open('$O/'+f+'.json') if l.startswith('{')][-1]); print(f, d['ms_per_step'], 'ms/step; host_io', d['host_io']['ms_per_step'])"
 tail -3 $O/pipeline_kernels.txt
