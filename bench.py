@@ -292,7 +292,19 @@ def main():
     # needs one more cached block than warm-up left behind sends torch's allocator to hipMalloc -- and a full Python garbage collection.
     # Warm-up therefore ends with one batch at `inflight + 1` (peak demand above the steady state's: the pool keeps the slack), and the
     # interpreter's long-lived objects are frozen out of the collector's generations.  Both are reported in the line (`timed_region`).
+    # (A pool reserved up front -- one big cached segment -- changes nothing: tools/bench_pool_ab.sh, 27-33 allocations either way.)
     vc.convert_batch([audios[j % len(audios)] for j in range(inflight + 1)], inflight=inflight + 1, **kw)
+    # ... and the allocator is given time to SETTLE: torch's caching allocator keeps growing its per-stream pools through the first ~50
+    # utterances of a process (tools/diag_alloc.py: 238 hipMalloc calls in the first 20 utterances, then 5, 1, 0, 0, 1, 2, 0 ... per 20),
+    # i.e. well into a 20-step region that starts after 5 warm-up steps.  Untimed batches of `inflight` utterances run until one of them
+    # needs no device allocation (at most 16 batches, ~25 ms per utterance); `timed_region.settle_utterances` says how many it took.
+    settle = 0
+    for _ in range(16):
+        n0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
+        run_steps(audios, settle, inflight)
+        settle += inflight
+        if torch.cuda.memory_stats(dev).get("num_device_alloc", 0) == n0:
+            break
     import gc
     gc.collect()
     gc.freeze()
@@ -308,7 +320,7 @@ def main():
     timed_region = {"device_allocations": int(mem1.get("num_device_alloc", 0) - mem0.get("num_device_alloc", 0)),
                     "allocator_retries": int(mem1.get("num_alloc_retries", 0) - mem0.get("num_alloc_retries", 0)),
                     "reserved_bytes": int(mem1.get("reserved_bytes.all.current", 0)),
-                    "gc_collections": [b - a for a, b in zip(gc0, gc1)]}
+                    "gc_collections": [b - a for a, b in zip(gc0, gc1)], "settle_utterances": settle}
     samples = sum(int(o.shape[0]) for o in outs)
     total_samples, t_max = D.reduce_report(samples, elapsed, dev)
     rank_seconds = D.gather_seconds(elapsed, dev)
