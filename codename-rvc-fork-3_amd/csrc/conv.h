@@ -84,6 +84,16 @@ void convbf1_pack_host(const float *w, int c, int k, std::vector<uint16_t> *out)
 int launch_convbf1(const float *x, const void *u, const float *bias, const float *res, const float *accin, float *y, int batch, int c,
                    int64_t L, int k, int dil, float slope, float out_scale, hipStream_t stream);
 
+// the upsampling step (ConvTranspose1d in polyphase form + the folded noise conv) on the bf16 matrix cores, exact bf16x3 operands
+// (upsbf.hip, K3u); even rates 2 / 8 / 10 / 12, c_in % 64 == 0, at most 64 folded noise rows
+bool upsbf_supported(int c_in, int c_out, int rate, int ksize, int vk);
+bool upsbf_fold_noise(int nc_k);       // the noise conv rides the GEMM as extra rows (vk = (rate - 1) stride + nc_k, + a ones row for the bias) whenever there is one
+size_t upsbf_weight_bytes(int c_in, int c_out, int rate, int vk);
+void upsbf_pack_host(const float *uw, const float *nw, const float *bias, int c_in, int c_out, int rate, int ksize, int vk, int nc_k,
+                     int nc_stride, std::vector<uint16_t> *out);   // uw [c_in][c_out][ksize], nw [c_out][nc_k] or null
+int launch_upsbf(const float *x, const float *har, int64_t Lh, const void *u, const float *bias, float *y, int batch, int c_in, int c_out,
+                 int64_t L_in, int64_t L_out, int rate, int ksize, int pad, int vk, int64_t S, int64_t P, float slope, hipStream_t stream);
+
 // fp32 -> bf16, round to nearest even (what torch's .bfloat16() does); NaN stays NaN
 static inline uint16_t bf16_rne(float f) {
     uint32_t u;

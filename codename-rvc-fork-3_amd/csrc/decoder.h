@@ -62,6 +62,8 @@ struct Stage {
     // launch, y += W_nc V2 with V2[k][t] = har[t * nc_stride + k - nc_pad].  Folding it costs (rate - 1) * nc_stride + nc_k
     // GEMM rows per tap for nc_k useful ones: 520 against 512 real input channels in the first stage of the 48 k vocoder
     // (half of that launch's matrix instructions multiplied zeros), 8-48 rows in the later stages.
+    DevBuf16 wub;                 // the upsampler GEMM (+ the folded noise rows) as bf16x3 fragments (upsbf.hip, K3u); taken instead of w when set
+    int ub_vk = 0;                // noise rows folded into K3u's GEMM (0: the stage's noise conv is a separate launch)
     int nc_rows = 0;              // nc_k padded to a multiple of 8
     DevBuf nc_w;                  // [1][nc_rows][c_out]
     std::vector<ConvW> c1, c2;    // [n_res_kernels * n_res_dilations]

@@ -624,14 +624,27 @@ extern "C" int rvc_decoder_finalize(rvc_decoder *d) {
                     packed[((size_t)tp0 * ctot + s.c_in + kq) * m_total + mrow(ph, co)] = nw->data[(size_t)co * s.nc_k + k];
             }
         if (s.w.upload(packed)) return 1;
+        std::vector<float> bias(s.c_out);
+        for (int co = 0; co < s.c_out; ++co) bias[co] = ub->data[co] + nb->data[co];
+        {   // K3u: the same GEMM on the bf16 matrix cores (exact bf16x3 operands).  The stage's noise conv is folded into the GEMM straight
+            // from har_source, with the bias as a row of ones -- except where decoder.hip already runs it as its own launch (nc_rows).
+            // Tiles of 64 GEMM rows (the last stage of the 48 k vocoder) stay on the fp32 kernel: 300 against 191 us (stager-bound).
+            static const int ups_bf = knob("RVC_UPS_BF", 1);
+            const int k_n = s.nc_rows > 0 ? 0 : s.nc_k;
+            const int vk = upsbf_fold_noise(k_n) ? (s.rate - 1) * s.nc_stride + k_n : 0;
+            if (ups_bf && s.opad == 0 && s.rate * s.c_out >= 128 && upsbf_supported(s.c_in, s.c_out, s.rate, s.ksize, vk)) {
+                std::vector<uint16_t> frags;
+                upsbf_pack_host(uw->data.data(), k_n ? nw->data.data() : nullptr, bias.data(), s.c_in, s.c_out, s.rate, s.ksize, vk, k_n, s.nc_stride, &frags);
+                if (s.wub.upload(frags)) return 1;
+                s.ub_vk = vk;
+            }
+        }
         if (s.nc_rows) {
             std::vector<float> ncw((size_t)s.nc_rows * s.c_out, 0.f);
             for (int k = 0; k < s.nc_k; ++k)
                 for (int co = 0; co < s.c_out; ++co) ncw[(size_t)k * s.c_out + co] = nw->data[(size_t)co * s.nc_k + k];
             if (s.nc_w.upload(ncw)) return 1;
         }
-        std::vector<float> bias(s.c_out);
-        for (int co = 0; co < s.c_out; ++co) bias[co] = ub->data[co] + nb->data[co];
         if (s.b.upload(bias)) return 1;
 
         const int nb_ = c.n_res_kernels * c.n_res_dilations;
@@ -865,12 +878,16 @@ extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const flo
         Stage &s = d->stages[i];
         const int64_t nq = len + 1;
         const int64_t len_out = (len - 1) * s.rate - 2 * s.pad + s.ksize + s.opad;
+        float *X = buf[1];
+        if (s.wub.p && (int64_t)s.c_in * len * 4 < ((int64_t)1 << 31) && (int64_t)s.c_out * len_out * 4 < ((int64_t)1 << 31) && L * 4 < ((int64_t)1 << 31)) {
+            if (launch_upsbf(cur, har, L, s.wub.p, s.b.p, X, batch, s.c_in, s.c_out, len, len_out, s.rate, s.ksize, s.pad, s.ub_vk, s.S, s.P, 0.1f, stream))
+                return 1;
+        } else {
         if (s.vk_rows) {
             hipLaunchKernelGGL(unfold_src_kernel, dim3((unsigned)ceil_div(nq, 256), s.vk_rows, batch), dim3(256), 0, stream, har, L,
                                s.S, s.P, s.vk, s.vk_rows, nq, V);
             RVC_LAUNCH_CHECK();
         }
-        float *X = buf[1];
         {
             ConvParams p;
             p.x1 = cur; p.c1 = s.c_in; p.slope1 = 0.1f; p.x1_bstride = (int64_t)s.c_in * len;
@@ -885,6 +902,7 @@ extern "C" int rvc_decoder_forward(rvc_decoder *d, const float *z_dev, const flo
             p.up_stride = s.rate; p.up_pad = s.pad; p.up_interleave = s.interleave ? 1 : 0; p.batch = batch;
             p.l_in2 = nq;
             if (launch_conv(p, stream)) return 1;
+        }
         }
         if (s.nc_rows) {   // the noise conv on its own: y += W_nc V2 (hifigan_nsf.py:190-191), bias already in the upsampler's
             hipLaunchKernelGGL(unfold_src_kernel, dim3((unsigned)ceil_div(len_out, 256), s.nc_rows, batch), dim3(256), 0, stream, har,

@@ -122,6 +122,10 @@ SYMBOLS = {
     "rvc_resblock_bf16w_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int,
                                            c_int, c_float, c_float, c_void_p]),
     "rvc_resblock_bf16x3_set_enabled": (c_int, [c_int]),
+    "rvc_upsample_bf16x3_weight_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
+    "rvc_upsample_bf16x3_pack_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rvc_upsample_bf16x3_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int,
+                                            c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "rvc_conv1d_bf16w_weight_bytes": (c_int, [c_int, c_int, POINTER(c_size_t)]),
     "rvc_conv1d_bf16w_pack_weight": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "rvc_conv1d_bf16w_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int,
@@ -670,6 +674,41 @@ def conv1d_bf16w_forward(x, u_packed, bias, k, dilation=1, slope_in=1.0, res=Non
                                          res.data_ptr() if res is not None else None, acc.data_ptr() if acc is not None else None,
                                          y.data_ptr(), b, c, length, k, dilation, float(slope_in), float(out_scale), _stream()),
            "rvc_conv1d_bf16w_forward")
+    return y
+
+
+# ---- K3u: upsampling step (polyphase ConvTranspose1d + folded noise conv) on the bf16 matrix cores -----------------
+def upsample_bf16x3_pack_weight(up_w: torch.Tensor, noise_w, bias, rate: int, nc_stride: int, device):
+    """ConvTranspose1d weight [c_in, c_out, ksize] (+ the noise conv's weight [c_out, 1, nc_k] or None, + the summed bias [c_out] or None)
+    -> (fragment slab, noise weights [c_out, nc_k] or None, bias or None) on the device, the triple `upsample_bf16x3_forward` takes."""
+    up_w = up_w.detach().float().cpu().contiguous()
+    c_in, c_out, ksize = up_w.shape
+    nc_k, nw = 0, None
+    if noise_w is not None:
+        nw = noise_w.detach().float().cpu().reshape(c_out, -1).contiguous()
+        nc_k = nw.shape[1]
+    b = bias.detach().float().cpu().contiguous() if bias is not None else None
+    n = c_size_t()
+    _check(_lib.rvc_upsample_bf16x3_weight_bytes(c_in, c_out, rate, ksize, nc_k, nc_stride, ctypes.byref(n)), "rvc_upsample_bf16x3_weight_bytes")
+    u = torch.empty(n.value // 2, dtype=torch.int16, device=device)
+    _check(_lib.rvc_upsample_bf16x3_pack_weight(up_w.data_ptr(), nw.data_ptr() if nw is not None else None, b.data_ptr() if b is not None else None,
+                                                c_in, c_out, rate, ksize, nc_k, nc_stride, u.data_ptr(), _stream()), "rvc_upsample_bf16x3_pack_weight")
+    return u, (nw.to(device) if nw is not None else None), (b.to(device) if b is not None else None)
+
+
+def upsample_bf16x3_forward(x, har, packed, c_out, rate, ksize, pad, nc_stride=1, nc_pad=0, slope=0.1):
+    """y [B, c_out, (L - 1) rate - 2 pad + ksize] = bias + conv_transpose1d(leaky(x)) + noise_conv(har) for x [B, c_in, L], har [B, Lh]."""
+    u, nw, bias = packed
+    x = _dev_f32(x, "x")
+    b, c_in, length = x.shape
+    l_out = (length - 1) * rate - 2 * pad + ksize
+    y = torch.empty((b, c_out, l_out), dtype=torch.float32, device=x.device)
+    if har is not None:
+        har = _dev_f32(har, "har")
+    _check(_lib.rvc_upsample_bf16x3_forward(x.data_ptr(), har.data_ptr() if har is not None else None, har.shape[-1] if har is not None else 0,
+                                            u.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                            y.data_ptr(), b, c_in, c_out, length, rate, ksize, pad, nw.shape[1] if nw is not None else 0, nc_stride,
+                                            nc_pad, float(slope), _stream()), "rvc_upsample_bf16x3_forward")
     return y
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RVC_AMD_ABI_VERSION 4   /* 3: round-5 additions (K3f, K12-K14, branch streams); 4: round-6 additions (K3f / K3d with one-term taps, K3f's runtime switch); no existing signature changed */
+#define RVC_AMD_ABI_VERSION 4   /* 3: round-5 additions (K3f, K12-K14, branch streams); 4: round-6 additions (K3f / K3d with one-term taps, K3f's runtime switch, K3u); no existing signature changed */
 
 /* ---- library ------------------------------------------------------------------------------------ */
 
@@ -413,6 +413,22 @@ int rvc_conv1d_bf16w_pack_weight(const float *w_host, int c, int k, void *u_dev,
 int rvc_conv1d_bf16w_forward(const float *x_dev, const void *u_dev, const float *bias_dev, const float *res_dev,
                              const float *acc_dev, float *y_dev, int batch, int c, int64_t length, int k, int dilation,
                              float slope_in, float out_scale, void *stream);
+/* ---- K3u: the vocoder's upsampling step on the bf16 matrix cores (exact bf16x3 operands) -------------------------------------- *
+ * Replaces, per stage i of HiFiGANNSFGenerator.forward / HiFiGANMRFGenerator.forward (rvc/lib/algorithm/generators/hifigan_nsf.py:184-193,
+ * hifigan_mrf.py:349-357):   x = leaky_relu(x, slope); x = ups[i](x); x = x + noise_convs[i](har_source)
+ *     y[co][t] = bias[co] + ConvTranspose1d(leaky(x))[co][t] + sum_k noise_w[co][k] har[t nc_stride + k - nc_pad]
+ * ConvTranspose1d(c_in, c_out, ksize, stride = rate, padding = pad) with ksize <= 2 rate in polyphase form (a GEMM with rows
+ * (channel, phase), two taps); the noise conv (one input channel, nc_k taps, stride nc_stride; nc_k = 0: none) enters as
+ * (rate - 1) nc_stride + nc_k < 64 extra GEMM rows read straight from har_source [batch][har_len], plus a row of ones whose taps are the
+ * bias (so pack_weight takes it: ups bias + noise-conv bias [c_out]); without a noise conv bias_dev is added on the way out.
+ * rate in {2, 8, 10, 12}, c_in % 64 == 0; length_out = (length_in - 1) rate - 2 pad + ksize.  Every fp32 operand split exactly into
+ * three bf16, six products, fp32 accumulate (csrc/upsbf.hip); persistent whole-CU workgroups. */
+int rvc_upsample_bf16x3_weight_bytes(int c_in, int c_out, int rate, int ksize, int nc_k, int nc_stride, size_t *bytes);
+int rvc_upsample_bf16x3_pack_weight(const float *up_w_host, const float *noise_w_host, const float *bias_host, int c_in, int c_out,
+                                    int rate, int ksize, int nc_k, int nc_stride, void *u_dev, void *stream);
+int rvc_upsample_bf16x3_forward(const float *x_dev, const float *har_dev, int64_t har_len, const void *u_dev, const float *bias_dev,
+                                float *y_dev, int batch, int c_in, int c_out, int64_t length_in, int rate, int ksize, int pad,
+                                int nc_k, int nc_stride, int nc_pad, float slope_in, void *stream);
 /* Process-wide runtime switch for K3f inside rvc_decoder_finalize (default 1): decoder handles finalized while it is 0 keep the
  * (conv, conv) pairs of their narrow stages on the unfused kernels (csrc/resblock.hip, winobf.hip, wino.hip) -- the fall-back an
  * operator reaches for without rebuilding the library.  The entry points above are not affected. */

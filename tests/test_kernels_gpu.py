@@ -276,6 +276,50 @@ def test_conv1d_bf16_taps_direct_matches_float64(native, dev, c, k, dil, length,
     assert (y1.cpu().double() - ref3).abs().max().item() <= 6e-5
 
 
+@pytest.mark.parametrize("c_in,c_out,rate,ksize,nc_k,nc_stride,length,batch", [
+    (512, 256, 12, 24, 0, 1, 200, 1), (512, 256, 12, 24, 0, 1, 3198, 1),            # stage 0 of the 48 k vocoder (its noise conv runs separately)
+    (256, 128, 10, 20, 8, 4, 777, 2), (256, 128, 10, 20, 8, 4, 38376, 1),           # stage 1: 44 folded noise rows
+    (128, 64, 2, 4, 4, 2, 5003, 1), (64, 32, 2, 4, 1, 1, 4097, 2), (64, 32, 2, 4, 1, 1, 63, 1),   # stages 2 / 3
+    (512, 256, 10, 16, 0, 1, 333, 1), (256, 128, 8, 16, 8, 4, 1000, 1),             # the 40 k / 32 k vocoders' first stages (ksize < 2 rate)
+    (128, 64, 2, 4, 0, 1, 1, 1), (64, 32, 2, 4, 1, 1, 767520, 1),                   # one input position; the benchmarked last stage
+])
+def test_upsample_bf16x3_matches_float64(native, dev, c_in, c_out, rate, ksize, nc_k, nc_stride, length, batch):
+    """K3u (upsbf.hip, rvc_upsample_bf16x3_*): one upsampling step of the NSF / MRF vocoder -- leaky ReLU, ConvTranspose1d in polyphase form,
+    the noise conv of har_source folded in as extra GEMM rows (more than 4 taps; the bias then rides a row of ones) or evaluated in the
+    epilogue (hifigan_nsf.py:184-193) -- on the bf16 matrix cores with exact bf16x3
+    operands, against F.conv_transpose1d + F.conv1d in float64.  Every stage shape of the 48 k / 40 k / 32 k vocoders, ragged lengths,
+    a single input position, batch > 1.  Gate: 2e-5 of the largest value; relative RMS at the fp32 kernel's level; bit-reproducible."""
+    g = torch.Generator().manual_seed(c_in + rate * 7 + length)
+    pad = (ksize - rate) // 2
+    x = torch.randn(batch, c_in, length, generator=g)
+    w = torch.randn(c_in, c_out, ksize, generator=g) / (2 * c_in) ** 0.5
+    b = torch.randn(c_out, generator=g)
+    l_out = (length - 1) * rate - 2 * pad + ksize
+    ref = F.conv_transpose1d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), stride=rate, padding=pad)
+    har, nw, nc_pad = None, None, 0
+    if nc_k:
+        nc_pad = 0 if nc_stride == 1 else (nc_k - nc_stride) // 2
+        lh = l_out * nc_stride
+        har = torch.randn(batch, lh, generator=g)
+        nw = torch.randn(c_out, 1, nc_k, generator=g) * 0.3
+        ref = ref + F.conv1d(har.double()[:, None], nw.double(), None, stride=nc_stride, padding=nc_pad)[:, :, :l_out]
+    assert ref.shape == (batch, c_out, l_out)
+    packed = native.upsample_bf16x3_pack_weight(w, nw, b, rate, nc_stride, dev)
+    args = (x.to(dev), har.to(dev) if har is not None else None, packed, c_out, rate, ksize, pad, nc_stride, nc_pad, 0.1)
+    got = native.upsample_bf16x3_forward(*args)
+    assert got.shape == ref.shape
+    err = (got.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+    rel = ((got.cpu().double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    lib = F.conv_transpose1d(F.leaky_relu(x.to(dev), 0.1), w.to(dev), b.to(dev), stride=rate, padding=pad)
+    if nc_k:
+        lib = lib + F.conv1d(har.to(dev)[:, None], nw.to(dev), None, stride=nc_stride, padding=nc_pad)[:, :, :l_out]
+    rel_lib = ((lib.cpu().double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    print(f"upsample {c_in}->{c_out} x{rate} k{ksize} noise {nc_k}/{nc_stride} L {length} B {batch}: relative RMS error vs float64: bf16x3 {rel:.2e}, torch fp32 {rel_lib:.2e}")
+    assert rel <= max(1.5 * rel_lib, 3e-7)
+    assert torch.equal(native.upsample_bf16x3_forward(*args), got)
+
+
 @pytest.mark.parametrize("c,form", [(32, "three"), (64, "three"), (128, "three"), (32, "one"), (64, "one"), (128, "one"), (128, "direct"), (256, "direct")])
 def test_resblock_pair_fresh_buffers_right_after_load(c, form):
     """ADVICE round 5 (resblock_bf.hip:290): K3f is the default path of the narrow stages and carries a race that was removed by
