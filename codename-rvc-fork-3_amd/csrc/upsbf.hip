@@ -138,6 +138,12 @@ upsbf_kernel(const UbParams p) {
         ct = rest - bb * p.col_tiles;
     };
 
+    // Both x buffers start as zeros: the noise chunk stages only the channel quads that hold noise rows (and the ones row), the products of
+    // its other k steps multiply zero taps with whatever the buffer holds -- which must then be a finite number, not a stale bit pattern.
+    for (int o = tid * 16; o < 2 * GM::X_BYTES; o += UB_NTH * 16) *reinterpret_cast<ub_u32x4 *>(xs + o) = ub_u32x4{0u, 0u, 0u, 0u};
+    lds_barrier();
+    const int nqp_noise = (p.vk + 1 + 7) / 8;                 // channel quad PAIRS of the noise chunk that carry data
+
     if (wave >= 4) {
         // ============================================ stagers: HBM <-> LDS ============================================================
         __builtin_amdgcn_s_setprio(1);
@@ -176,6 +182,7 @@ upsbf_kernel(const UbParams p) {
 #pragma unroll
                 for (int i = 0; i < NIT; ++i) {
                     const int wi = sw_o * NIT + i, qp = wi / RC, rc = wi - qp * RC;
+                    if (qp >= nqp_noise) continue;                                          // (wave-uniform) nothing of the noise rows in these channels
                     const int qd = 2 * qp + lq, r = rc * 32 + l31;
                     const int q = q0m1 + r;
                     const bool okq = r < GM::XROWS && q >= 0 && q <= (int)L_in;              // V exists for q in [0, L_in]
@@ -198,6 +205,7 @@ upsbf_kernel(const UbParams p) {
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
                 const int wi = sw_o * NIT + i, qp = wi / RC, rc = wi - qp * RC;
+                if (ci >= nxc && qp >= nqp_noise) continue;                                 // the noise chunk: only the quads that were fetched
                 const int qd = 2 * qp + lq, r = rc * 32 + l31;
                 unsigned w[2][3];
 #pragma unroll

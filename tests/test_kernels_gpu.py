@@ -892,7 +892,7 @@ def test_decoder_full_synth_golden(native, dev, ref_inputs):
     assert rms(out - g["o"]) <= 5e-5, rms(out - g["o"])
 
 
-@pytest.mark.parametrize("co", ["gemmbf", "winobf2", "winobf", "knn_screen", "attention_bf", "resblock_bf", "resblock_bf1", "convbf1", "linear_presplit", "posconv"])
+@pytest.mark.parametrize("co", ["gemmbf", "winobf2", "winobf", "knn_screen", "attention_bf", "resblock_bf", "resblock_bf1", "convbf1", "upsbf", "linear_presplit", "posconv"])
 @pytest.mark.parametrize("k,c", [(11, 128), (3, 64), (7, 32)])
 def test_fp32_winograd_next_to_the_bf16_gemm_is_bit_exact(native, dev, k, c, co):
     """Regression test of profiles/r03_mfma_cohabitation.txt / r04_mfma_cohabitation.txt: while one thread launches a kernel that
@@ -918,6 +918,11 @@ def test_fp32_winograd_next_to_the_bf16_gemm_is_bit_exact(native, dev, k, c, co)
         ud = native.conv1d_bf16w_pack_weight(torch.randn(256, 256, 7, generator=g) * 0.03, dev)
         xd1 = torch.randn(1, 256, 40000, generator=g).to(dev)
         yd1 = torch.empty_like(xd1)
+    if co == "upsbf":        # K3u
+        pk = native.upsample_bf16x3_pack_weight(torch.randn(256, 128, 20, generator=g) * 0.03, torch.randn(128, 1, 8, generator=g) * 0.1,
+                                                torch.zeros(128), 10, 4, dev)
+        xu = torch.randn(1, 256, 8000, generator=g).to(dev)
+        hu = torch.randn(1, 8000 * 40, generator=g).to(dev)
     if co == "posconv":      # K14
         pw = native.posconv_bf16x3_pack_weight(torch.randn(768, 48, 128, generator=g) * 0.02, 16, dev)
         pb = torch.zeros(768, device=dev)
@@ -959,6 +964,8 @@ def test_fp32_winograd_next_to_the_bf16_gemm_is_bit_exact(native, dev, k, c, co)
                     native.conv1d_winobf_forward(xb, ub, bb, 64, 11, 1, 0.1)
                 elif co == "convbf1":
                     native.conv1d_bf16w_forward(xd1, ud, None, 7, 3, 0.1, out=yd1)
+                elif co == "upsbf":
+                    native.upsample_bf16x3_forward(xu, hu, pk, 128, 10, 20, 5, 4, 2)
                 elif co == "posconv":
                     native.posconv_gelu_bf16x3(pxp, pw, pb, 16, 128, 64)
                 elif co in ("resblock_bf", "resblock_bf1"):
