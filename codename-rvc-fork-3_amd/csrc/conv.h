@@ -94,6 +94,16 @@ void upsbf_pack_host(const float *uw, const float *nw, const float *bias, int c_
 int launch_upsbf(const float *x, const float *har, int64_t Lh, const void *u, const float *bias, float *y, int batch, int c_in, int c_out,
                  int64_t L_in, int64_t L_out, int rate, int ksize, int pad, int vk, int64_t S, int64_t P, float slope, hipStream_t stream);
 
+// K10b (conv2dbf.hip): the U-Net's 3x3 convs as exact bf16x3 products; the K-split levels share K10's fixed-order finish pass
+bool conv2dbf_supported(int c_in, int c_out, int H, int W, int taps);
+size_t conv2dbf_weight_bytes(int c_out, int c_in);
+size_t conv2dbf_workspace_bytes(int batch, int c_in, int c_out, int H, int W);
+void conv2dbf_pack_host(const float *w, int c_out, int c_in, std::vector<uint16_t> *out);   // w [c_out][c_in][3][3]
+int launch_conv2dbf(const float *x, const void *u, const float *bias, const float *res, float *y, int batch, int c_in, int c_out, int H, int W,
+                    int relu, float *ws, size_t ws_bytes, hipStream_t stream);
+int launch_conv2d_finish(const float *partial, int split, int batch, int c_out, int H, int W, const float *bias, const float *res, int relu,
+                         float *y, hipStream_t stream);   // conv2d.hip: y = act(sum_s partial[s] + bias) + res, s in order
+
 // fp32 -> bf16, round to nearest even (what torch's .bfloat16() does); NaN stays NaN
 static inline uint16_t bf16_rne(float f) {
     uint32_t u;

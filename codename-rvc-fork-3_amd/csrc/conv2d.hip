@@ -261,6 +261,15 @@ __global__ void conv2d_finish_kernel(const float *partial, int split, int64_t n_
     y[i] = v;
 }
 
+int launch_conv2d_finish(const float *partial, int split, int batch, int c_out, int H, int W, const float *bias, const float *res, int relu,
+                         float *y, hipStream_t stream) {
+    const int64_t n_plane = (int64_t)batch * c_out * H * W;
+    hipLaunchKernelGGL(conv2d_finish_kernel, dim3((unsigned)ceil_div(n_plane, 256)), dim3(256), 0, stream, partial, split, n_plane,
+                       (int64_t)H * W, c_out, bias, res, relu, y);
+    RVC_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int WM, int WN, int NT, int TAPS>
 static size_t conv2d_lds_bytes() {
     constexpr int BM = 32 * WM, BN = 32 * NT * WN, PAD = TAPS == 9 ? 1 : 0;
@@ -339,12 +348,7 @@ int launch_conv2d(const float *x, const float *w, const float *bias, const float
     if (bn == 64) rc = taps == 9 ? conv2d_launch<2, 2, 1, 9>(p, stream) : conv2d_launch<2, 2, 1, 1>(p, stream);
     else rc = taps == 9 ? conv2d_launch<1, 4, 1, 9>(p, stream) : conv2d_launch<1, 4, 1, 1>(p, stream);
     if (rc) return rc;
-    if (p.split > 1) {
-        const int64_t n_plane = (int64_t)batch * c_out * H * W;
-        hipLaunchKernelGGL(conv2d_finish_kernel, dim3((unsigned)ceil_div(n_plane, 256)), dim3(256), 0, stream, p.partial, p.split, n_plane,
-                           (int64_t)H * W, c_out, bias, res, relu, y);
-        RVC_LAUNCH_CHECK();
-    }
+    if (p.split > 1) return launch_conv2d_finish(p.partial, p.split, batch, c_out, H, W, bias, res, relu, y, stream);
     return 0;
 }
 

@@ -143,6 +143,12 @@ SYMBOLS = {
     "rvc_conv2d_packed_floats": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
     "rvc_conv2d_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rvc_conv2d_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
+    "rvc_conv2d_bf16x3_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "rvc_conv2d_bf16x3_weight_bytes": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
+    "rvc_conv2d_bf16x3_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rvc_conv2d_bf16x3_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
+    "rvc_conv2d_bf16x3_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                          c_void_p, c_size_t, c_void_p]),
     "rvc_conv2d_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "rvc_comm_unique_id": (c_int, [c_void_p]),
@@ -896,6 +902,42 @@ def conv2d_forward(x, w_packed, bias, c_out, ksize=3, relu=False, res=None, out=
                                    res.data_ptr() if res is not None else None, y.data_ptr(), b, c_in, c_out, h, wd, ksize, ksize,
                                    1 if relu else 0, ws.data_ptr() if ws is not None else None, need.value, _stream()),
            "rvc_conv2d_forward")
+    return y
+
+
+# ---- K10b: the same 3x3 conv as exact bf16x3 products on the bf16 matrix cores ------------------------------
+def conv2d_bf16x3_supported(c_in: int, c_out: int, height: int, width: int) -> bool:
+    return bool(_lib.rvc_conv2d_bf16x3_supported(c_in, c_out, height, width))
+
+
+def conv2d_bf16x3_packable(c_in: int, c_out: int) -> bool:
+    m_pad = (c_out + 31) // 32 * 32
+    return c_in % 16 == 0 and (m_pad in (32, 64) or m_pad % 128 == 0)
+
+
+def conv2d_bf16x3_pack_weight(w: torch.Tensor, device) -> torch.Tensor:
+    """torch conv2d weight [C_out, C_in, 3, 3] -> bf16x3 tap fragments in HBM (int16 words)."""
+    w = w.detach().float().cpu().contiguous()
+    c_out, c_in, kh, kw = w.shape
+    n = c_size_t()
+    _check(_lib.rvc_conv2d_bf16x3_weight_bytes(c_out, c_in, kh, kw, ctypes.byref(n)), "rvc_conv2d_bf16x3_weight_bytes")
+    out = torch.empty(n.value // 2, dtype=torch.int16, device=device)
+    _check(_lib.rvc_conv2d_bf16x3_pack_weight(w.data_ptr(), c_out, c_in, kh, kw, out.data_ptr(), _stream()), "rvc_conv2d_bf16x3_pack_weight")
+    return out
+
+
+def conv2d_bf16x3_forward(x, u, bias, c_out, relu=False, res=None, out=None):
+    """y = act(conv2d(x, w, padding=1) + bias) + res  (x [B, C_in, H, W] float32 on the device; u from conv2d_bf16x3_pack_weight)."""
+    x = _dev_f32(x, "x")
+    b, c_in, h, wd = x.shape
+    y = out if out is not None else torch.empty((b, c_out, h, wd), dtype=torch.float32, device=x.device)
+    need = c_size_t()
+    _check(_lib.rvc_conv2d_bf16x3_workspace_bytes(b, c_in, c_out, h, wd, ctypes.byref(need)), "rvc_conv2d_bf16x3_workspace_bytes")
+    ws = _ws.get("conv2d", need.value, x.device) if need.value else None
+    _check(_lib.rvc_conv2d_bf16x3_forward(x.data_ptr(), u.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                          res.data_ptr() if res is not None else None, y.data_ptr(), b, c_in, c_out, h, wd,
+                                          1 if relu else 0, ws.data_ptr() if ws is not None else None, need.value, _stream()),
+           "rvc_conv2d_bf16x3_forward")
     return y
 
 

@@ -73,12 +73,27 @@ class RMVPE0Predictor:
             for k, v in w.items():
                 if k.endswith((".c1.w", ".c2.w", ".sc.w", "cnn.w")) and v.shape[1] % 8 == 0:
                     self.wp[k] = _native.conv2d_pack_weight(v, self.device)
+        # K10b (conv2dbf.hip): the 3x3 convs as exact bf16x3 products on the bf16 matrix cores (every level of the U-Net; the 1x1 shortcuts
+        # and shapes it does not take stay on K10)
+        self.wb = {}
+        if self.device.type == "cuda":
+            for k, v in w.items():
+                if k.endswith((".c1.w", ".c2.w", "cnn.w")) and v.shape[-1] == 3 and _native.conv2d_bf16x3_packable(v.shape[1], v.shape[0]):
+                    self.wb[k] = _native.conv2d_bf16x3_pack_weight(v, self.device)
         # BiGRU: one GEMM for the input projections of both directions, recurrence in librvc_amd (gru.hip)
         self.w["gru.wih"] = torch.cat([self.w["gru.weight_ih_l0"], self.w["gru.weight_ih_l0_reverse"]], 0).contiguous()
         self.w["gru.bih"] = torch.cat([self.w["gru.bias_ih_l0"], self.w["gru.bias_ih_l0_reverse"]], 0).contiguous()
         self.w["gru.whhT"] = torch.stack([self.w["gru.weight_hh_l0"].t(), self.w["gru.weight_hh_l0_reverse"].t()], 0).contiguous()
         self.w["gru.bhh"] = torch.stack([self.w["gru.bias_hh_l0"], self.w["gru.bias_hh_l0_reverse"]], 0).contiguous()
         return self
+
+    def _conv3(self, x, name, c_out, relu=False, res=None):
+        """One 3x3 conv + folded-BN bias (+ ReLU, + skip path): K10b where it takes the shape, else K10."""
+        from rvc_amd import _native
+        u = self.wb.get(name + ".w")
+        if u is not None and _native.conv2d_bf16x3_supported(x.shape[1], c_out, x.shape[2], x.shape[3]):
+            return _native.conv2d_bf16x3_forward(x, u, self.w[name + ".b"], c_out, relu=relu, res=res)
+        return _native.conv2d_forward(x, self.wp[name + ".w"], self.w[name + ".b"], c_out, 3, relu=relu, res=res)
 
     def _block(self, x, p):
         w = self.w
@@ -87,9 +102,9 @@ class RMVPE0Predictor:
             from rvc_amd import _native
             c_mid, c_out = w[p + ".c1.w"].shape[0], w[p + ".c2.w"].shape[0]
             x = x.contiguous()
-            y = _native.conv2d_forward(x, self.wp[p + ".c1.w"], w[p + ".c1.b"], c_mid, 3, relu=True)
+            y = self._conv3(x, p + ".c1", c_mid, relu=True)
             res = _native.conv2d_forward(x, self.wp[p + ".sc.w"], w[p + ".sc.b"], c_out, 1) if p + ".sc.w" in self.wp else x
-            return _native.conv2d_forward(y, self.wp[p + ".c2.w"], w[p + ".c2.b"], c_out, 3, relu=True, res=res)
+            return self._conv3(y, p + ".c2", c_out, relu=True, res=res)
         if x.is_cuda and x.shape[-1] * x.shape[-2] % 4 == 0:
             # conv by MIOpen; bias + ReLU (+ residual) as ONE pass of librvc_amd K8 instead of three PyTorch launches
             from rvc_amd import _native
@@ -136,7 +151,7 @@ class RMVPE0Predictor:
                 x = self._block(x, f"{p}.conv2.{m}")
         if x.is_cuda and "cnn.w" in self.wp and x.shape[-1] in (4, 8, 16, 32, 64, 128):
             from rvc_amd import _native
-            x = _native.conv2d_forward(x.contiguous(), self.wp["cnn.w"], w["cnn.b"], w["cnn.w"].shape[0], 3)
+            x = self._conv3(x.contiguous(), "cnn", w["cnn.w"].shape[0])
         else:
             x = F.conv2d(x, w["cnn.w"], w["cnn.b"], 1, 1)
         x = x.transpose(1, 2).flatten(-2)

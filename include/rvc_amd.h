@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RVC_AMD_ABI_VERSION 4   /* 3: round-5 additions (K3f, K12-K14, branch streams); 4: round-6 additions (K3f / K3d with one-term taps, K3f's runtime switch, K3u); no existing signature changed */
+#define RVC_AMD_ABI_VERSION 4   /* 3: round-5 additions (K3f, K12-K14, branch streams); 4: round-6 additions (K3f / K3d with one-term taps, K3f's runtime switch, K3u, K10b); no existing signature changed */
 
 /* ---- library ------------------------------------------------------------------------------------ */
 
@@ -341,6 +341,20 @@ int rvc_conv2d_workspace_bytes(int batch, int c_in, int c_out, int height, int w
 int rvc_conv2d_forward(const float *x_dev, const float *w_packed_dev, const float *bias_dev, const float *res_dev,
                        float *y_dev, int batch, int c_in, int c_out, int height, int width, int kh, int kw, int relu,
                        void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* ---- K10b: the same 3x3 conv on the bf16 matrix cores, every fp32 operand split exactly into three bf16 (six products of order
+ * <= 2^-16, fp32 accumulate: fp32-level results, not bit-equal to K10's k-ordered fp32 chain).  Replaces the same ConvBlockRes convs
+ * (RMVPE.py:13-64) for the shapes rvc_conv2d_bf16x3_supported() returns 1 for: C_in a multiple of 16, C_out <= 64 or a multiple of
+ * 128, W a power of two in 4..128 (and <= 256 / 128 / 64 pixels for <= 32 / <= 64 / more output channels); 3x3 only.
+ * u: rvc_conv2d_bf16x3_weight_bytes() bytes filled by rvc_conv2d_bf16x3_pack_weight from torch's HOST [C_out][C_in][3][3].
+ * workspace: rvc_conv2d_bf16x3_workspace_bytes() bytes (the K-split deep levels; partials summed in a fixed order). */
+int rvc_conv2d_bf16x3_supported(int c_in, int c_out, int height, int width);
+int rvc_conv2d_bf16x3_weight_bytes(int c_out, int c_in, int kh, int kw, size_t *bytes);
+int rvc_conv2d_bf16x3_pack_weight(const float *w_host, int c_out, int c_in, int kh, int kw, void *u_dev, void *stream);
+int rvc_conv2d_bf16x3_workspace_bytes(int batch, int c_in, int c_out, int height, int width, size_t *out);
+int rvc_conv2d_bf16x3_forward(const float *x_dev, const void *u_dev, const float *bias_dev, const float *res_dev, float *y_dev,
+                              int batch, int c_in, int c_out, int height, int width, int relu, void *workspace_dev,
+                              size_t workspace_bytes, void *stream);
 
 /* ---- the same conv in its fast form (unit-test entry of what the decoder uses for its ResBlock layers) ---------------- *
  * Winograd / Toom-Cook over groups of taps -- F(4,3) for 3 taps, F(4,4) for 7 and 11: identical mathematics, 1.5 / 3.5 / 5.25

@@ -578,6 +578,37 @@ def test_conv1d_winograd_f43_groups_still_pass():
     assert "12 passed" in r.stdout, r.stdout[-500:]
 
 
+@pytest.mark.parametrize("c_in,c_out,h,w,batch", [
+    (32, 32, 50, 64, 1), (64, 64, 37, 32, 2), (128, 128, 101, 16, 1), (256, 256, 51, 8, 1), (512, 512, 26, 4, 1),
+    (256, 512, 101, 4, 1), (512, 256, 13, 8, 1), (16, 16, 9, 128, 1), (32, 16, 7, 128, 1), (16, 3, 11, 128, 1),
+    (64, 32, 33, 64, 1), (16, 16, 1250, 128, 1), (32, 32, 700, 64, 1), (128, 64, 95, 32, 1), (256, 128, 47, 16, 2),
+    (512, 512, 5, 4, 1), (16, 32, 3, 4, 1),
+])
+def test_conv2d_bf16x3_matches_float64(native, dev, c_in, c_out, h, w, batch):
+    """K10b (conv2dbf.hip), the 3x3 conv of RMVPE's ConvBlockRes (RMVPE.py:13-60) as exact bf16x3 products: every level's
+    (channels, row length) pair of the U-Net and the decoder's 2 C -> C first convs, heights that are not a multiple of the tile's
+    rows, the 16- and 3-channel outputs (padded to 32 rows), the K-split deep levels, maps with more tiles than the chip has CUs
+    (a workgroup walks several: the tap ring and the staging run on across tiles), maps smaller than one tile -- vs float64."""
+    g = torch.Generator().manual_seed(c_in * 100 + c_out + h + w)
+    x = torch.randn(batch, c_in, h, w, generator=g)
+    wt = torch.randn(c_out, c_in, 3, 3, generator=g) / (c_in * 9) ** 0.5
+    b = torch.randn(c_out, generator=g)
+    res = torch.randn(batch, c_out, h, w, generator=g)
+    assert native.conv2d_bf16x3_supported(c_in, c_out, h, w)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1)) + res.double()
+    u = native.conv2d_bf16x3_pack_weight(wt, dev)
+    got = native.conv2d_bf16x3_forward(x.to(dev), u, b.to(dev), c_out, relu=True, res=res.to(dev)).cpu()
+    assert got.shape == ref.shape
+    err = (got.double() - ref).abs().max().item()
+    f32 = (F.relu(F.conv2d(x, wt, b, padding=1)) + res).double()
+    assert err <= 4e-6 and err <= 4 * max((f32 - ref).abs().max().item(), 1e-7), err   # fp32-level, not "2e-5"
+    plain_ref = F.conv2d(x.double(), wt.double(), None, padding=1)
+    plain = native.conv2d_bf16x3_forward(x.to(dev), u, None, c_out).cpu()
+    assert (plain.double() - plain_ref).abs().max().item() <= 4e-6
+    again = native.conv2d_bf16x3_forward(x.to(dev), u, None, c_out).cpu()
+    assert torch.equal(plain, again)                # split-K partials are summed in a fixed order
+
+
 @pytest.mark.parametrize("c_in,c_out,h,w,ks,batch", [
     (32, 32, 50, 64, 3, 1), (64, 64, 37, 32, 3, 2), (128, 128, 101, 16, 3, 1), (256, 256, 51, 8, 3, 1), (512, 512, 26, 4, 3, 1),
     (256, 512, 101, 4, 3, 1), (512, 256, 13, 8, 3, 1), (16, 16, 9, 128, 3, 1), (32, 16, 7, 128, 3, 1), (16, 3, 11, 128, 3, 1),
