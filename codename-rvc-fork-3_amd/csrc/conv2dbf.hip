@@ -96,17 +96,24 @@ __device__ __forceinline__ void c2b_split3(float a, float b, unsigned w[3]) {
     }
 }
 
+// offset of a buffer operation that may have to be a no-op: a select, never a branch
+__device__ __forceinline__ unsigned c2b_sel(bool ok, unsigned off) {
+    unsigned r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(C2B_OOB), "v"(off), "s"((unsigned long long)__builtin_amdgcn_ballot_w64(ok)));
+    return r;
+}
+
 // the six products of a multiply-add, smallest first: (tap split, window split) = (0,2) (1,1) (2,0) (0,1) (1,0) (0,0)
 __host__ __device__ constexpr int c2b_sa(int pr) { return pr < 3 ? pr : (pr == 4 ? 1 : 0); }
 __host__ __device__ constexpr int c2b_sb(int pr) { return pr < 3 ? 2 - pr : (pr == 3 ? 1 : 0); }
 
-// DBG (ablation build only, RVC_C2B_DEBUG; wrong results): 1 no matrix instructions, 2 no split + LDS writes after the first item,
-// 4 no output stores / skip-path loads, 8 no input loads after the second item, 16 no io-tile writes
-template <int MW, int DBG = 0>
+// DBG (ablation build only, RVC_C2B_DEBUG): 1 no matrix instructions (wrong results), 64 cycle stamps (tools/stamp_conv2dbf.py)
+// RES: the conv has ONE chunk (16 input channels) and one 32-row block: its 27 tap fragments stay in registers for the whole launch
+template <int MW, int DBG = 0, bool RES = false>
 __global__ void __launch_bounds__(C2B_NTH) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv2dbf_kernel(const C2bParams p) {
     using GM = C2bGeom<MW>;
-    constexpr int NW = GM::NW, BN = GM::BN, NJ = GM::NJ, ROWB = C2B_ROWB, TAPS = C2B_TAPS, PA = 3;
+    constexpr int NW = GM::NW, BN = GM::BN, NJ = GM::NJ, ROWB = C2B_ROWB, TAPS = C2B_TAPS, PA = RES ? TAPS : 3;
     static_assert(TAPS % PA == 0, "a tap's ring slot must be a compile-time register index");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char c2b_smem[];
@@ -135,6 +142,17 @@ conv2dbf_kernel(const C2bParams p) {
     for (int o = tid * 16; o < 2 * GM::X_BYTES; o += C2B_NTH * 16) *reinterpret_cast<c2b_u32x4 *>(xs + o) = c2b_u32x4{0u, 0u, 0u, 0u};
     lds_barrier();
 
+    // DBG & 64 (ablation build): wave 0 and wave 4 write cycle-counter stamps to `partial` (unsplit launches): [block][role 2][64]
+    unsigned long long *const stamps = (DBG & 64) ? reinterpret_cast<unsigned long long *>(p.partial) + ((size_t)blockIdx.x * 2 + (wave >= 4 ? 1 : 0)) * 64 : nullptr;
+    int n_stamp = 0;
+    auto stamp = [&]() __attribute__((always_inline)) {
+        if constexpr ((DBG & 64) != 0) {
+            if ((wave == 0 || wave == 4) && lane == 0 && n_stamp < 64) stamps[n_stamp] = __builtin_readcyclecounter();
+            ++n_stamp;
+        }
+    };
+    stamp();
+
     if (wave >= 4) {
         // ============================================ stagers: HBM -> LDS ================================================================
         __builtin_amdgcn_s_setprio(1);
@@ -155,17 +173,22 @@ conv2dbf_kernel(const C2bParams p) {
         }
         float xr[NJ][16];
         const int num_bytes = p.c_in * HW * 4;
+        // (Measured, profiles/r06_conv2dbf_stamps.txt: issuing the SAME sequence of memory operations in every phase -- no-op offsets where an
+        // item has no store or skip path -- makes the compiler's s_waitcnt counts exact instead of draining the queue, and is slower on
+        // every multi-chunk shape: the no-op requests still cost their turn in the address pipeline.  The loaded latency of this
+        // access pattern is ~7 k cycles at level 0, where the kernel moves ~3.3 TB/s through L2.)
         auto x_issue = [&](int i) __attribute__((always_inline)) {
+            const bool valid = i < n_items;
             const int k = i / n_chunks, c = i - k * n_chunks;
             int b, pxt, mblk;
             decode(k, b, pxt, mblk);
             const int t0 = pxt * th;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + (int64_t)b * p.c_in * HW), 0, num_bytes, C2B_RSRC);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + (valid ? (int64_t)b * p.c_in * HW : 0)), 0, num_bytes, C2B_RSRC);
             const int ch0 = (c_begin + c) * C2B_CK;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const bool ok = ((inside >> j) & 1) && (unsigned)(t0 + prow[j]) < (unsigned)H;
-                const unsigned vo = ok ? (unsigned)((t0 - 1) * W + st + 256 * j) * 4u : C2B_OOB;
+                const bool ok = (int)valid & (int)((inside >> j) & 1) & (int)((unsigned)(t0 + prow[j]) < (unsigned)H);   // (no short circuit: no branches)
+                const unsigned vo = c2b_sel(ok, (unsigned)((t0 - 1) * W + st + 256 * j) * 4u);
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
                     xr[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)vo, (ch0 + e) * HW * 4, 0));
@@ -187,41 +210,54 @@ conv2dbf_kernel(const C2bParams p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        // ---- the finished tile: io tile (+ skip path) -> HBM, 16 bytes per lane, whole rows of the tile (= consecutive pixels of the plane)
+        // ---- the finished tile: act(io tile + bias) + skip path -> HBM, 16 bytes per lane, whole rows of the tile (= consecutive pixels of
+        //      the plane); a K split stores the bare partial sums
         constexpr int LPR = BN / 4, RPP = 256 / LPR, PASSES = GM::BM / RPP;
         const int orow = st / LPR, ocol = (st % LPR) * 4;
-        const bool has_res = p.res != nullptr && p.split == 1;
+        const bool whole = p.split == 1;
+        const bool has_res = p.res != nullptr && whole, has_bias = p.bias != nullptr && whole, relu = p.relu && whole;
         const int out_bytes = p.c_out * HW * 4;
-        f32x4 rres[PASSES];
-        auto out_offset = [&](int mblk, int pxt, int ps) __attribute__((always_inline)) -> unsigned {
+        f32x4 rres[PASSES];                                  // a unit's skip-path values and bias, requested a phase before they are added
+        float rbias[PASSES];
+        auto out_offset = [&](bool valid, int mblk, int pxt, int ps) __attribute__((always_inline)) -> unsigned {
             const int co = mblk * GM::BM + ps * RPP + orow, pix = pxt * th * W + ocol;
-            return co < p.c_out && pix < HW ? (unsigned)(co * HW + pix) * 4u : C2B_OOB;
+            return c2b_sel((int)valid & (int)(co < p.c_out) & (int)(pix < HW), (unsigned)(co * HW + pix) * 4u);
         };
-        auto res_issue = [&](int k) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)(has_bias ? p.bias : p.x), 0, p.c_out * 4, C2B_RSRC);
+        auto epi_issue = [&](int k, bool valid) __attribute__((always_inline)) {
             int b, pxt, mblk;
             decode(k, b, pxt, mblk);
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res + (int64_t)b * p.c_out * HW), 0, out_bytes, C2B_RSRC);
+            const bool vr = (int)valid & (int)has_res;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(vr ? p.res + (int64_t)b * p.c_out * HW : p.x), 0, out_bytes, C2B_RSRC);
 #pragma unroll
             for (int ps = 0; ps < PASSES; ++ps)
-                rres[ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)out_offset(mblk, pxt, ps), 0, 0));
+                rres[ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)out_offset(vr, mblk, pxt, ps), 0, 0));
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int co = mblk * GM::BM + ps * RPP + orow;
+                rbias[ps] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (int)c2b_sel((int)valid & (int)has_bias & (int)(co < p.c_out), (unsigned)co * 4u), 0, 0));
+            }
         };
-        auto out_store = [&](int k) __attribute__((always_inline)) {
+        auto out_store = [&](int k, bool valid) __attribute__((always_inline)) {
             int b, pxt, mblk;
             decode(k, b, pxt, mblk);
-            float *const dst = p.split > 1 ? p.partial + ((int64_t)((int)blockIdx.y * p.batch + b) * p.c_out) * HW : p.y + (int64_t)b * p.c_out * HW;
+            float *const dst = !valid ? p.y : (whole ? p.y + (int64_t)b * p.c_out * HW : p.partial + ((int64_t)((int)blockIdx.y * p.batch + b) * p.c_out) * HW);
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, out_bytes, C2B_RSRC);
 #pragma unroll
             for (int ps = 0; ps < PASSES; ++ps) {
                 f32x4 v = *reinterpret_cast<const f32x4 *>(io + (ps * RPP + orow) * BN + ocol);
-                if (has_res) v += rres[ps];
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(c2b_u32x4, v), rs, (int)out_offset(mblk, pxt, ps), 0, 0);
+                v += rbias[ps];
+                if (relu) v = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+                v += rres[ps];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(c2b_u32x4, v), rs, (int)out_offset(valid, mblk, pxt, ps), 0, 0);
             }
         };
         // Per phase, behind barrier A(i) (item i's rows are complete in buffer i & 1, the compute waves are done with the other one, and
-        // -- first item of a unit -- the previous unit's outputs are in the io tile):
-        //   write item i + 1 (requested a phase ago) into buffer (i + 1) & 1; request item i + 2; store the previous unit; last chunk of
-        //   a unit: request its skip-path values (added a phase later: a wave's memory operations retire in order, so whatever is
-        //   consumed at the start of a phase must have been requested a whole phase earlier).
+        // -- first item of a unit -- the previous unit's accumulators are in the io tile):
+        //   write item i + 1 (requested a phase ago) into buffer (i + 1) & 1; request item i + 2; store the previous unit (its bias and
+        //   skip-path values were requested a phase ago); request this unit's.
+        // A wave's memory operations retire in order: whatever a phase consumes was requested a whole phase earlier, and nothing but
+        // older requests stands before it in the queue.
         // A unit of ONE chunk writes its io tile in the phase the previous unit's is drained: barrier B orders the two.
         x_issue(0);
         x_write(0);
@@ -229,14 +265,19 @@ conv2dbf_kernel(const C2bParams p) {
         for (int i = 0; i < n_items; ++i) {
             const int k = i / n_chunks, c = i - k * n_chunks;
             lds_barrier();                                    // (A)
-            if (i + 1 < n_items && !(dbg & 2)) x_write(i + 1);
-            if (i + 2 < n_items && !(dbg & 8)) x_issue(i + 2);
-            if (c == 0 && i > 0 && !(dbg & 4)) out_store(k - 1);   // its skip-path values were requested a phase ago
-            if (has_res && c == n_chunks - 1 && !(dbg & 4)) res_issue(k);
+            stamp();
+            if (i + 1 < n_items) x_write(i + 1);
+            stamp();
+            if (i + 2 < n_items) x_issue(i + 2);
+            stamp();
+            if (c == 0 && i > 0) out_store(k - 1, true);      // its bias / skip-path values were requested a phase ago
+            if (c == n_chunks - 1) epi_issue(k, true);
+            stamp();
             if (n_chunks == 1) lds_barrier();                 // (B)
+            stamp();
         }
-        lds_barrier();                                        // (E) the last unit's outputs are in the io tile
-        out_store(my_units - 1);
+        lds_barrier();                                        // (E) the last unit's accumulators are in the io tile
+        out_store(my_units - 1, true);
         return;
     }
 
@@ -272,11 +313,13 @@ conv2dbf_kernel(const C2bParams p) {
     decode(0, b, pxt, mblk);
     int base_cur = item_base(mblk, 0);
     const unsigned vo_lane = 16u * (unsigned)lane;
-    load_a(0, vo_lane, base_cur, 0);
-    load_a(1, vo_lane, base_cur, 1);
-    const float *const bias = p.split == 1 ? p.bias : nullptr;
-    const bool relu = p.relu && p.split == 1;
-    float bv[16];
+    if constexpr (RES) {
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) load_a(tap, vo_lane, base_cur, tap);
+    } else {
+        load_a(0, vo_lane, base_cur, 0);
+        load_a(1, vo_lane, base_cur, 1);
+    }
 
     for (int i = 0; i < n_items; ++i) {
         // the item behind this one (its first two taps are requested under this item's last two)
@@ -291,13 +334,9 @@ conv2dbf_kernel(const C2bParams p) {
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {                    // consumed a unit later
-                const int co = (mblk * MW + mw) * 32 + 4 * half + (r & 3) + 8 * (r >> 2);
-                bv[r] = bias && co < p.c_out ? bias[co] : 0.f;
-            }
         }
         lds_barrier();                                        // (A) item i's rows are in buffer i & 1
+        stamp();
         const unsigned char *const src = xs + (i & 1) * GM::X_BYTES;
 #pragma unroll
         for (int q = 0; q < 6; ++q) load_b1(0, src, 0, q & 1, 2 - (q >> 1));
@@ -313,26 +352,25 @@ conv2dbf_kernel(const C2bParams p) {
                     if (!(dbg & 1)) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tap % PA][c2b_sa(pr)], fb[tap & 1][cb][c2b_sb(pr)], acc[cb], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (q < 6 && tap + 1 < TAPS) load_b1((tap + 1) & 1, src, tap + 1, q & 1, 2 - (q >> 1));
-                    if (q == 11) {
+                    if (q == 11 && !RES) {
                         if (tap + 2 < TAPS) load_a((tap + 2) % PA, vo_lane, base_cur, tap + 2);
                         else load_a((tap + 2) % PA, vo_next, base_next, tap + 2 - TAPS);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
         }
+        stamp();
         if (c == n_chunks - 1) {
-            // ---- epilogue: bias, ReLU, into the io tile (skip path and the stores are the stagers'; a K split stores bare partial sums)
+            // ---- epilogue: the accumulators into the io tile (bias, ReLU, skip path and the stores are the stagers')
             if (n_chunks == 1) lds_barrier();                 // (B) the stagers have taken the previous unit out of the io tile
+            stamp();
             float *const io_mine = io + (mw * 32 + 4 * half) * BN + nw * 64 + l31;
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[cb][r] + bv[r];
-                    if (relu) v = fmaxf(v, 0.f);
-                    if (!(dbg & 16)) io_mine[((r & 3) + 8 * (r >> 2)) * BN + cb * 32] = v;
-                }
+                for (int r = 0; r < 16; ++r) io_mine[((r & 3) + 8 * (r >> 2)) * BN + cb * 32] = acc[cb][r];
         }
+        stamp();
         k = kn; c = cn; b = bnx; pxt = pxtn; mblk = mblkn;
         base_cur = base_next;
     }
@@ -345,7 +383,7 @@ static int c2b_mw(int c_out) {
     const int m_pad = (c_out + 31) / 32 * 32;
     if (m_pad == 32) return 1;
     if (m_pad == 64) return 2;
-    if (m_pad % 128 == 0) return 4;
+    if (m_pad % 128 == 0) return 4;       // (two waves per 32-row block sharing their tap fragments through L1 -- MW = 2 here -- is 5 % slower)
     return 0;
 }
 
@@ -386,6 +424,11 @@ void conv2dbf_pack_host(const float *w, int c_out, int c_in, std::vector<uint16_
                     }
 }
 
+static bool c2b_resident() {
+    static const int on = knob("RVC_C2B_RES", 1);
+    return on != 0;
+}
+
 static int c2b_cu_count() {
     static const int n = [] {
         int dev = 0, cus = 256;
@@ -416,6 +459,14 @@ size_t conv2dbf_workspace_bytes(int batch, int c_in, int c_out, int H, int W) {
 
 template <int MW, int DBG = 0>
 static int c2b_launch1(const C2bParams &p, int grid_x, hipStream_t stream) {
+    if constexpr (MW == 1 && DBG == 0) {
+        if (p.n_chunks_total == 1 && p.n_mblk == 1 && c2b_resident()) {
+            if (reserve_whole_cu((const void *)conv2dbf_kernel<1, 0, true>, "conv2d bf16x3")) return 1;
+            hipLaunchKernelGGL((conv2dbf_kernel<1, 0, true>), dim3((unsigned)grid_x, 1, 1), dim3(C2B_NTH), LDS_WHOLE_CU, stream, p);
+            RVC_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (reserve_whole_cu((const void *)conv2dbf_kernel<MW, DBG>, "conv2d bf16x3")) return 1;
     hipLaunchKernelGGL((conv2dbf_kernel<MW, DBG>), dim3((unsigned)grid_x, (unsigned)p.split, 1), dim3(C2B_NTH), LDS_WHOLE_CU, stream, p);   // owns its CU (common.h)
     RVC_LAUNCH_CHECK();
@@ -428,14 +479,7 @@ static int c2b_launch(const C2bParams &p, int grid_x, hipStream_t stream) {
     static const int dbg = knob("RVC_C2B_DEBUG", 0);
     switch (dbg) {
     case 1: return c2b_launch1<MW, 1>(p, grid_x, stream);
-    case 2: return c2b_launch1<MW, 2>(p, grid_x, stream);
-    case 3: return c2b_launch1<MW, 3>(p, grid_x, stream);
-    case 4: return c2b_launch1<MW, 4>(p, grid_x, stream);
-    case 8: return c2b_launch1<MW, 8>(p, grid_x, stream);
-    case 16: return c2b_launch1<MW, 16>(p, grid_x, stream);
-    case 14: return c2b_launch1<MW, 14>(p, grid_x, stream);
-    case 30: return c2b_launch1<MW, 30>(p, grid_x, stream);
-    case 31: return c2b_launch1<MW, 31>(p, grid_x, stream);
+    case 64: return c2b_launch1<MW, 64>(p, grid_x, stream);
     default: break;
     }
 #endif
@@ -460,6 +504,9 @@ int launch_conv2dbf(const float *x, const void *u, const float *bias, const floa
         if (!ws || ws_bytes < need) return fail("conv2d bf16x3: workspace of %zu bytes needed, %zu given", need, ws_bytes);
         p.partial = ws;
     }
+#ifdef RVC_ABLATE
+    if (knob("RVC_C2B_DEBUG", 0) == 64 && p.split == 1) p.partial = ws;   // stamps (tools/stamp_conv2dbf.py hands over a workspace)
+#endif
     const int cus = c2b_cu_count();
     const int rounds = (int)ceil_div(p.n_units, cus);
     const int grid_x = (int)ceil_div(p.n_units, rounds);      // every workgroup walks `rounds` units (the last ones one fewer)

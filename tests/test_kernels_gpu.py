@@ -923,7 +923,7 @@ def test_decoder_full_synth_golden(native, dev, ref_inputs):
     assert rms(out - g["o"]) <= 5e-5, rms(out - g["o"])
 
 
-@pytest.mark.parametrize("co", ["gemmbf", "winobf2", "winobf", "knn_screen", "attention_bf", "resblock_bf", "resblock_bf1", "convbf1", "upsbf", "linear_presplit", "posconv"])
+@pytest.mark.parametrize("co", ["gemmbf", "winobf2", "winobf", "knn_screen", "attention_bf", "resblock_bf", "resblock_bf1", "convbf1", "upsbf", "linear_presplit", "posconv", "conv2dbf"])
 @pytest.mark.parametrize("k,c", [(11, 128), (3, 64), (7, 32)])
 def test_fp32_winograd_next_to_the_bf16_gemm_is_bit_exact(native, dev, k, c, co):
     """Regression test of profiles/r03_mfma_cohabitation.txt / r04_mfma_cohabitation.txt: while one thread launches a kernel that
@@ -954,6 +954,10 @@ def test_fp32_winograd_next_to_the_bf16_gemm_is_bit_exact(native, dev, k, c, co)
                                                 torch.zeros(128), 10, 4, dev)
         xu = torch.randn(1, 256, 8000, generator=g).to(dev)
         hu = torch.randn(1, 8000 * 40, generator=g).to(dev)
+    if co == "conv2dbf":     # K10b
+        u2 = native.conv2d_bf16x3_pack_weight(torch.randn(64, 64, 3, 3, generator=g) * 0.04, dev)
+        x2 = torch.randn(1, 64, 752, 32, generator=g).to(dev)
+        y2 = torch.empty_like(x2)
     if co == "posconv":      # K14
         pw = native.posconv_bf16x3_pack_weight(torch.randn(768, 48, 128, generator=g) * 0.02, 16, dev)
         pb = torch.zeros(768, device=dev)
@@ -999,6 +1003,8 @@ def test_fp32_winograd_next_to_the_bf16_gemm_is_bit_exact(native, dev, k, c, co)
                     native.upsample_bf16x3_forward(xu, hu, pk, 128, 10, 20, 5, 4, 2)
                 elif co == "posconv":
                     native.posconv_gelu_bf16x3(pxp, pw, pb, 16, 128, 64)
+                elif co == "conv2dbf":
+                    native.conv2d_bf16x3_forward(x2, u2, None, 64, relu=True, out=y2)
                 elif co in ("resblock_bf", "resblock_bf1"):
                     native.resblock_bf16x3_forward(xp, up, None, None, 7, 3, 0.1, out=yp, bf16_taps=co == "resblock_bf1")
                 elif co == "linear_presplit":
