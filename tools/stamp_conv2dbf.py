@@ -29,5 +29,5 @@ for c_in, c_out, h, w in [(16, 16, 3008, 128), (32, 32, 1504, 64), (64, 64, 752,
             t0 = int(v[0])
             rel = [(int(v[i]) - t0) for i in range(n)]
             deltas = [rel[i] - rel[i - 1] for i in range(1, n)]
-            print(f"block {blk:3d} {name}: total {rel[-1]:7d} cycles; deltas (start | " + ("A mfma B io" if role == 0 else "A store write issue B") + ")")
+            print(f"block {blk:3d} {name}: total {rel[-1]:7d} cycles; deltas (start | " + ("mfma B io nextA" if role == 0 else "write issue store+request B nextA") + ")")
             print("    ", deltas[:1], [deltas[1 + i:1 + i + per] for i in range(0, len(deltas) - 1, per)])
