@@ -373,7 +373,8 @@ def main():
                   "three bf16 products per multiply-add against exact bf16x3 activations: fused pairs up to 128 channels x 7 taps, single convs at 256 channels "
                   "and at 128 x 11 taps; fp32 accumulate everywhere)")
                  if cfg["weights"] == "bf16" else
-                 "f32 (vocoder 7/11-tap convs and 3-tap ones at >= 128 channels: fp32 operands as exact bf16x3 splits on the bf16 matrix cores, fp32 accumulate)",
+                 "f32 (vocoder ResBlock convs and upsamplers, HuBERT, RMVPE's U-Net convs: fp32 operands as exact bf16x3 splits on the bf16 matrix cores -- six "
+                 "products of order <= 2^-16 per multiply-add, fp32 accumulate; everything else fp32 / fp64)",
         "data": "synthetic (seeded random-init weights, FM-tone utterances, clustered index)",
         "rtf": round(value / sr, 2),
         "headline_is": "inputs resident in HBM, waveform left in HBM (the bench contract's definition of `value`); `host_io` is the "

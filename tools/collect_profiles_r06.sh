@@ -3,7 +3,7 @@
 #   * bench lines of every single-GPU BASELINE config on ONE box (cfg 4 against cfg 2 is an A/B: verdict item 1), the sequential
 #     schedule, a > 41 s clip (100 s: the long-input front, verdict item 7);
 #   * rocprofv3 kernel stats of the judged command and of the sequential schedule; one utterance's kernel list; the vocoders';
-#   * K3f with one-term taps: shape table, SQ counters (matrix pipe busy), HBM traffic;
+#   * K3f with one-term taps: shape table, SQ counters (matrix pipe busy), HBM traffic; K10b: shape table, kernel durations, stamps;
 #   * the roofline kernel (K3y): HBM traffic, SQ counters, the L2 -> CU request counters the verdict named;
 #   * kNN: the screened search and the STREAMING regime (32 queries), kernel stats + HBM traffic (verdict item 8);
 #   * tools/micro/l2_ingest: what one CU can pull out of L2 next to a matrix stream (the "ingest wall" of DESIGN section 4, measured).
@@ -31,6 +31,10 @@ rocprofv3 --kernel-trace --output-format csv -d /tmp/d2 -o t -- python3 $R/tools
 rocprofv3 --kernel-trace --output-format csv -d /tmp/d3 -o t -- python3 $R/tools/profile_decoder.py "MRF HiFi-GAN" bf16 >/dev/null 2>&1; python3 $R/tools/summarize_trace.py /tmp/d3/t_kernel_trace.csv > $O/decoder_kernels_mrf_bf16.txt
 BENCH_ONE=1 python3 $R/tools/bench_resblock_bf.py 2>&1 | grep -v amdgpu.ids > $O/rbf1_shapes.txt
 python3 $R/tools/bench_convbf1.py 2>&1 | grep -v amdgpu.ids > $O/convbf1_shapes.txt
+# K10b (RMVPE's 3x3 convs as bf16x3 products) against K10: event timings per shape, the kernels' own durations, the per-phase stamps
+python3 $R/tools/bench_conv2dbf.py 2>&1 | grep -v amdgpu.ids > $O/conv2dbf_shapes.txt
+rocprofv3 --kernel-trace --output-format csv -d /tmp/c2 -o t -- python3 $R/tools/bench_conv2dbf.py > /dev/null 2>&1; python3 $R/tools/summarize_trace.py /tmp/c2/t_kernel_trace.csv > $O/conv2dbf_kernels.txt
+(echo "tools/stamp_conv2dbf.py (ablation build, RVC_C2B_DEBUG=64): cycle stamps of compute wave 0 and stager wave 4 of three workgroups per shape; 108 matrix instructions of 32 cycles = 3456 cycles per item"; cd $R && RVC_AMD_LIB=$R/codename-rvc-fork-3_amd/rvc_amd/_lib/librvc_amd_ablate.so RVC_C2B_DEBUG=64 python3 tools/stamp_conv2dbf.py 2>&1 | grep -v "amdgpu.ids\|RVC_AMD_LIB") > $O/conv2dbf_stamps.txt
 # HBM traffic of the roofline kernel: FETCH_SIZE and WRITE_SIZE in separate passes (they do not fit one)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -o f -- python3 $R/tools/pmc_conv.py > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -o w -- python3 $R/tools/pmc_conv.py > /dev/null 2>&1
