@@ -43,6 +43,10 @@ python3 $R/tools/summarize_pmc.py /tmp/pf/f_counter_collection.csv /tmp/pw/w_cou
 ONE=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/rf -o f -- python3 $R/tools/pmc_rbf.py > /dev/null 2>&1
 ONE=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/rw -o w -- python3 $R/tools/pmc_rbf.py > /dev/null 2>&1
 python3 $R/tools/summarize_pmc_rbf.py /tmp/rf/f_counter_collection.csv /tmp/rw/w_counter_collection.csv $P/pmc_resblock_bf1.json > $O/pmc_resblock_bf1.txt 2>&1
+# ... of K10b per U-Net level
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/c2f -o f -- python3 $R/tools/pmc_conv2dbf.py > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/c2w -o w -- python3 $R/tools/pmc_conv2dbf.py > /dev/null 2>&1
+python3 $R/tools/summarize_pmc_conv2dbf.py /tmp/c2f/f_counter_collection.csv /tmp/c2w/w_counter_collection.csv > $O/pmc_conv2dbf.txt 2>&1
 # SQ counters: the roofline kernel, then the one-term pairs (derived pipe-busy figure next to the raw ones)
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pc -o c -- python3 $R/tools/pmc_conv.py > /dev/null 2>&1
 ONE=1 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pc1 -o c -- python3 $R/tools/pmc_rbf.py > /dev/null 2>&1
