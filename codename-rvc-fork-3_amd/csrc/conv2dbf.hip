@@ -52,6 +52,7 @@ struct C2bParams {
     int c_in = 0, c_out = 0, H = 0, W = 0, log2w = 0, batch = 1, relu = 0;
     int split = 1, chunks_per_split = 0, n_chunks_total = 0;
     int n_px_tiles = 0, n_mblk = 0, n_units = 0;
+    int per_xcd = 0;                 // > 0: units per XCD (persistent launches, grid a multiple of 8); 0: unit = workgroup id + k * grid
     unsigned u_bytes = 0;
 };
 
@@ -128,10 +129,22 @@ conv2dbf_kernel(const C2bParams p) {
     const int n_chunks = p.chunks_per_split, c_begin = (int)blockIdx.y * n_chunks;
     const int G = (int)gridDim.x;
     constexpr int dbg = DBG;
-    const int my_units = (p.n_units - (int)blockIdx.x + G - 1) / G;
-    const int n_items = my_units * n_chunks;                  // item i = (unit blockIdx.x + (i / n_chunks) G, chunk c_begin + i % n_chunks)
+    // Unit u0 + k ustep is this workgroup's k-th.  A map with more units than CUs (p.per_xcd > 0: the grid is a multiple of 8) gives
+    // every XCD -- workgroup ids go round the eight of them -- a CONTIGUOUS range of units that its workgroups walk side by side:
+    // the two halo rows a pixel tile shares with each neighbour are then in that XCD's L2 (ids b, b + 1 sit on different XCDs: with
+    // unit = b + k G the halo came from HBM a third of the time, profiles/r06_pmc_conv2dbf.txt).
+    int u0 = (int)blockIdx.x, ustep = G, my_units = (p.n_units - (int)blockIdx.x + G - 1) / G;
+    if (p.per_xcd > 0) {
+        const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+        ustep = G >> 3;
+        u0 = xcd * p.per_xcd + slot;
+        const int end = (xcd + 1) * p.per_xcd < p.n_units ? (xcd + 1) * p.per_xcd : p.n_units;
+        my_units = u0 < end ? (end - u0 + ustep - 1) / ustep : 0;
+    }
+    if (my_units <= 0) return;
+    const int n_items = my_units * n_chunks;                  // item i = (this workgroup's unit i / n_chunks, chunk c_begin + i % n_chunks)
     auto decode = [&](int k, int &b, int &pxt, int &mblk) __attribute__((always_inline)) {
-        const int unit = (int)blockIdx.x + k * G;
+        const int unit = u0 + k * ustep;
         const int rest = unit / p.n_mblk;
         mblk = unit - rest * p.n_mblk;                        // the channel blocks of one pixel tile are neighbours: the patch comes from L2
         b = rest / p.n_px_tiles;
@@ -429,6 +442,11 @@ static bool c2b_resident() {
     return on != 0;
 }
 
+static bool c2b_xcd_ranges() {
+    static const int on = knob("RVC_C2B_XCD", 1);
+    return on != 0;
+}
+
 static int c2b_cu_count() {
     static const int n = [] {
         int dev = 0, cus = 256;
@@ -509,7 +527,11 @@ int launch_conv2dbf(const float *x, const void *u, const float *bias, const floa
 #endif
     const int cus = c2b_cu_count();
     const int rounds = (int)ceil_div(p.n_units, cus);
-    const int grid_x = (int)ceil_div(p.n_units, rounds);      // every workgroup walks `rounds` units (the last ones one fewer)
+    int grid_x = (int)ceil_div(p.n_units, rounds);            // every workgroup walks `rounds` units (the last ones one fewer)
+    if (rounds > 1 && p.split == 1 && c2b_xcd_ranges()) {
+        p.per_xcd = (int)ceil_div(p.n_units, 8);
+        grid_x = (int)ceil_div(ceil_div(p.per_xcd, rounds), 1) * 8;   // ceil(per_xcd / rounds) workgroups on each of the 8 XCDs
+    }
     const int mw = c2b_mw(c_out);
     int rc;
     if (mw == 1) rc = c2b_launch<1>(p, grid_x, stream);
