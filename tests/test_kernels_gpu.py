@@ -4,6 +4,7 @@ Run on the MI355X box: python -m pytest tests -m gpu.  Tolerances are stated at 
 integer outputs (neighbour ids) are exact up to documented near-ties; waveforms are gated at the
 north_star's 1e-3 RMS with the observed error asserted far below it.
 """
+import ctypes
 import os
 import sys
 
@@ -607,6 +608,47 @@ def test_conv2d_bf16x3_matches_float64(native, dev, c_in, c_out, h, w, batch):
     assert (plain.double() - plain_ref).abs().max().item() <= 4e-6
     again = native.conv2d_bf16x3_forward(x.to(dev), u, None, c_out).cpu()
     assert torch.equal(plain, again)                # split-K partials are summed in a fixed order
+
+
+def test_conv2d_bf16x3_random_shape_sweep(native, dev):
+    """K10b on 40 seeded random shapes -- every supported (output-channel class, row length) pair with ragged heights from 1 row up,
+    batches of 1-3, maps on either side of "more tiles than CUs" (the persistent walk with XCD-contiguous ranges) and of the K-split
+    threshold, with and without bias / ReLU / skip path -- against F.conv2d in float64."""
+    rng = np.random.default_rng(20260)
+    n_split = n_persist = 0
+    for it in range(40):
+        c_out = int(rng.choice([3, 16, 32, 64, 128, 256]))
+        c_in = int(rng.choice([16, 32, 64, 128, 256]))
+        max_w = 128 if c_out <= 32 else (128 if c_out <= 64 else 64)
+        w = int(rng.choice([x for x in (4, 8, 16, 32, 64, 128) if x <= max_w]))
+        batch = int(rng.integers(1, 4))
+        h = int(rng.integers(1, max(2, min(3000, 600_000 // (w * max(c_in, c_out) * batch)))))
+        if it % 8 == 0:
+            c_in, c_out, w, batch, h = 16, 16, 128, 1, int(rng.integers(600, 1400))      # > 256 tiles: several per workgroup
+        g = torch.Generator().manual_seed(1000 + it)
+        x = torch.randn(batch, c_in, h, w, generator=g)
+        wt = torch.randn(c_out, c_in, 3, 3, generator=g) / (c_in * 9) ** 0.5
+        use_b, use_relu, use_res = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        b = torch.randn(c_out, generator=g) if use_b else None
+        res = torch.randn(batch, c_out, h, w, generator=g) if use_res else None
+        assert native.conv2d_bf16x3_supported(c_in, c_out, h, w), (c_in, c_out, h, w)
+        ref = F.conv2d(x.double(), wt.double(), b.double() if use_b else None, padding=1)
+        if use_relu: ref = F.relu(ref)
+        if use_res: ref = ref + res.double()
+        u = native.conv2d_bf16x3_pack_weight(wt, dev)
+        got = native.conv2d_bf16x3_forward(x.to(dev), u, b.to(dev) if use_b else None, c_out, relu=use_relu,
+                                           res=res.to(dev) if use_res else None).cpu()
+        err = (got.double() - ref).abs().max().item()
+        f32 = F.conv2d(x, wt, b, padding=1)                 # what fp32 arithmetic itself loses on this shape (grows with 9 C_in)
+        if use_relu: f32 = F.relu(f32)
+        if use_res: f32 = f32 + res
+        # six fp32 accumulations per multiply-add instead of one: up to ~sqrt(6) x the rounding walk of a plain fp32 conv; K10's own gate is 2e-5
+        assert err <= min(1.5e-5, max(4e-6, 6 * (f32.double() - ref).abs().max().item())), (it, c_in, c_out, h, w, batch, use_b, use_relu, use_res, err)
+        need = ctypes.c_size_t()
+        assert native._lib.rvc_conv2d_bf16x3_workspace_bytes(batch, c_in, c_out, h, w, ctypes.byref(need)) == 0
+        n_split += need.value > 0
+        n_persist += c_out <= 32 and batch * ((h * w + 255) // 256) > 256
+    assert n_split >= 3 and n_persist >= 3, (n_split, n_persist)       # the sweep reached both regimes
 
 
 @pytest.mark.parametrize("c_in,c_out,h,w,ks,batch", [
