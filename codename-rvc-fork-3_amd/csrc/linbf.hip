@@ -392,6 +392,16 @@ int linbf_dispatch(const char *who, const void *xs_dev, int64_t x_row_stride, in
         if (out_features % rows_per_block) return 1e30;
         return (double)ceil_div(cols * (out_features / rows_per_block) * k_parts, cus) * rel;
     };
+    // (ablation build, RVC_LBF_TP=1: pick the block height by CU TIME -- blocks x relative block time -- instead of rounds: what a
+    // launch costs while other streams' kernels fill the CUs it leaves idle)
+    static const int by_cu_time = knob("RVC_LBF_TP", 0);
+    if (by_cu_time) {
+        auto cu_time = [&](int rows_per_block, double rel) { return out_features % rows_per_block ? 1e30 : cols * (out_features / rows_per_block) * k_parts * rel; };
+        const double t128 = cu_time(128, 1.0), t192 = cu_time(192, 1.5 * 0.85), t256 = cu_time(256, 1.85);
+        if (t192 <= t128 && t192 <= t256) return linbf_launch<3>(p, k_parts, (hipStream_t)stream);
+        if (t256 < t128) return linbf_launch<4>(p, k_parts, (hipStream_t)stream);
+        return linbf_launch<2>(p, k_parts, (hipStream_t)stream);
+    }
     const double c128 = cost(128, 1.0), c192 = cost(192, 1.5 * 0.85), c256 = cost(256, 1.85);
     if (c256 < c128 && c256 <= c192) return linbf_launch<4>(p, k_parts, (hipStream_t)stream);
     const bool use192 = c192 < c128;
