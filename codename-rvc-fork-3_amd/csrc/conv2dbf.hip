@@ -13,8 +13,9 @@
 //     (HBM -> registers an item ahead -> split -> LDS) while the four COMPUTE waves multiply the previous chunk (resblock_bf.hip's
 //     division of labour); one barrier per chunk;
 //   * a compute wave owns 32 output channels x 64 pixels (two accumulators: twelve independent-in-pairs matrix instructions per
-//     tap); its tap fragments (taps split at load, 3 KiB per tap and chunk) go L2 -> registers through a ring of three taps that
-//     runs on into the next chunk / tile and never touch LDS;
+//     tap); its tap fragments (taps split at load, 3 KiB per tap and chunk) go L2 -> registers through a ring of NINE taps -- a tap's
+//     registers take the next chunk's (or tile's) fragments as soon as its products are issued: one whole item of lead -- and never
+//     touch LDS (a ring of three, two taps of lead: equal on the C -> C convs, 3-5 % slower on the 2 C -> C ones);
 //   * block = 32 MW channels x 64 (4 / MW) pixels, MW = 1 / 2 / 4 for 32 / 64 / >= 128 (padded) output channels; the workgroup
 //     owns its CU (common.h) and walks units = (pixel tile, channel block) persistently when the map has more of them than the chip
 //     has CUs (levels 0 and 1: 1504 / 376 units), deep levels split K over gridDim.y so that ~190-250 workgroups run, and
@@ -39,6 +40,7 @@ constexpr unsigned C2B_OOB = 0x80000000u;   // beyond every tensor this kernel t
 constexpr int C2B_CK = 16;                  // input channels per chunk = one 16-deep k step per tap
 constexpr int C2B_ROWB = 112;               // [split 3][channel 16] bf16 + 16 bytes
 constexpr int C2B_TAPS = 9;
+constexpr bool C2B_RING9 = true;          // tap-fragment ring of nine taps (one item of lead: L2 / HBM latency) instead of three (two taps)
 constexpr int C2B_GROUP = 3 * 1024;         // tap fragments of one (32-row block, chunk, tap): [split 3][lane 64][8 bf16]
 static_assert((C2B_ROWB / 16) % 2 == 1, "row stride must be an odd multiple of 16 bytes");
 
@@ -114,7 +116,7 @@ template <int MW, int DBG = 0, bool RES = false>
 __global__ void __launch_bounds__(C2B_NTH) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv2dbf_kernel(const C2bParams p) {
     using GM = C2bGeom<MW>;
-    constexpr int NW = GM::NW, BN = GM::BN, NJ = GM::NJ, ROWB = C2B_ROWB, TAPS = C2B_TAPS, PA = RES ? TAPS : 3;
+    constexpr int NW = GM::NW, BN = GM::BN, NJ = GM::NJ, ROWB = C2B_ROWB, TAPS = C2B_TAPS, PA = (RES || C2B_RING9) ? TAPS : 3;
     static_assert(TAPS % PA == 0, "a tap's ring slot must be a compile-time register index");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char c2b_smem[];
@@ -326,7 +328,7 @@ conv2dbf_kernel(const C2bParams p) {
     decode(0, b, pxt, mblk);
     int base_cur = item_base(mblk, 0);
     const unsigned vo_lane = 16u * (unsigned)lane;
-    if constexpr (RES) {
+    if constexpr (PA == TAPS) {
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) load_a(tap, vo_lane, base_cur, tap);
     } else {
@@ -366,8 +368,12 @@ conv2dbf_kernel(const C2bParams p) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (q < 6 && tap + 1 < TAPS) load_b1((tap + 1) & 1, src, tap + 1, q & 1, 2 - (q >> 1));
                     if (q == 11 && !RES) {
-                        if (tap + 2 < TAPS) load_a((tap + 2) % PA, vo_lane, base_cur, tap + 2);
-                        else load_a((tap + 2) % PA, vo_next, base_next, tap + 2 - TAPS);
+                        if constexpr (PA == TAPS) {
+                            load_a(tap, vo_next, base_next, tap);    // a ring of nine: this tap's registers take the NEXT item's tap -- a whole item of lead
+                        } else {
+                            if (tap + 2 < TAPS) load_a((tap + 2) % PA, vo_lane, base_cur, tap + 2);
+                            else load_a((tap + 2) % PA, vo_next, base_next, tap + 2 - TAPS);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
