@@ -40,6 +40,10 @@ constexpr unsigned C2B_OOB = 0x80000000u;   // beyond every tensor this kernel t
 constexpr int C2B_CK = 16;                  // input channels per chunk = one 16-deep k step per tap
 constexpr int C2B_ROWB = 112;               // [split 3][channel 16] bf16 + 16 bytes
 constexpr int C2B_TAPS = 9;
+#ifndef C2B_STAGER_PRIO
+#define C2B_STAGER_PRIO 0
+#define C2B_COMPUTE_PRIO 1
+#endif
 constexpr bool C2B_RING9 = true;          // tap-fragment ring of nine taps (one item of lead: L2 / HBM latency) instead of three (two taps)
 constexpr int C2B_GROUP = 3 * 1024;         // tap fragments of one (32-row block, chunk, tap): [split 3][lane 64][8 bf16]
 static_assert((C2B_ROWB / 16) % 2 == 1, "row stride must be an odd multiple of 16 bytes");
@@ -170,7 +174,7 @@ conv2dbf_kernel(const C2bParams p) {
 
     if (wave >= 4) {
         // ============================================ stagers: HBM -> LDS ================================================================
-        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(C2B_STAGER_PRIO);
         const int st = tid - 256;
         // The tile is whole rows of the map, so the patch's first and last columns are the conv's zero padding for every tile: they are
         // zeroed once (above) and only the (th + 2) W interior positions are staged -- interior position q = st + 256 j is row q / W,
@@ -297,6 +301,7 @@ conv2dbf_kernel(const C2bParams p) {
     }
 
     // ================================================ compute waves ==========================================================
+    __builtin_amdgcn_s_setprio(C2B_COMPUTE_PRIO);
     const int mw = wave % MW, nw = wave / MW;
     int pn[2], xl[2];
 #pragma unroll
