@@ -120,7 +120,7 @@ template <int MW, int DBG = 0, bool RES = false>
 __global__ void __launch_bounds__(C2B_NTH) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv2dbf_kernel(const C2bParams p) {
     using GM = C2bGeom<MW>;
-    constexpr int NW = GM::NW, BN = GM::BN, NJ = GM::NJ, ROWB = C2B_ROWB, TAPS = C2B_TAPS, PA = (RES || C2B_RING9) ? TAPS : 3;
+    constexpr int BN = GM::BN, NJ = GM::NJ, ROWB = C2B_ROWB, TAPS = C2B_TAPS, PA = (RES || C2B_RING9) ? TAPS : 3;
     static_assert(TAPS % PA == 0, "a tap's ring slot must be a compile-time register index");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char c2b_smem[];
@@ -131,7 +131,7 @@ conv2dbf_kernel(const C2bParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int W = p.W, H = p.H, HW = H * W, lw = p.log2w;
-    const int th = BN >> lw, PC = W + 2, PATCH = (th + 2) * PC;
+    const int th = BN >> lw, PC = W + 2;
     const int n_chunks = p.chunks_per_split, c_begin = (int)blockIdx.y * n_chunks;
     const int G = (int)gridDim.x;
     constexpr int dbg = DBG;
@@ -303,11 +303,11 @@ conv2dbf_kernel(const C2bParams p) {
     // ================================================ compute waves ==========================================================
     __builtin_amdgcn_s_setprio(C2B_COMPUTE_PRIO);
     const int mw = wave % MW, nw = wave / MW;
-    int pn[2], xl[2];
+    int xl[2];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
-        pn[cb] = nw * 64 + cb * 32 + l31;                     // this lane's pixel of the tile, and its position in the patch (tap (0, 0))
-        const int prw = pn[cb] >> lw, pcl = pn[cb] & (W - 1);
+        const int pn = nw * 64 + cb * 32 + l31;               // this lane's pixel of the tile, and its position in the patch (tap (0, 0))
+        const int prw = pn >> lw, pcl = pn & (W - 1);
         xl[cb] = (prw * PC + pcl) * ROWB + half * 16;
     }
     const int rowsh1 = PC * ROWB;
